@@ -1,0 +1,75 @@
+/* libymk_hip.so - C ABI of the MI355X (gfx950) DocumentAnalyzer hot path.
+ *
+ * The reference (kotaro-kinoshita/yomitoku) is pure Python and has no FFI.  The seam this
+ * ABI plugs into is the one its optional ONNX backend already uses: one call per network
+ * forward with C-contiguous buffers in and out
+ *   sess.run(["output"], {"input": ndarray})   text_detector.py:122-125,
+ *                                              text_recognizer.py:248-251,
+ *                                              layout_parser.py:252-258,
+ *                                              table_structure_recognizer.py:262-268
+ * and the `self.model(tensor)` call it stands in for (text_detector.py:127-129 etc.).
+ * INTEGRATION.md shows the ctypes stub a yomitoku maintainer would add.
+ *
+ * Rules
+ *   - plain pointers and sizes only; `stream` is a hipStream_t passed as void* (NULL = default);
+ *   - pointers named *_dev are device (HBM) addresses owned by the caller; the library owns
+ *     weights and workspace, and allocates nothing on the per-call path once a shape was seen;
+ *   - every function returns 0 on success, non-zero on failure; ymk_last_error() returns the
+ *     message of the calling thread's last failure;
+ *   - a model handle may be used from one thread at a time; different handles are independent.
+ */
+#ifndef YMK_H
+#define YMK_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ymk_model ymk_model;
+
+int ymk_version(void);
+const char* ymk_last_error(void);
+/* number of visible HIP devices, or -1 */
+int ymk_device_count(void);
+
+/* ---- model lifecycle (replaces BaseModule.load_model, base.py:80-86) -------------------
+ * kind: "dbnet" | "parseq" | "rtdetr".  Weights are handed over tensor by tensor under the
+ * reference's state-dict names (host fp32, C-contiguous), scalar hyper-parameters by name,
+ * then ymk_model_finalize() folds BatchNorm, repacks panels and uploads to `device`. */
+ymk_model* ymk_model_create(const char* kind, int device);
+void ymk_model_destroy(ymk_model* m);
+int ymk_model_set_param(ymk_model* m, const char* key, double value);
+int ymk_model_set_tensor(ymk_model* m, const char* name, const float* host_data, int ndim, const int64_t* dims);
+int ymk_model_finalize(ymk_model* m);
+/* bytes of HBM held by the model's weights / workspace */
+int64_t ymk_model_weight_bytes(const ymk_model* m);
+int64_t ymk_model_workspace_bytes(const ymk_model* m);
+
+/* ---- DBNet text detector (replaces DBNet.forward, models/dbnet_plus.py:243-246) --------
+ * x_dev: fp32 [n][3][h][w] (h, w multiples of 32, as TextDetector.preprocess produces);
+ * prob_dev: fp32 [n][1][h][w] = preds["binary"]. */
+int ymk_dbnet_forward(ymk_model* m, const float* x_dev, int n, int h, int w, float* prob_dev, void* stream);
+
+/* ---- measurement aid for bench.py (not on the product path): between begin/end every launch of
+ * the implicit-GEMM convolution kernel is bracketed by HIP events on its own stream; end returns
+ * the summed kernel time, the algorithmic FLOPs (2*M*Cout*KH*KW*Cin, unpadded) and launch count.
+ * Single-threaded use only. */
+int ymk_prof_begin(void);
+int ymk_prof_end(double* conv_ms, double* conv_flop, int64_t* conv_launches);
+
+/* ---- single operators (exported for the parity tests; same kernels the models use) -----
+ * NHWC fp32 tensors; weight in PyTorch OIHW order on the host. */
+int ymk_op_conv2d(const float* x_dev, int n, int h, int w, int c, /* c % 4 == 0, or c == 4 with tap4 */
+                  const float* w_host_oihw, int cout, int cin, int kh, int kw, const float* scale_host,
+                  const float* bias_host, const float* res_dev, int stride, int pad, int dil, int act, int tap4,
+                  float* y_dev, void* stream);
+int ymk_op_maxpool3x3s2(const float* x_dev, int n, int h, int w, int c, float* y_dev, void* stream);
+int ymk_op_upsample_bilinear(const float* x_dev, int n, int h, int w, int c, int oh, int ow, const float* add_dev,
+                             float* y_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YMK_H */

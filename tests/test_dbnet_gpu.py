@@ -1,0 +1,60 @@
+"""DBNet forward parity: HIP path (through ymk_dbnet_forward) vs the CPU oracle, same seeded
+weights and inputs.  Tolerance from BASELINE.json north_star: probability maps within 1e-3."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+PROB_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def nets(dev):
+    from yomitoku_amd.nets import DBNet
+    from yomitoku_amd.utils.synth import dbnet_state_dict
+
+    sd = dbnet_state_dict(1234)
+    net = DBNet().load_state_dict(sd).to(dev)
+    return sd, net
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 64, 96), (2, 3, 160, 128), (1, 3, 352, 288)])
+def test_prob_map_matches_oracle(dev, nets, shape):
+    from oracle.dbnet import dbnet_forward
+
+    sd, net = nets
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(shape[2]))
+    ref = dbnet_forward(sd, x)["binary"]
+    out = net(x.to(dev))["binary"].cpu()
+    assert out.shape == ref.shape
+    err = (out - ref).abs().max().item()
+    assert err < PROB_TOL, f"max |dP| = {err}"
+    # the map must not be trivially saturated, else the check above is vacuous
+    assert 0.05 < ref.mean().item() < 0.95 and ref.std().item() > 0.05
+
+
+def test_batch_consistency(dev, nets):
+    """A page's map does not depend on its batch mates (pages shard independently)."""
+    _, net = nets
+    x = torch.randn(3, 3, 96, 128, generator=torch.Generator().manual_seed(5)).to(dev)
+    full = net(x)["binary"]
+    for i in range(3):
+        single = net(x[i : i + 1])["binary"]
+        assert torch.equal(single[0], full[i])
+
+
+def test_golden_fixture(dev, nets):
+    import os
+
+    import numpy as np
+
+    p = os.path.join(os.path.dirname(__file__), "golden", "dbnet_ref_64x96.npz")
+    if not os.path.exists(p):
+        pytest.skip("golden fixture not generated")
+    z = np.load(p)
+    from yomitoku_amd.nets import DBNet
+    from yomitoku_amd.utils.synth import dbnet_state_dict
+
+    net = DBNet().load_state_dict(dbnet_state_dict(int(z["seed"]))).to(dev)
+    out = net(torch.from_numpy(z["x"]).to(dev))["binary"].cpu().numpy()
+    assert np.abs(out - z["prob"]).max() < PROB_TOL

@@ -1,0 +1,114 @@
+"""Per-kernel parity: HIP operators (through the C ABI) vs plain PyTorch fp32 on the CPU."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-4  # fp32 MFMA is an exact fmaf chain; the CPU reference sums in another order
+
+
+def _close(a, b, tol=TOL):
+    a = a.float().cpu()
+    b = b.float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item() + 1e-6
+    assert err <= tol * max(1.0, ref), f"max abs err {err} (ref max {ref})"
+
+
+def test_gemm_identity_asymmetric(dev):
+    """A = I against an asymmetric B catches a transposed C write (guide rule 16)."""
+    from yomitoku_amd import hipops
+
+    c = 64
+    x = torch.zeros(1, c, 8, 8)
+    for i in range(64):
+        x[0, i, i // 8, i % 8] = 1.0  # pixel p has one-hot channel p
+    w = torch.arange(c * c, dtype=torch.float32).reshape(c, c, 1, 1) / 100.0  # w[co][ci]
+    y = hipops.conv2d(x.to(dev), w)
+    _close(y, F.conv2d(x, w), 1e-6)
+
+
+CASES = [
+    # (n, cin, h, w, cout, k, stride, pad, dil)
+    (1, 64, 24, 40, 64, 1, 1, 0, 1),
+    (2, 64, 20, 28, 256, 1, 1, 0, 1),
+    (1, 256, 17, 23, 128, 1, 2, 0, 1),
+    (1, 64, 19, 21, 64, 3, 1, 1, 1),
+    (2, 128, 18, 22, 128, 3, 2, 1, 1),
+    (1, 512, 10, 12, 512, 3, 1, 2, 2),
+    (1, 32, 30, 34, 32, 3, 1, 1, 1),
+    (1, 32, 30, 34, 64, 3, 1, 1, 1),
+    (1, 96, 9, 11, 200, 1, 1, 0, 1),      # cin not a multiple of 32, cout ragged
+    (1, 4, 5, 7, 36, 1, 1, 0, 1),         # tiny K
+    (3, 256, 40, 48, 64, 3, 1, 1, 1),     # wide-M path (128x64 tiles)
+    (1, 1024, 26, 30, 2048, 1, 1, 0, 1),  # 128x128 tiles
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv2d_matches_torch(dev, case):
+    from yomitoku_amd import hipops
+
+    n, cin, h, w, cout, k, stride, pad, dil = case
+    g = torch.Generator().manual_seed(hash(case) % (2**31))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, wt, None, stride, pad, dil) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+    res = torch.randn(ref.shape, generator=g)
+    ref = F.relu(ref + res)
+    y = hipops.conv2d(x.to(dev), wt, scale, bias, res.to(dev), stride, pad, dil, "relu")
+    _close(y, ref)
+
+
+def test_stem_conv7x7_tap4(dev):
+    from yomitoku_amd import hipops
+
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 3, 64, 96, generator=g)
+    wt = torch.randn(64, 3, 7, 7, generator=g) / 12.0
+    y = hipops.conv2d(x.to(dev), wt, None, None, None, 2, 3, 1, "relu")
+    _close(y, F.relu(F.conv2d(x, wt, None, 2, 3)))
+
+
+def test_conv3x3_stem_tap4_s2(dev):
+    from yomitoku_amd import hipops
+
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(1, 3, 40, 40, generator=g)
+    wt = torch.randn(32, 3, 3, 3, generator=g) / 5.0
+    y = hipops.conv2d(x.to(dev), wt, None, None, None, 2, 1, 1, "none")
+    _close(y, F.conv2d(x, wt, None, 2, 1))
+
+
+@pytest.mark.parametrize("act", ["silu", "sigmoid", "gelu"])
+def test_conv_activations(dev, act):
+    from yomitoku_amd import hipops
+
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, 64, 12, 12, generator=g)
+    wt = torch.randn(64, 64, 1, 1, generator=g) / 8.0
+    ref = F.conv2d(x, wt)
+    ref = {"silu": F.silu, "sigmoid": torch.sigmoid, "gelu": F.gelu}[act](ref)
+    _close(hipops.conv2d(x.to(dev), wt, act=act), ref, 1e-5)
+
+
+def test_maxpool(dev):
+    from yomitoku_amd import hipops
+
+    x = torch.randn(2, 64, 33, 47, generator=torch.Generator().manual_seed(1))
+    _close(hipops.maxpool3x3s2(x.to(dev)), F.max_pool2d(x, 3, 2, 1), 0.0)
+
+
+@pytest.mark.parametrize("shape,size", [((1, 64, 10, 14), (20, 28)), ((2, 64, 7, 9), (28, 36)), ((1, 256, 9, 12), (18, 25))])
+def test_bilinear(dev, shape, size):
+    from yomitoku_amd import hipops
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(*shape, generator=g)
+    add = torch.randn(shape[0], shape[1], *size, generator=g)
+    ref = F.interpolate(x, size=size, mode="bilinear", align_corners=False) + add
+    _close(hipops.upsample_bilinear(x.to(dev), size, add.to(dev)), ref, 1e-6)

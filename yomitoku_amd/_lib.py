@@ -1,0 +1,92 @@
+"""ctypes binding of libymk_hip.so (the C ABI declared in include/ymk.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C yomitoku_amd/csrc``.
+There is no CPU fallback: if the shared object is missing or a call fails, this module raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libymk_hip.so")
+
+# name -> (restype, argtypes); kept in one table so tests can check every symbol of ymk.h exists
+SIGNATURES = {
+    "ymk_version": (c_int, []),
+    "ymk_last_error": (c_char_p, []),
+    "ymk_device_count": (c_int, []),
+    "ymk_model_create": (c_void_p, [c_char_p, c_int]),
+    "ymk_model_destroy": (None, [c_void_p]),
+    "ymk_model_set_param": (c_int, [c_void_p, c_char_p, c_double]),
+    "ymk_model_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, c_int, POINTER(c_int64)]),
+    "ymk_model_finalize": (c_int, [c_void_p]),
+    "ymk_model_weight_bytes": (c_int64, [c_void_p]),
+    "ymk_model_workspace_bytes": (c_int64, [c_void_p]),
+    "ymk_dbnet_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ymk_prof_begin": (c_int, []),
+    "ymk_prof_end": (c_int, [POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
+    "ymk_op_conv2d": (
+        c_int,
+        [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+         c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    ),
+    "ymk_op_maxpool3x3s2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ymk_op_upsample_bilinear": (
+        c_int,
+        [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    ),
+}
+
+_lib = None
+
+
+class YmkError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libymk_hip.so once; raises YmkError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise YmkError(
+            f"{LIB_PATH} not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C yomitoku_amd/csrc` (there is no CPU fallback)"
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = "ymk call"):
+    if status != 0:
+        msg = load().ymk_last_error()
+        raise YmkError(f"{what} failed: {msg.decode('utf-8', 'replace') if msg else status}")
+
+
+def ptr(t):
+    """Device/host address of a torch tensor (must be contiguous) or None."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def current_stream_ptr():
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dims_array(shape):
+    arr = (c_int64 * max(1, len(shape)))(*[int(s) for s in shape])
+    return arr

@@ -1,0 +1,167 @@
+// extern "C" surface of libymk_hip.so (declared in include/ymk.h).
+#include "../../include/ymk.h"
+#include "ymk_common.h"
+
+namespace ymk {
+const std::string& last_error();
+void dbnet_forward(Model* m, const float* x, int n, int h, int w, float* prob, hipStream_t s);
+void prof_begin();
+void prof_end(double* ms, double* flop, int64_t* launches);
+}  // namespace ymk
+
+struct ymk_model {
+  ymk::Model* impl = nullptr;
+  int device = 0;
+};
+
+#define YMK_API_BEGIN try {
+#define YMK_API_END                                 \
+  return 0;                                         \
+  }                                                 \
+  catch (const std::exception& e) {                 \
+    ymk::set_error(e.what());                       \
+    return 1;                                       \
+  }                                                 \
+  catch (...) {                                     \
+    ymk::set_error("unknown C++ exception");        \
+    return 2;                                       \
+  }
+
+extern "C" {
+
+int ymk_version(void) { return 100; }
+
+const char* ymk_last_error(void) { return ymk::last_error().c_str(); }
+
+int ymk_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+  return n;
+}
+
+ymk_model* ymk_model_create(const char* kind, int device) {
+  try {
+    YMK_CHECK(kind != nullptr, "kind is null");
+    YMK_HIP(hipSetDevice(device));
+    std::string k(kind);
+    ymk::Model* impl = nullptr;
+    if (k == "dbnet") impl = ymk::create_dbnet();
+    else throw ymk::Error("unknown model kind: " + k);
+    auto* m = new ymk_model();
+    m->impl = impl;
+    m->device = device;
+    return m;
+  } catch (const std::exception& e) {
+    ymk::set_error(e.what());
+    return nullptr;
+  }
+}
+
+void ymk_model_destroy(ymk_model* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  delete m->impl;
+  delete m;
+}
+
+int ymk_model_set_param(ymk_model* m, const char* key, double value) {
+  YMK_API_BEGIN
+  YMK_CHECK(m && key, "null argument");
+  m->impl->params[key] = value;
+  YMK_API_END
+}
+
+int ymk_model_set_tensor(ymk_model* m, const char* name, const float* host_data, int ndim, const int64_t* dims) {
+  YMK_API_BEGIN
+  YMK_CHECK(m && name && host_data && (ndim == 0 || dims), "null argument");
+  YMK_CHECK(!m->impl->finalized, "model already finalized");
+  m->impl->ws.put(name, host_data, ndim, dims);
+  YMK_API_END
+}
+
+int ymk_model_finalize(ymk_model* m) {
+  YMK_API_BEGIN
+  YMK_CHECK(m, "null model");
+  YMK_HIP(hipSetDevice(m->device));
+  m->impl->finalize();
+  YMK_API_END
+}
+
+int64_t ymk_model_weight_bytes(const ymk_model* m) { return m ? (int64_t)m->impl->pool.bytes() : -1; }
+int64_t ymk_model_workspace_bytes(const ymk_model* m) { return m ? (int64_t)m->impl->arena.capacity() : -1; }
+
+int ymk_dbnet_forward(ymk_model* m, const float* x_dev, int n, int h, int w, float* prob_dev, void* stream) {
+  YMK_API_BEGIN
+  YMK_CHECK(m && x_dev && prob_dev, "null argument");
+  YMK_HIP(hipSetDevice(m->device));
+  ymk::dbnet_forward(m->impl, x_dev, n, h, w, prob_dev, (hipStream_t)stream);
+  YMK_API_END
+}
+
+int ymk_prof_begin(void) {
+  YMK_API_BEGIN
+  ymk::prof_begin();
+  YMK_API_END
+}
+
+int ymk_prof_end(double* conv_ms, double* conv_flop, int64_t* conv_launches) {
+  YMK_API_BEGIN
+  YMK_CHECK(conv_ms && conv_flop && conv_launches, "null argument");
+  ymk::prof_end(conv_ms, conv_flop, conv_launches);
+  YMK_API_END
+}
+
+// ------------------------------------------------------------------ single operators
+int ymk_op_conv2d(const float* x_dev, int n, int h, int w, int c, const float* w_host_oihw, int cout, int cin, int kh,
+                  int kw, const float* scale_host, const float* bias_host, const float* res_dev, int stride, int pad,
+                  int dil, int act, int tap4, float* y_dev, void* stream) {
+  YMK_API_BEGIN
+  using namespace ymk;
+  DevicePool pool;
+  ConvW cw;
+  cw.cout = cout;
+  cw.cin = tap4 ? 4 : cin;
+  cw.kh = kh;
+  cw.kw = kw;
+  cw.mode = tap4 ? 1 : 0;
+  std::vector<float> panel;
+  pack_conv_weight(w_host_oihw, cout, cin, kh, kw, tap4 != 0, panel, cw.kpad, cw.ctiles);
+  cw.w = pool.upload(panel);
+  if (scale_host) cw.scale = pool.upload(scale_host, cout);
+  if (bias_host) cw.bias = pool.upload(bias_host, cout);
+  Tensor in{const_cast<float*>(x_dev), n, h, w, c, c};
+  const int oh = conv_out_dim(h, kh, stride, pad, dil), ow = conv_out_dim(w, kw, stride, pad, dil);
+  Tensor out{y_dev, n, oh, ow, cout, cout};
+  Tensor res{const_cast<float*>(res_dev), n, oh, ow, cout, cout};
+  ConvArgs a;
+  a.stride = stride;
+  a.pad = pad;
+  a.dil = dil;
+  a.act = act;
+  a.res = res_dev ? &res : nullptr;
+  conv2d((hipStream_t)stream, in, cw, a, out);
+  YMK_HIP(hipStreamSynchronize((hipStream_t)stream));  // pool frees the panel on return
+  YMK_API_END
+}
+
+int ymk_op_maxpool3x3s2(const float* x_dev, int n, int h, int w, int c, float* y_dev, void* stream) {
+  YMK_API_BEGIN
+  using namespace ymk;
+  Tensor in{const_cast<float*>(x_dev), n, h, w, c, c};
+  Tensor out{y_dev, n, (h + 2 - 3) / 2 + 1, (w + 2 - 3) / 2 + 1, c, c};
+  maxpool3x3s2((hipStream_t)stream, in, out);
+  YMK_API_END
+}
+
+int ymk_op_upsample_bilinear(const float* x_dev, int n, int h, int w, int c, int oh, int ow, const float* add_dev,
+                             float* y_dev, void* stream) {
+  YMK_API_BEGIN
+  using namespace ymk;
+  Tensor in{const_cast<float*>(x_dev), n, h, w, c, c};
+  Tensor out{y_dev, n, oh, ow, c, c};
+  Tensor add{const_cast<float*>(add_dev), n, oh, ow, c, c};
+  upsample_bilinear((hipStream_t)stream, in, out, add_dev ? &add : nullptr);
+  YMK_API_END
+}
+
+}  // extern "C"

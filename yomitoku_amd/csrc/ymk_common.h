@@ -1,0 +1,189 @@
+// Internal header of libymk_hip.so (gfx950 only). Not part of the C ABI.
+//
+// Conventions
+//   * activations live in HBM as NHWC fp32 ("pixel-major": one pixel's channels are
+//     contiguous) with an explicit pixel stride `ld` so a tensor may be a channel slice
+//     of a wider concat buffer;
+//   * weights are repacked once at load into the K-major panel layout ymk_conv.hip wants;
+//   * nothing on the per-call path allocates: every model owns an Arena sized at first use.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include <cmath>
+
+namespace ymk {
+
+void set_error(const std::string& msg);
+
+struct Error : public std::runtime_error {
+  explicit Error(const std::string& m) : std::runtime_error(m) {}
+};
+
+#define YMK_HIP(expr)                                                                 \
+  do {                                                                                \
+    hipError_t e__ = (expr);                                                          \
+    if (e__ != hipSuccess) {                                                          \
+      throw ::ymk::Error(std::string(#expr) + " failed: " + hipGetErrorString(e__) +  \
+                         " at " + __FILE__ + ":" + std::to_string(__LINE__));         \
+    }                                                                                 \
+  } while (0)
+
+#define YMK_CHECK(cond, msg)                                                          \
+  do {                                                                                \
+    if (!(cond)) throw ::ymk::Error(std::string("check failed: ") + #cond + ": " + (msg)); \
+  } while (0)
+
+// ---------------------------------------------------------------- tensors
+struct Tensor {
+  float* p = nullptr;
+  int n = 0, h = 0, w = 0, c = 0;
+  int ld = 0;  // floats between consecutive pixels (>= c)
+  size_t pixels() const { return (size_t)n * h * w; }
+  Tensor slice_c(int c0, int cn) const {
+    Tensor t = *this;
+    t.p = p + c0;
+    t.c = cn;
+    return t;
+  }
+};
+
+// Bump allocator over one hipMalloc'd slab. reset() at the start of a forward.
+class Arena {
+ public:
+  ~Arena();
+  void reserve(size_t bytes);  // grows (re-allocates) if needed; only legal when empty
+  void reset() { off_ = 0; }
+  float* alloc_f(size_t count);
+  void* alloc_bytes(size_t bytes);
+  Tensor tensor(int n, int h, int w, int c);
+  size_t used() const { return off_; }
+  size_t high_water() const { return high_; }
+  size_t capacity() const { return cap_; }
+  bool dry_run = false;  // when true only measures (returns fake pointers)
+ private:
+  char* base_ = nullptr;
+  size_t cap_ = 0, off_ = 0, high_ = 0;
+};
+
+// ---------------------------------------------------------------- activations
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_SIGMOID = 3, ACT_GELU = 4 };
+
+// ---------------------------------------------------------------- conv / linear
+// Packed weight panel for the implicit-GEMM kernel (ymk_conv.hip).
+//   mode 0 ("chunk"): K runs tap-major, each tap owns ctiles*32 slots (channels zero padded)
+//   mode 1 ("tap4") : input has exactly 4 channels per pixel; K = tap*4 + c, padded to 32
+struct ConvW {
+  float* w = nullptr;      // [cout][kpad] device
+  float* scale = nullptr;  // [cout] or null (folded BN gamma/sqrt(var+eps))
+  float* bias = nullptr;   // [cout] or null
+  int cout = 0, cin = 0, kh = 1, kw = 1;
+  int kpad = 0, ctiles = 0, mode = 0;
+};
+
+enum Epi : int { EPI_STORE = 0, EPI_DECONV2X2 = 1 };
+
+struct ConvArgs {
+  int stride = 1, pad = 0, dil = 1;
+  int act = ACT_NONE;
+  int epi = EPI_STORE;
+  const Tensor* res = nullptr;  // residual added before the activation
+};
+
+// out must be pre-shaped (n, oh, ow, cout[, ld]); for EPI_DECONV2X2 out is (n, 2h, 2w, cout/4).
+void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, const Tensor& out);
+
+// Host-side packing: OIHW fp32 -> panel. `cin_pad4` packs for the tap4 mode (cin<=4).
+void pack_conv_weight(const float* oihw, int cout, int cin, int kh, int kw, bool tap4,
+                      std::vector<float>& panel, int& kpad, int& ctiles);
+
+inline int conv_out_dim(int in, int k, int stride, int pad, int dil) {
+  return (in + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+}
+
+// ---------------------------------------------------------------- elementwise (ymk_elem.hip)
+void nchw3_to_nhwc4(hipStream_t s, const float* in, int n, int h, int w, const Tensor& out);
+void maxpool3x3s2(hipStream_t s, const Tensor& in, const Tensor& out);
+// out = bilinear_resize(in -> out dims, align_corners=False) [+ add]   (torch F.interpolate)
+void upsample_bilinear(hipStream_t s, const Tensor& in, const Tensor& out, const Tensor* add);
+void upsample_nearest2x(hipStream_t s, const Tensor& in, const Tensor& out);
+void avgpool2x2_ceil(hipStream_t s, const Tensor& in, const Tensor& out);
+// per-image per-channel mean over h*w: out[n][c]; scratch = GAP_CHUNKS*n*c floats
+constexpr int GAP_CHUNKS = 256;
+void global_avgpool(hipStream_t s, const Tensor& in, float* scratch, float* out_nc);
+void add_act(hipStream_t s, const Tensor& a, const Tensor& b, int act, const Tensor& out);
+
+// Adaptive-scale-fusion pieces (DBNet++), see ymk_dbnet.cpp
+void asf_channel_gate(hipStream_t s, const float* gap_nc, const float* w1, const float* w2, int n,
+                      int c, int cmid, float* gate_nc);
+void asf_channel_mean(hipStream_t s, const Tensor& x, const float* gate_nc, float* mean_nhw);
+void asf_apply(hipStream_t s, const Tensor& x, const float* gate_nc, const float* mean_nhw,
+               const float* w_sp3x3, float w_sp1x1, const float* w_att /*[4][c]*/,
+               const Tensor& fuse /*4*c ch*/, const Tensor& out);
+// final ConvTranspose2d(c->1, 2, 2) + bias + sigmoid: in (n,h,w,c) -> out plane (n, 2h, 2w)
+void deconv2x2_to1_sigmoid(hipStream_t s, const Tensor& in, const float* w_c4 /*[c][4]*/, float bias,
+                           float* out);
+
+// ---------------------------------------------------------------- weight store
+struct HostTensor {
+  std::vector<int64_t> dims;
+  std::vector<float> data;
+  size_t numel() const { return data.size(); }
+};
+
+class WeightStore {
+ public:
+  void put(const std::string& name, const float* data, int ndim, const int64_t* dims);
+  const HostTensor& get(const std::string& name) const;
+  bool has(const std::string& name) const { return t_.count(name) != 0; }
+  void clear() { t_.clear(); }
+  size_t size() const { return t_.size(); }
+ private:
+  std::map<std::string, HostTensor> t_;
+};
+
+// Device buffer pool owned by a model (weights). Freed with the model.
+class DevicePool {
+ public:
+  ~DevicePool();
+  float* upload(const std::vector<float>& v);
+  float* upload(const float* p, size_t n);
+  float* alloc(size_t n);
+  size_t bytes() const { return bytes_; }
+ private:
+  std::vector<void*> ptrs_;
+  size_t bytes_ = 0;
+};
+
+// conv (+ optional BatchNorm folded to scale/bias) from a state-dict
+ConvW make_conv(DevicePool& pool, const WeightStore& ws, const std::string& conv_prefix,
+                const std::string& bn_prefix /* "" = none */, bool tap4 = false, float bn_eps = 1e-5f);
+// nn.Linear(in,out): weight [out][in] (+bias) -> 1x1 conv panel
+ConvW make_linear(DevicePool& pool, const WeightStore& ws, const std::string& prefix, bool has_bias = true);
+ConvW make_linear_raw(DevicePool& pool, const float* w_out_in, const float* bias, int out, int in);
+
+// ---------------------------------------------------------------- models
+class Model {
+ public:
+  virtual ~Model() {}
+  virtual const char* kind() const = 0;
+  virtual void finalize() = 0;
+  WeightStore ws;
+  std::map<std::string, double> params;
+  double param(const std::string& k, double dflt) const {
+    auto it = params.find(k);
+    return it == params.end() ? dflt : it->second;
+  }
+  DevicePool pool;
+  Arena arena;
+  bool finalized = false;
+};
+
+Model* create_dbnet();
+
+}  // namespace ymk

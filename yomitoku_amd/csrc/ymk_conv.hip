@@ -1,0 +1,368 @@
+// Implicit-GEMM convolution / linear layer for gfx950 (CDNA4), exact fp32 on the matrix cores.
+//
+// Replaces the ATen conv2d / linear calls of the reference's nets
+// (models/dbnet_plus.py:33-38,56-127; models/layers/rtdetr_backbone.py; parseq_transformer.py).
+//
+//   out[m][co] = act( scale[co] * sum_k A[m][k] * Wp[co][k] + bias[co] + res[m][co] )
+//
+//   m  = (n, oh, ow) output pixel           (GEMM M, NHWC so a pixel's channels are contiguous)
+//   k  = (kh, kw, c) filter tap x channel   (GEMM K, gathered on the fly - no im2col buffer)
+//   co = output channel                     (GEMM N)
+//
+// Matrix instruction: v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate, bit-identical to an fmaf
+// chain in k order; 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak). Operand layout (guide §3):
+//   A: lane l holds A[i = l&31][k = l>>5],  B: lane l holds B[k = l>>5][j = l&31],
+//   D: lane l, reg r holds D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+// K is consumed in chunks of 8 with the in-chunk order permuted so that each half-wave reads
+// 4 consecutive k with one ds_read_b128: step s of chunk kc multiplies k = kc*8 + 4*(l>>5) + s.
+//
+// Block = 256 threads = 4 waves; block tile BM x BN, K tile 32, LDS rows padded to 36 floats
+// (144 B = 9 x 16 B slots: the 16-lane groups of ds_read_b128 hit 16 distinct slots, guide G4).
+// Global -> register -> LDS double buffering, one barrier per K tile.
+// blockIdx is remapped so that each XCD (private L2) owns a contiguous range of tiles, n fastest,
+// i.e. the blocks that re-read one A row panel run on the same L2 (guide T1, bijective form).
+#include "ymk_common.h"
+
+namespace ymk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvK {
+  const float* in;
+  const float* w;
+  const float* scale;
+  const float* bias;
+  const float* res;
+  float* out;
+  int H, W, C, in_ld;
+  int OH, OW, Cout, out_ld, res_ld;
+  int KH, KW, stride, pad, dil;
+  int Kpad, ctiles, mode;
+  int M;        // n*oh*ow
+  int act, epi;
+  int ntiles_n;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case ACT_RELU: return fmaxf(v, 0.f);
+    case ACT_SILU: return v / (1.f + __expf(-v));
+    case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    default: return v;
+  }
+}
+
+constexpr int LDK = 36;  // padded K-tile row (floats)
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm(ConvK p) {
+  static_assert(WM * WN == 4, "4 waves per block");
+  constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
+  constexpr int TM = WTM / 32, TN = WTN / 32;  // 32x32 MFMA tiles per wave
+  constexpr int APASS = BM / 32, BPASS = BN / 32;
+  constexpr int STAGE = (BM + BN) * LDK;
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+  const int t = threadIdx.x;
+  // XCD-aware bijective remap of the block id (block b runs on XCD b % 8)
+  int tile;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = tile / p.ntiles_n, tile_n = tile - tile_m * p.ntiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- staging coordinates: thread loads 16 B (4 k) of row (t>>3)+32*i
+  const int colq = t & 7, rowb = t >> 3;
+  int pixb[APASS], ih0[APASS], iw0[APASS];
+#pragma unroll
+  for (int i = 0; i < APASS; ++i) {
+    const int m = m0 + rowb + 32 * i;
+    if (m < p.M) {
+      const int ohw = p.OH * p.OW;
+      const int n = m / ohw, rem = m - n * ohw;
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      pixb[i] = n * p.H * p.W;
+      ih0[i] = oh * p.stride - p.pad;
+      iw0[i] = ow * p.stride - p.pad;
+    } else {
+      pixb[i] = 0;
+      ih0[i] = -(1 << 28);  // fails every bounds test
+      iw0[i] = 0;
+    }
+  }
+
+  float4 ra[APASS], rb[BPASS];
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  auto load_tile = [&](int kt) {
+    int kh, kw, c;
+    bool tapok;
+    if (p.mode == 0) {
+      const int tap = kt / p.ctiles, cc = kt - tap * p.ctiles;
+      kh = tap / p.KW;
+      kw = tap - kh * p.KW;
+      c = cc * 32 + colq * 4;
+      tapok = c < p.C;
+    } else {
+      const int tap = kt * 8 + colq;
+      kh = tap / p.KW;
+      kw = tap - kh * p.KW;
+      c = 0;
+      tapok = tap < p.KH * p.KW;
+    }
+    const int dh = kh * p.dil, dw = kw * p.dil;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      const int ih = ih0[i] + dh, iw = iw0[i] + dw;
+      const bool ok = tapok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      if (ok) {
+        const size_t pix = (size_t)(pixb[i] + ih * p.W + iw);
+        ra[i] = *reinterpret_cast<const float4*>(p.in + pix * p.in_ld + c);
+      } else {
+        ra[i] = zero4;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) {
+      const int co = n0 + rowb + 32 * j;
+      if (co < p.Cout) {
+        rb[j] = *reinterpret_cast<const float4*>(p.w + (size_t)co * p.Kpad + kt * 32 + colq * 4);
+      } else {
+        rb[j] = zero4;
+      }
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    float* As = lds + buf * STAGE;
+    float* Bs = As + BM * LDK;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i)
+      *reinterpret_cast<float4*>(As + (rowb + 32 * i) * LDK + colq * 4) = ra[i];
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j)
+      *reinterpret_cast<float4*>(Bs + (rowb + 32 * j) * LDK + colq * 4) = rb[j];
+  };
+
+  // ---- MFMA coordinates
+  const int wv = t >> 6, lane = t & 63;
+  const int wm = wv / WN, wn = wv - wm * WN;
+  const int li = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int ktiles = p.Kpad >> 5;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < ktiles) load_tile(kt + 1);
+
+    const float* As = lds + buf * STAGE + (wm * WTM + li) * LDK + lh * 4;
+    const float* Bs = lds + buf * STAGE + BM * LDK + (wn * WTN + li) * LDK + lh * 4;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      float4 fa[TM], fb[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+        fa[a] = *reinterpret_cast<const float4*>(As + a * 32 * LDK + kc * 8);
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+        fb[b] = *reinterpret_cast<const float4*>(Bs + b * 32 * LDK + kc * 8);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, fb[b].x, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, fb[b].y, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, fb[b].z, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
+        }
+    }
+
+    if (kt + 1 < ktiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: D[row][col]: col = lane&31 (channel, contiguous 128 B per half-wave)
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int co = n0 + wn * WTN + b * 32 + li;
+    if (co >= p.Cout) continue;
+    const float sc = p.scale ? p.scale[co] : 1.f;
+    const float bi = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int m = m0 + wm * WTM + a * 32 + row;
+        if (m >= p.M) continue;
+        float v = acc[a][b][r] * sc + bi;
+        if (p.epi == EPI_STORE) {
+          if (p.res) v += p.res[(size_t)m * p.res_ld + co];
+          v = apply_act(v, p.act);
+          p.out[(size_t)m * p.out_ld + co] = v;
+        } else {  // ConvTranspose2d(k=2, s=2): co = (a2*2+b2)*Cq + cq  ->  pixel (2oh+a2, 2ow+b2)
+          const int cq_n = p.Cout >> 2;
+          const int ab = co / cq_n, cq = co - ab * cq_n;
+          const int ohw = p.OH * p.OW;
+          const int n = m / ohw, rem = m - n * ohw;
+          const int oh = rem / p.OW, ow = rem - oh * p.OW;
+          const size_t opix = ((size_t)n * (2 * p.OH) + 2 * oh + (ab >> 1)) * (2 * p.OW) + 2 * ow + (ab & 1);
+          v = apply_act(v, p.act);
+          p.out[opix * p.out_ld + cq] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream
+struct ProfState {
+  bool on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  size_t used = 0;
+  double flop = 0.0;
+};
+static ProfState g_prof;
+
+void prof_begin() {
+  g_prof.on = true;
+  g_prof.used = 0;
+  g_prof.flop = 0.0;
+}
+void prof_end(double* ms, double* flop, int64_t* launches) {
+  double total = 0.0;
+  for (size_t i = 0; i < g_prof.used; ++i) {
+    YMK_HIP(hipEventSynchronize(g_prof.ev[i].second));
+    float t = 0.f;
+    YMK_HIP(hipEventElapsedTime(&t, g_prof.ev[i].first, g_prof.ev[i].second));
+    total += t;
+  }
+  *ms = total;
+  *flop = g_prof.flop;
+  *launches = (int64_t)g_prof.used;
+  g_prof.on = false;
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch(hipStream_t s, ConvK& k) {
+  const int mt = (k.M + BM - 1) / BM, nt = (k.Cout + BN - 1) / BN;
+  k.ntiles_n = nt;
+  std::pair<hipEvent_t, hipEvent_t>* e = nullptr;
+  if (g_prof.on) {
+    if (g_prof.used == g_prof.ev.size()) {
+      std::pair<hipEvent_t, hipEvent_t> n;
+      YMK_HIP(hipEventCreate(&n.first));
+      YMK_HIP(hipEventCreate(&n.second));
+      g_prof.ev.push_back(n);
+    }
+    e = &g_prof.ev[g_prof.used++];
+    const int creal = k.mode == 0 ? k.C : 3;
+    g_prof.flop += 2.0 * (double)k.M * (double)k.Cout * (double)(k.KH * k.KW * creal);
+    YMK_HIP(hipEventRecord(e->first, s));
+  }
+  hipLaunchKernelGGL((conv_igemm<BM, BN, WM, WN>), dim3(mt * nt), dim3(256), 0, s, k);
+  if (e) YMK_HIP(hipEventRecord(e->second, s));
+}
+
+void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, const Tensor& out) {
+  ConvK k;
+  k.in = in.p;
+  k.w = w.w;
+  k.scale = w.scale;
+  k.bias = w.bias;
+  k.res = a.res ? a.res->p : nullptr;
+  k.res_ld = a.res ? a.res->ld : 0;
+  k.out = out.p;
+  k.H = in.h;
+  k.W = in.w;
+  k.C = in.c;
+  k.in_ld = in.ld;
+  k.KH = w.kh;
+  k.KW = w.kw;
+  k.stride = a.stride;
+  k.pad = a.pad;
+  k.dil = a.dil;
+  k.OH = conv_out_dim(in.h, w.kh, a.stride, a.pad, a.dil);
+  k.OW = conv_out_dim(in.w, w.kw, a.stride, a.pad, a.dil);
+  k.Cout = w.cout;
+  k.out_ld = out.ld;
+  k.Kpad = w.kpad;
+  k.ctiles = w.ctiles;
+  k.mode = w.mode;
+  k.M = in.n * k.OH * k.OW;
+  k.act = a.act;
+  k.epi = a.epi;
+  YMK_CHECK(w.w != nullptr, "conv weight not packed");
+  if (w.mode == 0) {
+    YMK_CHECK(in.c == w.cin, "conv: input channels " + std::to_string(in.c) + " != weight cin " + std::to_string(w.cin));
+    YMK_CHECK(in.c % 4 == 0 && in.ld % 4 == 0, "conv: channels/ld must be multiples of 4");
+  } else {
+    YMK_CHECK(in.c == 4 && in.ld == 4, "conv tap4 mode wants a 4-channel packed input");
+  }
+  YMK_CHECK(((uintptr_t)in.p & 15) == 0, "conv: input not 16B aligned");
+  if (a.epi == EPI_STORE) {
+    YMK_CHECK(out.n == in.n && out.h == k.OH && out.w == k.OW && out.c == w.cout, "conv: bad output shape");
+    if (a.res) YMK_CHECK(a.res->n == out.n && a.res->h == out.h && a.res->w == out.w && a.res->c == out.c, "conv: bad residual shape");
+  } else {
+    YMK_CHECK(w.kh == 1 && w.kw == 1 && a.stride == 1 && a.pad == 0, "deconv epilogue wants a 1x1 panel");
+    YMK_CHECK(out.n == in.n && out.h == 2 * in.h && out.w == 2 * in.w && out.c * 4 == w.cout, "deconv: bad output shape");
+  }
+  if (k.M == 0) return;
+
+  // tile selection: wide tiles when there is enough work to fill 256 CUs x 2 blocks
+  const long blocks128 = (long)((k.M + 127) / 128) * ((w.cout + 127) / 128);
+  if (w.cout <= 32) {
+    launch<128, 32, 4, 1>(s, k);
+  } else if (w.cout <= 64) {
+    if ((k.M + 127) / 128 >= 256) launch<128, 64, 2, 2>(s, k);
+    else launch<64, 64, 2, 2>(s, k);
+  } else if (blocks128 >= 384) {
+    launch<128, 128, 2, 2>(s, k);
+  } else {
+    const long blocks64 = (long)((k.M + 127) / 128) * ((w.cout + 63) / 64);
+    if (blocks64 >= 256) launch<128, 64, 2, 2>(s, k);
+    else launch<64, 64, 2, 2>(s, k);
+  }
+  YMK_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ host packing
+void pack_conv_weight(const float* oihw, int cout, int cin, int kh, int kw, bool tap4,
+                      std::vector<float>& panel, int& kpad, int& ctiles) {
+  const int taps = kh * kw;
+  if (tap4) {
+    YMK_CHECK(cin <= 4, "tap4 packing wants cin <= 4");
+    ctiles = 0;
+    kpad = ((taps * 4 + 31) / 32) * 32;
+    panel.assign((size_t)cout * kpad, 0.f);
+    for (int co = 0; co < cout; ++co)
+      for (int c = 0; c < cin; ++c)
+        for (int tp = 0; tp < taps; ++tp)
+          panel[(size_t)co * kpad + tp * 4 + c] = oihw[((size_t)co * cin + c) * taps + tp];
+  } else {
+    ctiles = (cin + 31) / 32;
+    kpad = taps * ctiles * 32;
+    panel.assign((size_t)cout * kpad, 0.f);
+    for (int co = 0; co < cout; ++co)
+      for (int c = 0; c < cin; ++c)
+        for (int tp = 0; tp < taps; ++tp)
+          panel[(size_t)co * kpad + (size_t)tp * ctiles * 32 + c] = oihw[((size_t)co * cin + c) * taps + tp];
+  }
+}
+
+}  // namespace ymk

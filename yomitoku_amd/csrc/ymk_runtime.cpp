@@ -1,0 +1,142 @@
+// Host runtime of libymk_hip.so: error slot, arena, weight store, state-dict -> packed panels.
+#include "ymk_common.h"
+#include <cmath>
+
+namespace ymk {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+const std::string& last_error() { return g_err; }
+
+// ---------------------------------------------------------------- Arena
+Arena::~Arena() {
+  if (base_) (void)hipFree(base_);
+}
+void Arena::reserve(size_t bytes) {
+  if (bytes <= cap_) return;
+  YMK_CHECK(off_ == 0, "arena reserve while in use");
+  if (base_) YMK_HIP(hipFree(base_));
+  base_ = nullptr;
+  cap_ = 0;
+  YMK_HIP(hipMalloc((void**)&base_, bytes));
+  cap_ = bytes;
+}
+void* Arena::alloc_bytes(size_t bytes) {
+  const size_t a = (bytes + 255) & ~(size_t)255;
+  const size_t at = off_;
+  off_ += a;
+  if (off_ > high_) high_ = off_;
+  if (dry_run) return (void*)(uintptr_t)(4096 + at);  // aligned fake address, never dereferenced
+  YMK_CHECK(off_ <= cap_, "arena overflow: need " + std::to_string(off_) + " have " + std::to_string(cap_));
+  return base_ + at;
+}
+float* Arena::alloc_f(size_t count) { return (float*)alloc_bytes(count * sizeof(float)); }
+Tensor Arena::tensor(int n, int h, int w, int c) {
+  Tensor t;
+  t.n = n;
+  t.h = h;
+  t.w = w;
+  t.c = c;
+  t.ld = c;
+  t.p = alloc_f((size_t)n * h * w * c);
+  return t;
+}
+
+// ---------------------------------------------------------------- DevicePool
+DevicePool::~DevicePool() {
+  for (void* p : ptrs_) (void)hipFree(p);
+}
+float* DevicePool::alloc(size_t n) {
+  void* p = nullptr;
+  const size_t b = (n ? n : 1) * sizeof(float);
+  YMK_HIP(hipMalloc(&p, b));
+  ptrs_.push_back(p);
+  bytes_ += b;
+  return (float*)p;
+}
+float* DevicePool::upload(const float* src, size_t n) {
+  float* d = alloc(n);
+  if (n) YMK_HIP(hipMemcpy(d, src, n * sizeof(float), hipMemcpyHostToDevice));
+  return d;
+}
+float* DevicePool::upload(const std::vector<float>& v) { return upload(v.data(), v.size()); }
+
+// ---------------------------------------------------------------- WeightStore
+void WeightStore::put(const std::string& name, const float* data, int ndim, const int64_t* dims) {
+  HostTensor t;
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    t.dims.push_back(dims[i]);
+    n *= (size_t)dims[i];
+  }
+  t.data.assign(data, data + n);
+  t_[name] = std::move(t);
+}
+const HostTensor& WeightStore::get(const std::string& name) const {
+  auto it = t_.find(name);
+  if (it == t_.end()) throw Error("missing weight tensor: " + name);
+  return it->second;
+}
+
+// ---------------------------------------------------------------- packing helpers
+ConvW make_conv(DevicePool& pool, const WeightStore& ws, const std::string& conv_prefix, const std::string& bn_prefix,
+                bool tap4, float bn_eps) {
+  const HostTensor& w = ws.get(conv_prefix + ".weight");
+  YMK_CHECK(w.dims.size() == 4, conv_prefix + ".weight must be OIHW");
+  ConvW c;
+  c.cout = (int)w.dims[0];
+  c.cin = (int)w.dims[1];
+  c.kh = (int)w.dims[2];
+  c.kw = (int)w.dims[3];
+  c.mode = tap4 ? 1 : 0;
+  std::vector<float> panel;
+  pack_conv_weight(w.data.data(), c.cout, c.cin, c.kh, c.kw, tap4, panel, c.kpad, c.ctiles);
+  if (tap4) c.cin = 4;
+  c.w = pool.upload(panel);
+  std::vector<float> scale, bias;
+  const bool has_cb = ws.has(conv_prefix + ".bias");
+  if (!bn_prefix.empty()) {
+    // eval BatchNorm: y = (x - mean) / sqrt(var + eps) * gamma + beta    (x may carry a conv bias)
+    const HostTensor& g = ws.get(bn_prefix + ".weight");
+    const HostTensor& b = ws.get(bn_prefix + ".bias");
+    const HostTensor& m = ws.get(bn_prefix + ".running_mean");
+    const HostTensor& v = ws.get(bn_prefix + ".running_var");
+    YMK_CHECK((int)g.numel() == c.cout, bn_prefix + ": channel mismatch");
+    scale.resize(c.cout);
+    bias.resize(c.cout);
+    for (int i = 0; i < c.cout; ++i) {
+      const float s = g.data[i] / std::sqrt(v.data[i] + bn_eps);
+      const float cb = has_cb ? ws.get(conv_prefix + ".bias").data[i] : 0.f;
+      scale[i] = s;
+      bias[i] = b.data[i] + (cb - m.data[i]) * s;
+    }
+    c.scale = pool.upload(scale);
+    c.bias = pool.upload(bias);
+  } else if (has_cb) {
+    c.bias = pool.upload(ws.get(conv_prefix + ".bias").data);
+  }
+  return c;
+}
+
+ConvW make_linear_raw(DevicePool& pool, const float* w_out_in, const float* bias, int out, int in) {
+  ConvW c;
+  c.cout = out;
+  c.cin = in;
+  c.kh = c.kw = 1;
+  c.mode = 0;
+  std::vector<float> panel;
+  pack_conv_weight(w_out_in, out, in, 1, 1, false, panel, c.kpad, c.ctiles);
+  c.w = pool.upload(panel);
+  if (bias) c.bias = pool.upload(bias, out);
+  return c;
+}
+
+ConvW make_linear(DevicePool& pool, const WeightStore& ws, const std::string& prefix, bool has_bias) {
+  const HostTensor& w = ws.get(prefix + ".weight");
+  YMK_CHECK(w.dims.size() == 2, prefix + ".weight must be [out][in]");
+  const float* b = nullptr;
+  if (has_bias && ws.has(prefix + ".bias")) b = ws.get(prefix + ".bias").data.data();
+  return make_linear_raw(pool, w.data.data(), b, (int)w.dims[0], (int)w.dims[1]);
+}
+
+}  // namespace ymk

@@ -1,0 +1,107 @@
+"""Page sharding across the GPUs of one node.
+
+The reference has no distributed code: pages are independent units (cli/main.py:116-120 loops
+them sequentially).  Here every rank (one process per GPU) holds a full replica of the models and
+takes a strided share of the pages; the only collective is a one-off broadcast of the packed
+checkpoint from rank 0 (RCCL over xGMI when the backend is "nccl"), so that weights are read /
+generated once.  There is no collective on the per-page path.
+"""
+
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+from typing import List, Mapping, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend: str | None = None):
+    """Initialise torch.distributed from the torchrun environment (no-op for world size 1)."""
+    rank, local_rank, world = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
+    """Round-robin page assignment: item i goes to rank i % world (keeps ranks within one page
+    of each other for any n_items)."""
+    return list(range(rank, n_items, world))
+
+
+def gather_in_order(local: Sequence, n_items: int, rank: int, world: int) -> list | None:
+    """Inverse of shard_indices for picklable per-page results: rank 0 gets the full list in page
+    order (host-side gather of Python objects; not a data-path collective)."""
+    if world == 1:
+        return list(local)
+    out = [None] * world if rank == 0 else None
+    dist.gather_object(list(local), out, dst=0)
+    if rank != 0:
+        return None
+    merged = [None] * n_items
+    for r, part in enumerate(out):
+        for j, idx in enumerate(shard_indices(n_items, r, world)):
+            merged[idx] = part[j]
+    return merged
+
+
+def broadcast_state_dict(sd: Mapping[str, torch.Tensor] | None, src: int = 0, device=None):
+    """Broadcast a checkpoint from `src` as ONE flat fp32 message (+ a tiny int64 one).
+
+    Rank `src` passes the state dict, the others pass None and receive an identical copy (CPU
+    tensors).  The flat buffer lives on `device` during the collective: with the nccl backend that
+    is the rank's GPU, so the ~0.1-0.5 GB message travels over xGMI, not through the host.
+    """
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return sd
+    rank = dist.get_rank()
+    meta = [None]
+    if rank == src:
+        meta[0] = [(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in sd.items()]
+    dist.broadcast_object_list(meta, src=src)
+    meta = meta[0]
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    f_numel = sum(int(torch.Size(s).numel()) for _, s, d in meta if d.startswith("float"))
+    i_numel = sum(int(torch.Size(s).numel()) for _, s, d in meta if not d.startswith("float"))
+    fbuf = torch.empty(f_numel, dtype=torch.float32, device=device)
+    ibuf = torch.empty(max(i_numel, 1), dtype=torch.int64, device=device)
+    if rank == src:
+        fo = io = 0
+        for k, s, d in meta:
+            v = sd[k]
+            n = v.numel()
+            if d.startswith("float"):
+                fbuf[fo : fo + n] = v.reshape(-1).to(device=device, dtype=torch.float32)
+                fo += n
+            else:
+                ibuf[io : io + n] = v.reshape(-1).to(device=device, dtype=torch.int64)
+                io += n
+    dist.broadcast(fbuf, src=src)
+    dist.broadcast(ibuf, src=src)
+    if rank == src:
+        return sd
+    out = OrderedDict()
+    fcpu, icpu = fbuf.cpu(), ibuf.cpu()
+    fo = io = 0
+    for k, s, d in meta:
+        n = int(torch.Size(s).numel())
+        if d.startswith("float"):
+            out[k] = fcpu[fo : fo + n].reshape(s).to(getattr(torch, d)).clone()
+            fo += n
+        else:
+            out[k] = icpu[io : io + n].reshape(s).to(getattr(torch, d)).clone()
+            io += n
+    return out

@@ -1,0 +1,84 @@
+"""Thin Python entry points to single HIP operators of libymk_hip.so (NHWC fp32 on device).
+
+They exist so the parity tests can exercise exactly the kernels the models use, one at a time.
+Inputs/outputs here are NCHW torch tensors on a HIP device; the layout change is done with torch.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+ACT = {"none": 0, "relu": 1, "silu": 2, "sigmoid": 3, "gelu": 4}
+
+
+def _nhwc(x: torch.Tensor) -> torch.Tensor:
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _nchw(x: torch.Tensor) -> torch.Tensor:
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def conv2d(x, weight, scale=None, bias=None, residual=None, stride=1, padding=0, dilation=1, act="none"):
+    """y = act(scale * conv(x, weight) + bias + residual); x NCHW on device, weight OIHW (any device)."""
+    lib = _lib.load()
+    assert x.is_cuda
+    n, c, h, w = x.shape
+    cout, cin, kh, kw = weight.shape
+    assert cin == c
+    tap4 = c <= 4
+    xh = _nhwc(x.float())
+    if tap4 and c < 4:
+        xh = torch.cat([xh, xh.new_zeros(n, h, w, 4 - c)], dim=-1).contiguous()
+    cpad = xh.shape[-1]
+    if not tap4 and cpad % 4:
+        raise ValueError("channels must be a multiple of 4")
+    oh = (h + 2 * padding - dilation * (kh - 1) - 1) // stride + 1
+    ow = (w + 2 * padding - dilation * (kw - 1) - 1) // stride + 1
+    y = torch.empty((n, oh, ow, cout), dtype=torch.float32, device=x.device)
+    wh = weight.detach().float().cpu().contiguous()
+    sh = scale.detach().float().cpu().contiguous() if scale is not None else None
+    bh = bias.detach().float().cpu().contiguous() if bias is not None else None
+    rh = _nhwc(residual.float()) if residual is not None else None
+    with torch.cuda.device(x.device):
+        _lib.check(
+            lib.ymk_op_conv2d(
+                xh.data_ptr(), n, h, w, cpad, wh.data_ptr(), cout, cin, kh, kw, _lib.ptr(sh), _lib.ptr(bh),
+                _lib.ptr(rh), stride, padding, dilation, ACT[act], 1 if tap4 else 0, y.data_ptr(),
+                _lib.current_stream_ptr(),
+            ),
+            "ymk_op_conv2d",
+        )
+    return _nchw(y)
+
+
+def maxpool3x3s2(x):
+    lib = _lib.load()
+    n, c, h, w = x.shape
+    xh = _nhwc(x.float())
+    y = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(
+            lib.ymk_op_maxpool3x3s2(xh.data_ptr(), n, h, w, c, y.data_ptr(), _lib.current_stream_ptr()),
+            "ymk_op_maxpool3x3s2",
+        )
+    return _nchw(y)
+
+
+def upsample_bilinear(x, size, add=None):
+    lib = _lib.load()
+    n, c, h, w = x.shape
+    oh, ow = size
+    xh = _nhwc(x.float())
+    ah = _nhwc(add.float()) if add is not None else None
+    y = torch.empty((n, oh, ow, c), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(
+            lib.ymk_op_upsample_bilinear(
+                xh.data_ptr(), n, h, w, c, oh, ow, _lib.ptr(ah), y.data_ptr(), _lib.current_stream_ptr()
+            ),
+            "ymk_op_upsample_bilinear",
+        )
+    return _nchw(y)

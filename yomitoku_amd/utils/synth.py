@@ -1,0 +1,148 @@
+"""Seeded synthetic checkpoints and inputs.
+
+There is no network in the build/bench environment, so the pretrained safetensors of the
+reference cannot be fetched.  These generators produce state dicts with exactly the reference's
+parameter names and shapes, drawn from a seeded CPU generator so that the oracle,
+the HIP path and the golden fixtures all see identical bytes.  The draws are variance preserving
+(fan-in scaled convolutions, near-identity BatchNorm statistics, damped residual branches) so
+that activations stay O(1) through 50 layers and the probability map / logits are not saturated -
+otherwise a parity test would be vacuous.
+"""
+
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+
+class _Draw:
+    def __init__(self, seed: int):
+        self.g = torch.Generator(device="cpu")
+        self.g.manual_seed(int(seed))
+
+    def normal(self, shape, std=1.0, mean=0.0):
+        return torch.randn(*shape, generator=self.g, dtype=torch.float32) * std + mean
+
+    def uniform(self, shape, lo, hi):
+        return torch.rand(*shape, generator=self.g, dtype=torch.float32) * (hi - lo) + lo
+
+
+def _conv(sd, d, name, cout, cin, k, bias=False, gain=2.0, kw=None):
+    kw = k if kw is None else kw
+    fan_in = cin * k * kw
+    sd[name + ".weight"] = d.normal((cout, cin, k, kw), std=math.sqrt(gain / fan_in))
+    if bias:
+        sd[name + ".bias"] = d.normal((cout,), std=0.05)
+
+
+def _bn(sd, d, name, c, gamma=(0.8, 1.2)):
+    sd[name + ".weight"] = d.uniform((c,), *gamma)
+    sd[name + ".bias"] = d.normal((c,), std=0.05)
+    sd[name + ".running_mean"] = d.normal((c,), std=0.05)
+    sd[name + ".running_var"] = d.uniform((c,), 0.8, 1.2)
+    sd[name + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.int64)
+
+
+def dbnet_state_dict(seed: int = 1234, hidden: int = 256) -> "OrderedDict[str, torch.Tensor]":
+    """State dict of DBNet (reference models/dbnet_plus.py; torchvision resnet50 naming)."""
+    d = _Draw(seed)
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    bb = "backbone.body."
+    _conv(sd, d, bb + "conv1", 64, 3, 7)
+    _bn(sd, d, bb + "bn1", 64)
+    inplanes = 64
+    for li, (planes, blocks) in enumerate(zip((64, 128, 256, 512), (3, 4, 6, 3)), start=1):
+        for bi in range(blocks):
+            p = f"{bb}layer{li}.{bi}."
+            _conv(sd, d, p + "conv1", planes, inplanes, 1)
+            _bn(sd, d, p + "bn1", planes)
+            _conv(sd, d, p + "conv2", planes, planes, 3)
+            _bn(sd, d, p + "bn2", planes)
+            _conv(sd, d, p + "conv3", planes * 4, planes, 1)
+            _bn(sd, d, p + "bn3", planes * 4, gamma=(0.2, 0.4))  # damped residual branch
+            if bi == 0:
+                _conv(sd, d, p + "downsample.0", planes * 4, inplanes, 1, gain=1.0)
+                _bn(sd, d, p + "downsample.1", planes * 4)
+            inplanes = planes * 4
+    dec = "decoder."
+    q = hidden // 4
+    for li, cin in enumerate((256, 512, 1024, 2048), start=1):
+        _conv(sd, d, f"{dec}input_proj.layer{li}", hidden, cin, 1, gain=1.0)
+    _conv(sd, d, dec + "out_proj.layer1", q, hidden, 3, gain=1.0)
+    for li in (2, 3, 4):
+        _conv(sd, d, f"{dec}out_proj.layer{li}.0", q, hidden, 3, gain=1.0)
+
+    def head(prefix, cin):
+        _conv(sd, d, prefix + ".0", q, cin, 3)
+        _bn(sd, d, prefix + ".1", q)
+        # ConvTranspose2d weights are [in][out][kh][kw]
+        sd[prefix + ".3.weight"] = d.normal((q, q, 2, 2), std=math.sqrt(2.0 / q))
+        sd[prefix + ".3.bias"] = d.normal((q,), std=0.05)
+        _bn(sd, d, prefix + ".4", q)
+        sd[prefix + ".6.weight"] = d.normal((q, 1, 2, 2), std=math.sqrt(1.0 / q) * 0.6)
+        sd[prefix + ".6.bias"] = d.normal((1,), std=0.05) - 0.5
+
+    head(dec + "binarize", hidden)
+    # the `thresh` head exists in the checkpoint (adaptive=True, serial=True) but never runs in forward
+    _conv(sd, d, dec + "thresh.0", q, hidden + 1, 3)
+    _bn(sd, d, dec + "thresh.1", q)
+    sd[dec + "thresh.3.weight"] = d.normal((q, q, 2, 2), std=math.sqrt(2.0 / q))
+    sd[dec + "thresh.3.bias"] = d.normal((q,), std=0.05)
+    _bn(sd, d, dec + "thresh.4", q)
+    sd[dec + "thresh.6.weight"] = d.normal((q, 1, 2, 2), std=math.sqrt(1.0 / q))
+    sd[dec + "thresh.6.bias"] = d.normal((1,), std=0.05)
+    ca = dec + "concat_attention."
+    _conv(sd, d, ca + "conv", q, hidden, 3, bias=True, gain=1.0)
+    ea = ca + "enhanced_attention."
+    _conv(sd, d, ea + "channel_wise.1", q // 4, q, 1)
+    _conv(sd, d, ea + "channel_wise.3", q, q // 4, 1)
+    _conv(sd, d, ea + "spatial_wise.0", 1, 1, 3)
+    _conv(sd, d, ea + "spatial_wise.2", 1, 1, 1)
+    _conv(sd, d, ea + "attention_wise.0", 4, q, 1, gain=1.0)
+    return sd
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic inputs
+def synthetic_page(seed: int = 0, height: int = 1600, width: int = 1200) -> np.ndarray:
+    """uint8 BGR page: light background with dark text-like line blocks, a ruled table and a
+    textured figure block.  Deterministic for a given (seed, height, width)."""
+    rng = np.random.default_rng(seed)
+    img = np.clip(rng.normal(245.0, 3.0, size=(height, width, 3)), 0, 255).astype(np.uint8)
+    n_lines = int(rng.integers(40, 121))
+    y = int(rng.integers(20, 60))
+    for _ in range(n_lines):
+        lh = int(rng.integers(16, 49))
+        if y + lh + 10 >= height:
+            break
+        x0 = int(rng.integers(20, max(21, width // 6)))
+        lw = int(rng.integers(80, min(1000, width - x0 - 20) + 1))
+        x = x0
+        while x < x0 + lw:  # glyph-like strokes
+            gw = int(rng.integers(max(4, lh // 3), lh + 1))
+            gx1 = min(x + gw, x0 + lw)
+            ink = int(rng.integers(10, 70))
+            block = img[y : y + lh, x:gx1]
+            stroke = rng.random((lh, gx1 - x)) < 0.55
+            block[stroke] = ink
+            x = gx1 + int(rng.integers(2, max(3, lh // 4)))
+        y += lh + int(rng.integers(6, 30))
+    for _ in range(int(rng.integers(0, 3))):  # ruled tables
+        th, tw = int(rng.integers(120, 360)), int(rng.integers(300, width - 100))
+        ty, tx = int(rng.integers(0, height - th)), int(rng.integers(0, width - tw))
+        rows, cols = int(rng.integers(2, 7)), int(rng.integers(2, 6))
+        img[ty : ty + th, tx : tx + tw] = 250
+        for r in range(rows + 1):
+            yy = ty + (th - 2) * r // rows
+            img[yy : yy + 2, tx : tx + tw] = 30
+        for c in range(cols + 1):
+            xx = tx + (tw - 2) * c // cols
+            img[ty : ty + th, xx : xx + 2] = 30
+    if rng.random() < 0.5:  # figure block
+        fh, fw = int(rng.integers(150, 400)), int(rng.integers(200, 500))
+        fy, fx = int(rng.integers(0, height - fh)), int(rng.integers(0, width - fw))
+        img[fy : fy + fh, fx : fx + fw] = rng.integers(0, 256, size=(fh, fw, 3), dtype=np.uint8)
+    return img
