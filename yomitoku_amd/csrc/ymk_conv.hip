@@ -41,6 +41,8 @@ struct ConvK {
   int M;        // n*oh*ow
   int act, epi;
   int ntiles_n;
+  unsigned in_bytes;  // extent of the input view (buffer descriptor range)
+  int vec;      // 1: Cout, leading dims and pointers allow 16 B epilogue accesses
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -55,13 +57,22 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 constexpr int LDK = 36;  // padded K-tile row (floats)
 
-template <int BM, int BN, int WM, int WN>
+// A-operand gathers go through a raw buffer descriptor: padding taps and tail rows use an offset
+// beyond num_records, for which the hardware returns zeros - no branch, no select after the load,
+// so the loaded registers flow straight to ds_write and their wait can sit after the MFMAs.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in SSA registers
+constexpr unsigned OOB_OFFSET = 0xFFFFFFF0u;
+
+template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_igemm(ConvK p) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;  // 32x32 MFMA tiles per wave
   constexpr int APASS = BM / 32, BPASS = BN / 32;
   constexpr int STAGE = (BM + BN) * LDK;
+  constexpr int LDC = BN + 4;  // epilogue staging row (floats)
+  static_assert(BM * LDC <= 2 * STAGE, "epilogue tile must fit the staging LDS");
   __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
   const int t = threadIdx.x;
@@ -90,51 +101,55 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvK p) {
       iw0[i] = ow * p.stride - p.pad;
     } else {
       pixb[i] = 0;
-      ih0[i] = -(1 << 28);  // fails every bounds test
+      ih0[i] = -(1 << 20);  // fails every bounds test
       iw0[i] = 0;
     }
   }
+  // weight rows of this thread (the panel is zero padded to a multiple of 128 rows)
+  const float* wrow = p.w + (size_t)(n0 + rowb) * p.Kpad + colq * 4;
 
-  float4 ra[APASS], rb[BPASS];
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+  f32x4 ra[APASS], rb[BPASS];
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
+  // K-tile cursor (wave-uniform, kept in scalar registers): tap (kh, kw) and channel tile cc
+  int cur_kh = 0, cur_kw = 0, cur_cc = 0;
+
+  // branch-free gather of one K tile: out-of-image / padded taps read a safe address and are zeroed
   auto load_tile = [&](int kt) {
-    int kh, kw, c;
+    int dh, dw, c;
     bool tapok;
-    if (p.mode == 0) {
-      const int tap = kt / p.ctiles, cc = kt - tap * p.ctiles;
-      kh = tap / p.KW;
-      kw = tap - kh * p.KW;
-      c = cc * 32 + colq * 4;
+    if (MODE == 0) {
+      dh = cur_kh * p.dil;
+      dw = cur_kw * p.dil;
+      c = cur_cc * 32 + colq * 4;
       tapok = c < p.C;
+      if (++cur_cc == p.ctiles) {
+        cur_cc = 0;
+        if (++cur_kw == p.KW) {
+          cur_kw = 0;
+          ++cur_kh;
+        }
+      }
     } else {
       const int tap = kt * 8 + colq;
-      kh = tap / p.KW;
-      kw = tap - kh * p.KW;
+      const int kh = tap / p.KW, kw = tap - kh * p.KW;
+      dh = kh * p.dil;
+      dw = kw * p.dil;
       c = 0;
       tapok = tap < p.KH * p.KW;
     }
-    const int dh = kh * p.dil, dw = kw * p.dil;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
       const int ih = ih0[i] + dh, iw = iw0[i] + dw;
       const bool ok = tapok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-      if (ok) {
-        const size_t pix = (size_t)(pixb[i] + ih * p.W + iw);
-        ra[i] = *reinterpret_cast<const float4*>(p.in + pix * p.in_ld + c);
-      } else {
-        ra[i] = zero4;
-      }
+      const unsigned off = ((unsigned)(pixb[i] + ih * p.W + iw) * (unsigned)p.in_ld + (unsigned)c) * 4u;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok ? off : OOB_OFFSET), 0, 0);
+      ra[i] = __builtin_bit_cast(f32x4, v);
     }
 #pragma unroll
-    for (int j = 0; j < BPASS; ++j) {
-      const int co = n0 + rowb + 32 * j;
-      if (co < p.Cout) {
-        rb[j] = *reinterpret_cast<const float4*>(p.w + (size_t)co * p.Kpad + kt * 32 + colq * 4);
-      } else {
-        rb[j] = zero4;
-      }
-    }
+    for (int j = 0; j < BPASS; ++j)
+      rb[j] = *reinterpret_cast<const f32x4*>(wrow + (size_t)(32 * j) * p.Kpad + kt * 32);
   };
 
   auto store_tile = [&](int buf) {
@@ -142,10 +157,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvK p) {
     float* Bs = As + BM * LDK;
 #pragma unroll
     for (int i = 0; i < APASS; ++i)
-      *reinterpret_cast<float4*>(As + (rowb + 32 * i) * LDK + colq * 4) = ra[i];
+      *reinterpret_cast<f32x4*>(As + (rowb + 32 * i) * LDK + colq * 4) = ra[i];
 #pragma unroll
     for (int j = 0; j < BPASS; ++j)
-      *reinterpret_cast<float4*>(Bs + (rowb + 32 * j) * LDK + colq * 4) = rb[j];
+      *reinterpret_cast<f32x4*>(Bs + (rowb + 32 * j) * LDK + colq * 4) = rb[j];
   };
 
   // ---- MFMA coordinates
@@ -174,13 +189,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvK p) {
     const float* Bs = lds + buf * STAGE + BM * LDK + (wn * WTN + li) * LDK + lh * 4;
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) {
-      float4 fa[TM], fb[TN];
+      f32x4 fa[TM], fb[TN];
 #pragma unroll
       for (int a = 0; a < TM; ++a)
-        fa[a] = *reinterpret_cast<const float4*>(As + a * 32 * LDK + kc * 8);
+        fa[a] = *reinterpret_cast<const f32x4*>(As + a * 32 * LDK + kc * 8);
 #pragma unroll
       for (int b = 0; b < TN; ++b)
-        fb[b] = *reinterpret_cast<const float4*>(Bs + b * 32 * LDK + kc * 8);
+        fb[b] = *reinterpret_cast<const f32x4*>(Bs + b * 32 * LDK + kc * 8);
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -196,35 +211,73 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvK p) {
     __syncthreads();
   }
 
-  // ---- epilogue: D[row][col]: col = lane&31 (channel, contiguous 128 B per half-wave)
+  // ---- epilogue: accumulators -> LDS tile [BM][LDC] -> 16 B per lane, full rows coalesced.
+  // D[row][col]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* Cs = lds;
 #pragma unroll
-  for (int b = 0; b < TN; ++b) {
-    const int co = n0 + wn * WTN + b * 32 + li;
-    if (co >= p.Cout) continue;
-    const float sc = p.scale ? p.scale[co] : 1.f;
-    const float bi = p.bias ? p.bias[co] : 0.f;
+  for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int a = 0; a < TM; ++a) {
+    for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int m = m0 + wm * WTM + a * 32 + row;
-        if (m >= p.M) continue;
-        float v = acc[a][b][r] * sc + bi;
-        if (p.epi == EPI_STORE) {
-          if (p.res) v += p.res[(size_t)m * p.res_ld + co];
-          v = apply_act(v, p.act);
-          p.out[(size_t)m * p.out_ld + co] = v;
-        } else {  // ConvTranspose2d(k=2, s=2): co = (a2*2+b2)*Cq + cq  ->  pixel (2oh+a2, 2ow+b2)
-          const int cq_n = p.Cout >> 2;
-          const int ab = co / cq_n, cq = co - ab * cq_n;
-          const int ohw = p.OH * p.OW;
-          const int n = m / ohw, rem = m - n * ohw;
-          const int oh = rem / p.OW, ow = rem - oh * p.OW;
-          const size_t opix = ((size_t)n * (2 * p.OH) + 2 * oh + (ab >> 1)) * (2 * p.OW) + 2 * ow + (ab & 1);
-          v = apply_act(v, p.act);
-          p.out[opix * p.out_ld + cq] = v;
+        const int row = wm * WTM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        Cs[row * LDC + wn * WTN + b * 32 + li] = acc[a][b][r];
+      }
+  __syncthreads();
+
+  constexpr int TPR = BN / 4;        // threads per output row
+  constexpr int RPP = 256 / TPR;     // rows per pass
+  const int c4 = t % TPR, r0 = t / TPR;
+  const int co = n0 + c4 * 4;
+  if (co >= p.Cout) return;
+  const int ohw = p.OH * p.OW;
+  if (p.vec) {
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = zero4;
+    if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + co);
+    if (p.bias) bi = *reinterpret_cast<const float4*>(p.bias + co);
+    int cq = co, ab = 0;
+    if (p.epi == EPI_DECONV2X2) {
+      const int cq_n = p.Cout >> 2;
+      ab = co / cq_n;
+      cq = co - ab * cq_n;
+    }
+#pragma unroll 4
+    for (int row = r0; row < BM; row += RPP) {
+      const int m = m0 + row;
+      if (m >= p.M) break;
+      float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + c4 * 4);
+      v.x = v.x * sc.x + bi.x;
+      v.y = v.y * sc.y + bi.y;
+      v.z = v.z * sc.z + bi.z;
+      v.w = v.w * sc.w + bi.w;
+      size_t o;
+      if (p.epi == EPI_STORE) {
+        if (p.res) {
+          const float4 rr = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.res_ld + co);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
         }
+        o = (size_t)m * p.out_ld + co;
+      } else {  // ConvTranspose2d(k=2, s=2): co = (a2*2+b2)*Cq + cq -> pixel (2oh+a2, 2ow+b2)
+        const int n = m / ohw, rem = m - n * ohw;
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        const size_t opix = ((size_t)n * (2 * p.OH) + 2 * oh + (ab >> 1)) * (2 * p.OW) + 2 * ow + (ab & 1);
+        o = opix * p.out_ld + cq;
+      }
+      v.x = apply_act(v.x, p.act);
+      v.y = apply_act(v.y, p.act);
+      v.z = apply_act(v.z, p.act);
+      v.w = apply_act(v.w, p.act);
+      *reinterpret_cast<float4*>(p.out + o) = v;
+    }
+  } else {  // ragged Cout / unaligned rows: scalar stores (EPI_STORE only)
+    for (int row = r0; row < BM; row += RPP) {
+      const int m = m0 + row;
+      if (m >= p.M) break;
+      for (int e = 0; e < 4 && co + e < p.Cout; ++e) {
+        float v = Cs[row * LDC + c4 * 4 + e];
+        v = v * (p.scale ? p.scale[co + e] : 1.f) + (p.bias ? p.bias[co + e] : 0.f);
+        if (p.res) v += p.res[(size_t)m * p.res_ld + co + e];
+        p.out[(size_t)m * p.out_ld + co + e] = apply_act(v, p.act);
       }
     }
   }
@@ -236,6 +289,8 @@ struct ProfState {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   size_t used = 0;
   double flop = 0.0;
+  std::vector<std::string> desc;
+  std::vector<double> lflop;
 };
 static ProfState g_prof;
 
@@ -251,6 +306,9 @@ void prof_end(double* ms, double* flop, int64_t* launches) {
     float t = 0.f;
     YMK_HIP(hipEventElapsedTime(&t, g_prof.ev[i].first, g_prof.ev[i].second));
     total += t;
+    if (getenv("YMK_PROF_DUMP"))
+      fprintf(stderr, "[ymk-prof] %3zu %s  %8.1f us  %6.1f TFLOP/s\n", i, g_prof.desc[i].c_str(), t * 1e3,
+              g_prof.lflop[i] / (t * 1e-3) / 1e12);
   }
   *ms = total;
   *flop = g_prof.flop;
@@ -258,7 +316,7 @@ void prof_end(double* ms, double* flop, int64_t* launches) {
   g_prof.on = false;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int MODE = 0>
 static void launch(hipStream_t s, ConvK& k) {
   const int mt = (k.M + BM - 1) / BM, nt = (k.Cout + BN - 1) / BN;
   k.ntiles_n = nt;
@@ -272,10 +330,17 @@ static void launch(hipStream_t s, ConvK& k) {
     }
     e = &g_prof.ev[g_prof.used++];
     const int creal = k.mode == 0 ? k.C : 3;
-    g_prof.flop += 2.0 * (double)k.M * (double)k.Cout * (double)(k.KH * k.KW * creal);
+    const double fl = 2.0 * (double)k.M * (double)k.Cout * (double)(k.KH * k.KW * creal);
+    g_prof.flop += fl;
+    char buf[160];
+    snprintf(buf, sizeof buf, "M=%7d Cin=%4d Cout=%4d k=%dx%d s=%d d=%d tile=%dx%d grid=%d", k.M, k.C, k.Cout, k.KH, k.KW,
+             k.stride, k.dil, BM, BN, mt * nt);
+    if (g_prof.desc.size() < g_prof.used) { g_prof.desc.resize(g_prof.used); g_prof.lflop.resize(g_prof.used); }
+    g_prof.desc[g_prof.used - 1] = buf;
+    g_prof.lflop[g_prof.used - 1] = fl;
     YMK_HIP(hipEventRecord(e->first, s));
   }
-  hipLaunchKernelGGL((conv_igemm<BM, BN, WM, WN>), dim3(mt * nt), dim3(256), 0, s, k);
+  hipLaunchKernelGGL((conv_igemm<BM, BN, WM, WN, MODE>), dim3(mt * nt), dim3(256), 0, s, k);
   if (e) YMK_HIP(hipEventRecord(e->second, s));
 }
 
@@ -323,10 +388,25 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
     YMK_CHECK(out.n == in.n && out.h == 2 * in.h && out.w == 2 * in.w && out.c * 4 == w.cout, "deconv: bad output shape");
   }
   if (k.M == 0) return;
+  {
+    const size_t ib = ((in.pixels() - 1) * (size_t)in.ld + in.c) * sizeof(float);
+    YMK_CHECK(ib < (size_t)OOB_OFFSET, "conv input view must stay below 4 GiB (split the batch)");
+    k.in_bytes = (unsigned)ib;
+  }
+  {
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    const int cq = a.epi == EPI_DECONV2X2 ? w.cout / 4 : w.cout;
+    k.vec = (cq % 4 == 0) && (out.ld % 4 == 0) && al16(out.p) && (!w.scale || al16(w.scale)) &&
+            (!w.bias || al16(w.bias)) && (!a.res || (a.res->ld % 4 == 0 && al16(a.res->p)));
+    if (a.epi == EPI_DECONV2X2) YMK_CHECK(k.vec, "deconv epilogue needs 16 B aligned channels");
+  }
 
   // tile selection: wide tiles when there is enough work to fill 256 CUs x 2 blocks
   const long blocks128 = (long)((k.M + 127) / 128) * ((w.cout + 127) / 128);
-  if (w.cout <= 32) {
+  if (w.mode == 1) {  // 4-channel stems: Cout is 32 or 64
+    if (w.cout <= 32) launch<128, 32, 4, 1, 1>(s, k);
+    else launch<128, 64, 2, 2, 1>(s, k);
+  } else if (w.cout <= 32) {
     launch<128, 32, 4, 1>(s, k);
   } else if (w.cout <= 64) {
     if ((k.M + 127) / 128 >= 256) launch<128, 64, 2, 2>(s, k);
@@ -349,7 +429,7 @@ void pack_conv_weight(const float* oihw, int cout, int cin, int kh, int kw, bool
     YMK_CHECK(cin <= 4, "tap4 packing wants cin <= 4");
     ctiles = 0;
     kpad = ((taps * 4 + 31) / 32) * 32;
-    panel.assign((size_t)cout * kpad, 0.f);
+    panel.assign((size_t)((cout + 127) / 128 * 128) * kpad, 0.f);
     for (int co = 0; co < cout; ++co)
       for (int c = 0; c < cin; ++c)
         for (int tp = 0; tp < taps; ++tp)
@@ -357,7 +437,7 @@ void pack_conv_weight(const float* oihw, int cout, int cin, int kh, int kw, bool
   } else {
     ctiles = (cin + 31) / 32;
     kpad = taps * ctiles * 32;
-    panel.assign((size_t)cout * kpad, 0.f);
+    panel.assign((size_t)((cout + 127) / 128 * 128) * kpad, 0.f);  // rows padded: no N guard in the kernel
     for (int co = 0; co < cout; ++co)
       for (int c = 0; c < cin; ++c)
         for (int tp = 0; tp < taps; ++tp)
