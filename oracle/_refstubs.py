@@ -106,6 +106,95 @@ class _IntermediateLayerGetter(nn.ModuleDict):
         return out
 
 
+# ------------------------------------------------------------------ timm restatement
+class _PatchEmbed(nn.Module):
+    def __init__(self, img_size, patch_size, in_chans, embed_dim):
+        super().__init__()
+        self.img_size = tuple(img_size)
+        self.patch_size = tuple(patch_size)
+        self.grid_size = (self.img_size[0] // self.patch_size[0], self.img_size[1] // self.patch_size[1])
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
+        self.norm = nn.Identity()
+
+    def forward(self, x):
+        return self.norm(self.proj(x).flatten(2).transpose(1, 2))
+
+
+class _TimmAttention(nn.Module):
+    def __init__(self, dim, num_heads, qkv_bias):
+        super().__init__()
+        self.num_heads = num_heads
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+        x = torch.nn.functional.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
+        return self.proj(x.transpose(1, 2).reshape(B, N, C))
+
+
+class _TimmMlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class _TimmBlock(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio, qkv_bias):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _TimmAttention(dim, num_heads, qkv_bias)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _TimmMlp(dim, int(dim * mlp_ratio))
+
+    def forward(self, x):
+        x = x + self.attn(self.norm1(x))
+        return x + self.mlp(self.norm2(x))
+
+
+class _TimmViT(nn.Module):
+    """timm.models.vision_transformer.VisionTransformer, the subset the reference's Encoder uses
+    (class_token=False, global_pool="", num_classes=0)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0,
+                 qkv_bias=True, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0, embed_layer=_PatchEmbed,
+                 num_classes=0, global_pool="", class_token=False, **_):
+        super().__init__()
+        self.patch_embed = embed_layer(img_size, patch_size, in_chans, embed_dim)
+        n = self.patch_embed.grid_size[0] * self.patch_embed.grid_size[1]
+        self.pos_embed = nn.Parameter(torch.randn(1, n, embed_dim) * 0.02)
+        self.pos_drop = nn.Identity()
+        self.patch_drop = nn.Identity()
+        self.norm_pre = nn.Identity()
+        self.blocks = nn.Sequential(*[_TimmBlock(embed_dim, num_heads, mlp_ratio, qkv_bias) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+
+    def no_weight_decay(self):
+        return {"pos_embed"}
+
+    def forward_features(self, x):
+        x = self.patch_embed(x)
+        x = self.pos_drop(x + self.pos_embed)
+        return self.norm(self.blocks(self.norm_pre(self.patch_drop(x))))
+
+
+def _named_apply(fn, module, name="", depth_first=True, include_root=False):
+    if not depth_first and include_root:
+        fn(module=module, name=name)
+    for child_name, child in module.named_children():
+        child_name = ".".join((name, child_name)) if name else child_name
+        _named_apply(fn, child, child_name, depth_first, True)
+    if depth_first and include_root:
+        fn(module=module, name=name)
+    return module
+
+
 def _module(name, **attrs):
     m = types.ModuleType(name)
     for k, v in attrs.items():
@@ -120,6 +209,12 @@ def install_stubs():
         tv = _module("torchvision")
         tv.models = _module("torchvision.models", resnet50=lambda **kw: _ResNet50(**kw))
         tv.models._utils = _module("torchvision.models._utils", IntermediateLayerGetter=_IntermediateLayerGetter)
+    if "timm" not in sys.modules:
+        tm = _module("timm")
+        tm.models = _module("timm.models")
+        tm.models.vision_transformer = _module("timm.models.vision_transformer", PatchEmbed=_PatchEmbed,
+                                               VisionTransformer=_TimmViT)
+        tm.models.helpers = _module("timm.models.helpers", named_apply=_named_apply)
     if "omegaconf" not in sys.modules:
 
         class ListConfig(list):

@@ -46,10 +46,52 @@ def pin_dbnet():
     np.savez_compressed(os.path.join(GOLDEN, "dbnet_ref_64x96.npz"), seed=seed, x=x.numpy(), prob=ref.numpy())
 
 
+def pin_parseq():
+    from types import SimpleNamespace
+
+    from yomitoku_amd.utils.synth import parseq_state_dict, synthetic_line_batch
+
+    from .parseq import PRESETS, make_cfg, parseq_forward
+
+    mod = ref_import("yomitoku.models.parseq")
+    ocfg = make_cfg(**PRESETS["parseq-tiny-dynw-v4"])
+    rcfg = AttrDict(
+        max_label_length=100, decode_ar=1, refine_iters=1, num_tokens=ocfg.num_tokens,
+        data={"img_size": [32, 800]},
+        encoder={"patch_size": [4, 8], "num_heads": 6, "embed_dim": 192, "mlp_ratio": 4, "depth": 12},
+        decoder={"embed_dim": 192, "num_heads": 6, "mlp_ratio": 4, "depth": 1},
+    )
+    cases = [
+        # (file tag, checkpoint kwargs, batch, width)
+        ("eos", dict(seed=1235, eos_bias=4.5), 3, 96),
+        ("rep", dict(seed=1236, eos_bias=3.0, favour_token=17, favour_bias=12.0), 3, 72),
+    ]
+    for tag, kw, bs, width in cases:
+        sd = parseq_state_dict(**kw)
+        model = mod.PARSeq(rcfg)
+        res = model.load_state_dict(sd, strict=True)
+        model.eval()
+        model.tokenizer = SimpleNamespace(eos_id=0, bos_id=ocfg.num_tokens - 2, pad_id=ocfg.num_tokens - 1)
+        x = synthetic_line_batch(11, bs, width)
+        with torch.inference_mode():
+            ref = model(x)
+        ours, steps = parseq_forward(sd, ocfg, x, return_steps=True)
+        err = (ref - ours).abs().max().item()
+        ids = ref.argmax(-1)
+        lens = [int((row == 0).nonzero()[0]) if (row == 0).any() else len(row) for row in ids]
+        print(f"[parseq/{tag}] reference vs oracle: max abs diff {err:.3e}, AR steps {steps}, lengths {lens} ({res})")
+        assert err < 1e-5, err
+        # logits are large (B x 101 x 7119): keep the decisive slices - arg-max ids, max logit, a strided sample
+        np.savez_compressed(
+            os.path.join(GOLDEN, f"parseq_ref_{tag}.npz"), ckpt=np.array(repr(kw)), x=x.numpy(), steps=steps,
+            ids=ids.numpy().astype(np.int32), top=ref.max(-1).values.numpy(), sample=ref[:, :, ::97].numpy(),
+        )
+
+
 def main(argv):
     what = argv[1] if len(argv) > 1 else "all"
     os.makedirs(GOLDEN, exist_ok=True)
-    todo = {"dbnet": pin_dbnet}
+    todo = {"dbnet": pin_dbnet, "parseq": pin_parseq}
     for k, fn in todo.items():
         if what in (k, "all"):
             fn()

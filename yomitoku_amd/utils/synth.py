@@ -146,3 +146,72 @@ def synthetic_page(seed: int = 0, height: int = 1600, width: int = 1200) -> np.n
         fy, fx = int(rng.integers(0, height - fh)), int(rng.integers(0, width - fw))
         img[fy : fy + fh, fx : fx + fw] = rng.integers(0, 256, size=(fh, fw, 3), dtype=np.uint8)
     return img
+
+
+# ---------------------------------------------------------------------------------------------
+def parseq_state_dict(seed: int = 1235, patch=(4, 8), enc_dim: int = 192, enc_depth: int = 12, enc_mlp: int = 4,
+                      dec_dim: int = 192, dec_mlp: int = 4, num_tokens: int = 7121, max_label_length: int = 100,
+                      img_size=(32, 800), eos_bias: float = 4.5, favour_token: int | None = None,
+                      favour_bias: float = 0.0) -> "OrderedDict[str, torch.Tensor]":
+    """State dict of PARSeq (reference models/parseq.py:61-78, parseq_transformer.py:43-57, timm ViT naming).
+
+    `eos_bias` lifts the <eos> logit so that greedy decoding stops after a varying number of steps
+    (random weights would otherwise almost never emit <eos>); `favour_token`/`favour_bias` lift one
+    ordinary class to provoke the repetition early-stop (models/parseq.py:226-242)."""
+    d = _Draw(seed)
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    ph, pw = patch
+    gh, gw = img_size[0] // ph, img_size[1] // pw
+
+    def lin(name, out, inp, gain=1.0, bias_std=0.02):
+        sd[name + ".weight"] = d.normal((out, inp), std=gain / math.sqrt(inp))
+        sd[name + ".bias"] = d.normal((out,), std=bias_std)
+
+    def ln(name, c):
+        sd[name + ".weight"] = d.uniform((c,), 0.8, 1.2)
+        sd[name + ".bias"] = d.normal((c,), std=0.05)
+
+    e = "encoder."
+    sd[e + "pos_embed"] = d.normal((1, gh * gw, enc_dim), std=0.2)
+    sd[e + "patch_embed.proj.weight"] = d.normal((enc_dim, 3, ph, pw), std=1.0 / math.sqrt(3 * ph * pw))
+    sd[e + "patch_embed.proj.bias"] = d.normal((enc_dim,), std=0.02)
+    for i in range(enc_depth):
+        p = f"{e}blocks.{i}."
+        ln(p + "norm1", enc_dim)
+        lin(p + "attn.qkv", 3 * enc_dim, enc_dim, gain=1.5)
+        lin(p + "attn.proj", enc_dim, enc_dim, gain=0.5)
+        ln(p + "norm2", enc_dim)
+        lin(p + "mlp.fc1", enc_mlp * enc_dim, enc_dim)
+        lin(p + "mlp.fc2", enc_dim, enc_mlp * enc_dim, gain=0.5)
+    ln(e + "norm", enc_dim)
+    p = "decoder.layers.0."
+    for att in ("self_attn", "cross_attn"):
+        sd[p + att + ".in_proj_weight"] = d.normal((3 * dec_dim, dec_dim), std=1.5 / math.sqrt(dec_dim))
+        sd[p + att + ".in_proj_bias"] = d.normal((3 * dec_dim,), std=0.02)
+        lin(p + att + ".out_proj", dec_dim, dec_dim, gain=0.7)
+    lin(p + "linear1", dec_mlp * dec_dim, dec_dim)
+    lin(p + "linear2", dec_dim, dec_mlp * dec_dim, gain=0.5)
+    for n in ("norm1", "norm2", "norm_q", "norm_c"):
+        ln(p + n, dec_dim)
+    ln("decoder.norm", dec_dim)
+    lin("head", num_tokens - 2, dec_dim, gain=2.0, bias_std=0.1)
+    sd["head.bias"][0] += eos_bias
+    if favour_token is not None:
+        sd["head.bias"][favour_token] += favour_bias
+    sd["text_embed.embedding.weight"] = d.normal((num_tokens, dec_dim), std=1.0 / math.sqrt(dec_dim))
+    sd["pos_queries"] = d.normal((1, max_label_length + 1, dec_dim), std=0.5)
+    return sd
+
+
+def synthetic_line_batch(seed: int, batch: int, width: int, height: int = 32) -> torch.Tensor:
+    """fp32 B x 3 x H x W in [-1, 1] as ParseqDataset emits (ToTensor + Normalize(0.5, 0.5)):
+    dark strokes on light paper up to a per-sample content width, then black (-1) canvas padding."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.full((batch, 3, height, width), -1.0)
+    for b in range(batch):
+        cw = int(torch.randint(max(8, width // 3), width + 1, (1,), generator=g))
+        paper = 0.85 + 0.1 * torch.rand(1, height, cw, generator=g)
+        ink = (torch.rand(1, height, cw, generator=g) < 0.3).float()
+        img = paper * (1 - ink) + 0.1 * ink
+        x[b, :, :, :cw] = (img.expand(3, -1, -1) + 0.02 * torch.randn(3, height, cw, generator=g)).clamp(0, 1) * 2 - 1
+    return x
