@@ -52,6 +52,21 @@ int64_t ymk_model_workspace_bytes(const ymk_model* m);
  * prob_dev: fp32 [n][1][h][w] = preds["binary"]. */
 int ymk_dbnet_forward(ymk_model* m, const float* x_dev, int n, int h, int w, float* prob_dev, void* stream);
 
+/* ---- PARSeq text recogniser (replaces PARSeq.forward, models/parseq.py:159-311) ----------
+ * x_dev: fp32 [b][3][32][w] in [-1,1] (w a multiple of the patch width, <= 800: the dynamic-width
+ * batches of TextRecognizer._collate, text_recognizer.py:146-156); logits_dev: fp32
+ * [b][max_label_length+1][num_tokens-2] (always allocate the full 101 rows); *out_len receives the
+ * number of valid rows per sample (101 when refine_iters >= 1, else the AR steps executed),
+ * *ar_steps the greedy steps executed before every row held an <eos>.  Synchronises the stream
+ * once per AR step (the reference's own early-stop test, models/parseq.py:245-250). */
+int ymk_parseq_dims(ymk_model* m, int* num_steps, int* num_classes);
+int ymk_parseq_forward(ymk_model* m, const float* x_dev, int b, int w, float* logits_dev, int* out_len, int* ar_steps,
+                       void* stream);
+/* what ParseqTokenizer.decode needs from softmax(logits) (parseq_tokenizer.py:79-87) without
+ * materialising it: per row the arg-max class id and max probability. rows = b * out_len. */
+int ymk_parseq_token_stats(const float* logits_dev, int rows, int num_classes, int* ids_dev, float* probs_dev,
+                           void* stream);
+
 /* ---- measurement aid for bench.py (not on the product path): between begin/end every launch of
  * the implicit-GEMM convolution kernel is bracketed by HIP events on its own stream; end returns
  * the summed kernel time, the algorithmic FLOPs (2*M*Cout*KH*KW*Cin, unpadded) and launch count.
@@ -65,6 +80,14 @@ int ymk_op_conv2d(const float* x_dev, int n, int h, int w, int c, /* c % 4 == 0,
                   const float* w_host_oihw, int cout, int cin, int kh, int kw, const float* scale_host,
                   const float* bias_host, const float* res_dev, int stride, int pad, int dil, int act, int tap4,
                   float* y_dev, void* stream);
+/* rows x d LayerNorm (eps as given); attention over contiguous [b][l][heads*hd] q/k/v with optional
+ * boolean masks (non-zero = blocked): mask_qk [lq][lk], kpm [b][lk]; use_small selects the masked
+ * small-query kernel even without masks (otherwise the fp32-MFMA flash kernel runs). */
+int ymk_op_layernorm(const float* x_dev, int rows, int d, const float* g_dev, const float* b_dev, float eps,
+                     float* y_dev, void* stream);
+int ymk_op_attention(const float* q_dev, const float* k_dev, const float* v_dev, float* o_dev, int b, int heads, int lq,
+                     int lk, int hd, float scale, const unsigned char* mask_qk_dev, const unsigned char* kpm_dev,
+                     int use_small, void* stream);
 int ymk_op_maxpool3x3s2(const float* x_dev, int n, int h, int w, int c, float* y_dev, void* stream);
 int ymk_op_upsample_bilinear(const float* x_dev, int n, int h, int w, int c, int oh, int ow, const float* add_dev,
                              float* y_dev, void* stream);

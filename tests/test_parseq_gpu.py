@@ -1,0 +1,82 @@
+"""PARSeq forward parity: HIP path (ymk_parseq_forward) vs the CPU oracle and the golden vectors the
+REFERENCE class produced.  Tolerance (BASELINE.json north_star): text logits within 1e-3."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-3
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _net(dev, sd, preset="parseq-tiny-dynw-v4", **cfg_over):
+    from oracle.parseq import PRESETS, make_cfg
+    from yomitoku_amd.nets import PARSeq
+
+    ocfg = make_cfg(**{**PRESETS[preset], **cfg_over})
+    cfg = {
+        "num_tokens": ocfg.num_tokens, "max_label_length": ocfg.max_label_length, "refine_iters": ocfg.refine_iters,
+        "decode_ar": 1, "repetition_stop": ocfg.repetition_stop, "data": {"img_size": [32, 800]},
+        "encoder": {"patch_size": list(ocfg.patch), "num_heads": ocfg.enc_heads, "embed_dim": ocfg.enc_dim,
+                    "mlp_ratio": 4, "depth": ocfg.enc_depth},
+        "decoder": {"embed_dim": ocfg.dec_dim, "num_heads": ocfg.dec_heads, "mlp_ratio": 4, "depth": 1},
+    }
+    return ocfg, PARSeq(cfg).load_state_dict(sd).to(dev)
+
+
+@pytest.mark.parametrize("tag", ["eos", "rep"])
+def test_matches_reference_golden(dev, tag):
+    from yomitoku_amd.utils.synth import parseq_state_dict
+
+    z = np.load(os.path.join(GOLD, f"parseq_ref_{tag}.npz"))
+    kw = ast.literal_eval(str(z["ckpt"]))  # repr() of the synth.parseq_state_dict kwargs
+    sd = parseq_state_dict(**kw)
+    _, net = _net(dev, sd)
+    logits = net(torch.from_numpy(z["x"]).to(dev))
+    assert net.last_ar_steps == int(z["steps"])
+    lg = logits.cpu()
+    assert lg.shape[:2] == z["ids"].shape
+    assert np.array_equal(lg.argmax(-1).numpy().astype(np.int32), z["ids"])
+    assert np.abs(lg.max(-1).values.numpy() - z["top"]).max() < LOGIT_TOL
+    assert np.abs(lg[:, :, ::97].numpy() - z["sample"]).max() < LOGIT_TOL
+    # fused tokenizer statistics == softmax().max()
+    ids, probs = net.token_stats(logits)
+    ref_p, ref_i = lg.softmax(-1).max(-1)
+    assert torch.equal(ids.cpu().long(), ref_i)
+    assert (probs.cpu() - ref_p).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("batch,width,seed", [(5, 160, 1), (2, 800, 2), (9, 72, 3)])
+def test_matches_oracle_tiny(dev, batch, width, seed):
+    from oracle.parseq import parseq_forward
+    from yomitoku_amd.utils.synth import parseq_state_dict, synthetic_line_batch
+
+    sd = parseq_state_dict(1235, eos_bias=5.5)
+    ocfg, net = _net(dev, sd)
+    x = synthetic_line_batch(seed, batch, width)
+    ref, steps = parseq_forward(sd, ocfg, x, return_steps=True)
+    out = net(x.to(dev)).cpu()
+    assert net.last_ar_steps == steps
+    assert out.shape == ref.shape
+    assert torch.equal(out.argmax(-1), ref.argmax(-1))
+    assert (out - ref).abs().max().item() < LOGIT_TOL
+
+
+def test_matches_oracle_open_beta_no_refine(dev):
+    """parseq (open-beta) geometry: 8x8 patches, D=512, 8 heads, charset v1; refine_iters=0 returns the
+    AR logits of the executed steps only."""
+    from oracle.parseq import parseq_forward
+    from yomitoku_amd.utils.synth import parseq_state_dict, synthetic_line_batch
+
+    kw = dict(patch=(8, 8), enc_dim=512, dec_dim=512, num_tokens=7312, enc_depth=3)
+    sd = parseq_state_dict(77, eos_bias=6.0, **kw)
+    ocfg, net = _net(dev, sd, "parseq", enc_depth=3, refine_iters=0)
+    x = synthetic_line_batch(5, 4, 224)
+    ref, steps = parseq_forward(sd, ocfg, x, return_steps=True)
+    out = net(x.to(dev)).cpu()
+    assert out.shape == ref.shape and out.shape[1] == steps
+    assert (out - ref).abs().max().item() < LOGIT_TOL

@@ -26,12 +26,21 @@ SIGNATURES = {
     "ymk_model_weight_bytes": (c_int64, [c_void_p]),
     "ymk_model_workspace_bytes": (c_int64, [c_void_p]),
     "ymk_dbnet_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ymk_parseq_dims": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+    "ymk_parseq_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, POINTER(c_int), POINTER(c_int), c_void_p]),
+    "ymk_parseq_token_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ymk_prof_begin": (c_int, []),
     "ymk_prof_end": (c_int, [POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
     "ymk_op_conv2d": (
         c_int,
         [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
          c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    ),
+    "ymk_op_layernorm": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
+    "ymk_op_attention": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int,
+         c_void_p],
     ),
     "ymk_op_maxpool3x3s2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ymk_op_upsample_bilinear": (

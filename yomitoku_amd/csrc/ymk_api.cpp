@@ -1,10 +1,15 @@
 // extern "C" surface of libymk_hip.so (declared in include/ymk.h).
 #include "../../include/ymk.h"
 #include "ymk_common.h"
+#include "ymk_seq.h"
 
 namespace ymk {
 const std::string& last_error();
 void dbnet_forward(Model* m, const float* x, int n, int h, int w, float* prob, hipStream_t s);
+void parseq_forward(Model* m, const float* x, int B, int W, float* logits, int* out_len, int* ar_steps, hipStream_t s);
+void parseq_dims(Model* m, int* num_steps, int* num_classes);
+Model* create_parseq();
+void row_maxprob(hipStream_t s, const float* logits, int rows, int C, int* ids, float* probs);
 void prof_begin();
 void prof_end(double* ms, double* flop, int64_t* launches);
 }  // namespace ymk
@@ -46,6 +51,7 @@ ymk_model* ymk_model_create(const char* kind, int device) {
     std::string k(kind);
     ymk::Model* impl = nullptr;
     if (k == "dbnet") impl = ymk::create_dbnet();
+    else if (k == "parseq") impl = ymk::create_parseq();
     else throw ymk::Error("unknown model kind: " + k);
     auto* m = new ymk_model();
     m->impl = impl;
@@ -98,6 +104,30 @@ int ymk_dbnet_forward(ymk_model* m, const float* x_dev, int n, int h, int w, flo
   YMK_API_END
 }
 
+int ymk_parseq_dims(ymk_model* m, int* num_steps, int* num_classes) {
+  YMK_API_BEGIN
+  YMK_CHECK(m && num_steps && num_classes, "null argument");
+  ymk::parseq_dims(m->impl, num_steps, num_classes);
+  YMK_API_END
+}
+
+int ymk_parseq_forward(ymk_model* m, const float* x_dev, int b, int w, float* logits_dev, int* out_len, int* ar_steps,
+                       void* stream) {
+  YMK_API_BEGIN
+  YMK_CHECK(m && x_dev && logits_dev && out_len && ar_steps, "null argument");
+  YMK_HIP(hipSetDevice(m->device));
+  ymk::parseq_forward(m->impl, x_dev, b, w, logits_dev, out_len, ar_steps, (hipStream_t)stream);
+  YMK_API_END
+}
+
+int ymk_parseq_token_stats(const float* logits_dev, int rows, int num_classes, int* ids_dev, float* probs_dev,
+                           void* stream) {
+  YMK_API_BEGIN
+  YMK_CHECK(logits_dev && ids_dev && probs_dev, "null argument");
+  ymk::row_maxprob((hipStream_t)stream, logits_dev, rows, num_classes, ids_dev, probs_dev);
+  YMK_API_END
+}
+
 int ymk_prof_begin(void) {
   YMK_API_BEGIN
   ymk::prof_begin();
@@ -141,6 +171,27 @@ int ymk_op_conv2d(const float* x_dev, int n, int h, int w, int c, const float* w
   a.res = res_dev ? &res : nullptr;
   conv2d((hipStream_t)stream, in, cw, a, out);
   YMK_HIP(hipStreamSynchronize((hipStream_t)stream));  // pool frees the panel on return
+  YMK_API_END
+}
+
+int ymk_op_layernorm(const float* x_dev, int rows, int d, const float* g_dev, const float* b_dev, float eps,
+                     float* y_dev, void* stream) {
+  YMK_API_BEGIN
+  ymk::layernorm((hipStream_t)stream, x_dev, d, 0, g_dev, b_dev, eps, y_dev, d, rows, d);
+  YMK_API_END
+}
+
+int ymk_op_attention(const float* q_dev, const float* k_dev, const float* v_dev, float* o_dev, int b, int heads, int lq,
+                     int lk, int hd, float scale, const unsigned char* mask_qk_dev, const unsigned char* kpm_dev,
+                     int use_small, void* stream) {
+  YMK_API_BEGIN
+  const int D = heads * hd;
+  if (use_small || mask_qk_dev || kpm_dev)
+    ymk::small_attention((hipStream_t)stream, q_dev, k_dev, v_dev, o_dev, b, heads, lq, lk, hd, D, D, D, D, (long)lq * D,
+                         (long)lk * D, (long)lk * D, (long)lq * D, scale, mask_qk_dev, lk, kpm_dev, lk);
+  else
+    ymk::flash_attention((hipStream_t)stream, q_dev, k_dev, v_dev, o_dev, b, heads, lq, lk, hd, D, D, D, D, (long)lq * D,
+                         (long)lk * D, (long)lk * D, (long)lq * D, scale);
   YMK_API_END
 }
 

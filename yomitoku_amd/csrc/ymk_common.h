@@ -90,6 +90,7 @@ enum Epi : int { EPI_STORE = 0, EPI_DECONV2X2 = 1 };
 
 struct ConvArgs {
   int stride = 1, pad = 0, dil = 1;
+  int stride_w = 0;  // 0: same as stride (vertical); PARSeq-tiny patchify is 4 x 8
   int act = ACT_NONE;
   int epi = EPI_STORE;
   const Tensor* res = nullptr;  // residual added before the activation
@@ -97,6 +98,11 @@ struct ConvArgs {
 
 // out must be pre-shaped (n, oh, ow, cout[, ld]); for EPI_DECONV2X2 out is (n, 2h, 2w, cout/4).
 void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, const Tensor& out);
+
+// Row-major GEMM view of the same kernel: out[m][:] = act(A[m][:] . W^T * scale + bias + res[m][:]).
+// `res_ld == 0` broadcasts one residual row to every m.
+void gemm(hipStream_t s, const float* A, int M, int K, int lda, const ConvW& w, int act, const float* res, int res_ld,
+          float* out, int out_ld);
 
 // Host-side packing: OIHW fp32 -> panel. `cin_pad4` packs for the tap4 mode (cin<=4).
 void pack_conv_weight(const float* oihw, int cout, int cin, int kh, int kw, bool tap4,

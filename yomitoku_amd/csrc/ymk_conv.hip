@@ -36,7 +36,7 @@ struct ConvK {
   float* out;
   int H, W, C, in_ld;
   int OH, OW, Cout, out_ld, res_ld;
-  int KH, KW, stride, pad, dil;
+  int KH, KW, stride, stride_w, pad, dil;
   int Kpad, ctiles, mode;
   int M;        // n*oh*ow
   int act, epi;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvK p) {
       const int oh = rem / p.OW, ow = rem - oh * p.OW;
       pixb[i] = n * p.H * p.W;
       ih0[i] = oh * p.stride - p.pad;
-      iw0[i] = ow * p.stride - p.pad;
+      iw0[i] = ow * p.stride_w - p.pad;
     } else {
       pixb[i] = 0;
       ih0[i] = -(1 << 20);  // fails every bounds test
@@ -360,10 +360,11 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
   k.KH = w.kh;
   k.KW = w.kw;
   k.stride = a.stride;
+  k.stride_w = a.stride_w > 0 ? a.stride_w : a.stride;
   k.pad = a.pad;
   k.dil = a.dil;
   k.OH = conv_out_dim(in.h, w.kh, a.stride, a.pad, a.dil);
-  k.OW = conv_out_dim(in.w, w.kw, a.stride, a.pad, a.dil);
+  k.OW = conv_out_dim(in.w, w.kw, k.stride_w, a.pad, a.dil);
   k.Cout = w.cout;
   k.out_ld = out.ld;
   k.Kpad = w.kpad;
@@ -382,7 +383,8 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
   YMK_CHECK(((uintptr_t)in.p & 15) == 0, "conv: input not 16B aligned");
   if (a.epi == EPI_STORE) {
     YMK_CHECK(out.n == in.n && out.h == k.OH && out.w == k.OW && out.c == w.cout, "conv: bad output shape");
-    if (a.res) YMK_CHECK(a.res->n == out.n && a.res->h == out.h && a.res->w == out.w && a.res->c == out.c, "conv: bad residual shape");
+    if (a.res && a.res->ld != 0)  // ld == 0: one row broadcast over every output pixel
+      YMK_CHECK(a.res->n == out.n && a.res->h == out.h && a.res->w == out.w && a.res->c == out.c, "conv: bad residual shape");
   } else {
     YMK_CHECK(w.kh == 1 && w.kw == 1 && a.stride == 1 && a.pad == 0, "deconv epilogue wants a 1x1 panel");
     YMK_CHECK(out.n == in.n && out.h == 2 * in.h && out.w == 2 * in.w && out.c * 4 == w.cout, "deconv: bad output shape");
@@ -419,6 +421,18 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
     else launch<64, 64, 2, 2>(s, k);
   }
   YMK_HIP(hipGetLastError());
+}
+
+void gemm(hipStream_t s, const float* A, int M, int K, int lda, const ConvW& w, int act, const float* res, int res_ld,
+          float* out, int out_ld) {
+  YMK_CHECK(K == w.cin, "gemm: K " + std::to_string(K) + " != weight in-features " + std::to_string(w.cin));
+  Tensor in{const_cast<float*>(A), 1, 1, M, K, lda};
+  Tensor o{out, 1, 1, M, w.cout, out_ld};
+  Tensor r{const_cast<float*>(res), 1, 1, M, w.cout, res_ld};
+  ConvArgs a;
+  a.act = act;
+  a.res = res ? &r : nullptr;
+  conv2d(s, in, w, a, o);
 }
 
 // ------------------------------------------------------------------ host packing

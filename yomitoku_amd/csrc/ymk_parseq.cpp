@@ -1,0 +1,336 @@
+// PARSeq text recogniser forward on gfx950.
+// Follows models/parseq.py:159-311 (encode, greedy AR decode with early stop and repetition stop,
+// refinement with the reference's integer-indexed mask, repetition cut) and
+// models/layers/parseq_transformer.py:69-169,206-234 (two-stream decoder layer, ViT encoder with the
+// dynamic-width position-embedding crop).  Differences in *how* (not what) it is computed:
+//   - K/V of the context and of the encoder memory are projected once and cached (the reference
+//     re-projects them every step); rows are bit-identical because each output row of the MFMA GEMM
+//     is an independent fmaf chain;
+//   - tokens, <eos> bookkeeping and the repetition detector live on the device; the host reads one
+//     int per step (the "every row has an <eos>" flag, models/parseq.py:245-250).
+#include "ymk_common.h"
+#include "ymk_seq.h"
+
+namespace ymk {
+
+void tile_rows(hipStream_t s, const float* src, int rows, int D, float* dst, int B);
+
+namespace {
+
+struct EncBlock {
+  float *ln1g, *ln1b, *ln2g, *ln2b;
+  ConvW qkv, proj, fc1, fc2;
+};
+
+class ParseqModel : public Model {
+ public:
+  const char* kind() const override { return "parseq"; }
+
+  void finalize() override {
+    ph_ = (int)param("patch_h", 4);
+    pw_ = (int)param("patch_w", 8);
+    img_h_ = (int)param("img_h", 32);
+    img_w_ = (int)param("img_w", 800);
+    D_ = (int)param("enc_dim", 192);
+    eh_ = (int)param("enc_heads", 6);
+    depth_ = (int)param("enc_depth", 12);
+    Dd_ = (int)param("dec_dim", 192);
+    dh_ = (int)param("dec_heads", 6);
+    ntok_ = (int)param("num_tokens", 7121);
+    maxlen_ = (int)param("max_label_length", 100);
+    refine_ = (int)param("refine_iters", 1);
+    rep_on_ = (int)param("repetition_stop", 1);
+    rep_pmax_ = (int)param("rep_period_max", 8);
+    rep_p1_ = (int)param("rep_min_run_p1", 8);
+    rep_min_ = (int)param("rep_min_repeats", 3);
+    YMK_CHECK((int)param("dec_depth", 1) == 1, "only decoder depth 1 is implemented (all shipped configs)");
+    YMK_CHECK((int)param("decode_ar", 1) == 1, "only decode_ar=1 is implemented (all shipped configs)");
+    YMK_CHECK(D_ == Dd_, "encoder and decoder widths must match (cross attention has no kdim)");
+    YMK_CHECK(D_ % eh_ == 0 && Dd_ % dh_ == 0, "embed dim must divide by heads");
+    C_ = ntok_ - 2;
+    eos_ = 0;
+    bos_ = ntok_ - 2;
+    pad_ = ntok_ - 1;
+    nsteps_ = maxlen_ + 1;
+    gh_ = img_h_ / ph_;
+    full_gw_ = img_w_ / pw_;
+
+    const std::string e = "encoder.";
+    patch_ = make_conv(pool, ws, e + "patch_embed.proj", "", /*tap4=*/true);
+    {
+      const HostTensor& pe = ws.get(e + "pos_embed");
+      YMK_CHECK((int)pe.numel() == gh_ * full_gw_ * D_, "pos_embed size");
+      pos_embed_ = pool.upload(pe.data);
+    }
+    blocks_.resize(depth_);
+    for (int i = 0; i < depth_; ++i) {
+      const std::string p = e + "blocks." + std::to_string(i) + ".";
+      EncBlock& b = blocks_[i];
+      b.ln1g = pool.upload(ws.get(p + "norm1.weight").data);
+      b.ln1b = pool.upload(ws.get(p + "norm1.bias").data);
+      b.ln2g = pool.upload(ws.get(p + "norm2.weight").data);
+      b.ln2b = pool.upload(ws.get(p + "norm2.bias").data);
+      b.qkv = make_linear(pool, ws, p + "attn.qkv");
+      b.proj = make_linear(pool, ws, p + "attn.proj");
+      b.fc1 = make_linear(pool, ws, p + "mlp.fc1");
+      b.fc2 = make_linear(pool, ws, p + "mlp.fc2");
+    }
+    enc_ng_ = pool.upload(ws.get(e + "norm.weight").data);
+    enc_nb_ = pool.upload(ws.get(e + "norm.bias").data);
+
+    const std::string d = "decoder.layers.0.";
+    auto split_mha = [&](const std::string& name, ConvW& wq, ConvW& wkv, ConvW& wo) {
+      const HostTensor& w = ws.get(d + name + ".in_proj_weight");
+      const HostTensor& b = ws.get(d + name + ".in_proj_bias");
+      YMK_CHECK((int)w.dims[0] == 3 * Dd_ && (int)w.dims[1] == Dd_, name + ".in_proj_weight shape");
+      wq = make_linear_raw(pool, w.data.data(), b.data.data(), Dd_, Dd_);
+      wkv = make_linear_raw(pool, w.data.data() + (size_t)Dd_ * Dd_, b.data.data() + Dd_, 2 * Dd_, Dd_);
+      wo = make_linear(pool, ws, d + name + ".out_proj");
+    };
+    split_mha("self_attn", sa_q_, sa_kv_, sa_o_);
+    split_mha("cross_attn", ca_q_, ca_kv_, ca_o_);
+    lin1_ = make_linear(pool, ws, d + "linear1");
+    lin2_ = make_linear(pool, ws, d + "linear2");
+    auto up = [&](const std::string& n) { return pool.upload(ws.get(n).data); };
+    n1g_ = up(d + "norm1.weight"); n1b_ = up(d + "norm1.bias");
+    n2g_ = up(d + "norm2.weight"); n2b_ = up(d + "norm2.bias");
+    nqg_ = up(d + "norm_q.weight"); nqb_ = up(d + "norm_q.bias");
+    ncg_ = up(d + "norm_c.weight"); ncb_ = up(d + "norm_c.bias");
+    dng_ = up("decoder.norm.weight"); dnb_ = up("decoder.norm.bias");
+    head_ = make_linear(pool, ws, "head");
+    YMK_CHECK(head_.cout == C_, "head width must be num_tokens - 2");
+    {
+      const HostTensor& em = ws.get("text_embed.embedding.weight");
+      YMK_CHECK((int)em.dims[0] == ntok_ && (int)em.dims[1] == Dd_, "text_embed shape");
+      emb_ = pool.upload(em.data);
+      const HostTensor& pq = ws.get("pos_queries");
+      YMK_CHECK((int)pq.numel() == nsteps_ * Dd_, "pos_queries shape");
+      posq_ = pool.upload(pq.data);
+    }
+    {
+      // refinement query mask (models/parseq.py:267-277): triu(1) with rows 0 and 1 cleared
+      std::vector<float> tmp;
+      std::vector<unsigned char> m((size_t)nsteps_ * nsteps_, 0);
+      for (int q = 2; q < nsteps_; ++q)
+        for (int k = q + 1; k < nsteps_; ++k) m[(size_t)q * nsteps_ + k] = 1;
+      void* dm = nullptr;
+      YMK_HIP(hipMalloc(&dm, m.size()));
+      YMK_HIP(hipMemcpy(dm, m.data(), m.size(), hipMemcpyHostToDevice));
+      qmask_ = (unsigned char*)dm;
+      YMK_HIP(hipHostMalloc((void**)&host_flag_, sizeof(int)));
+    }
+    ws.clear();
+    finalized = true;
+  }
+
+  ~ParseqModel() override {
+    if (qmask_) (void)hipFree(qmask_);
+    if (host_flag_) (void)hipHostFree(host_flag_);
+  }
+
+  int num_classes() const { return C_; }
+  int num_steps() const { return nsteps_; }
+
+  // x: device fp32 [B][3][img_h][W]; logits: device [B][nsteps][C]; returns rows valid per sample
+  void forward(const float* x, int B, int W, float* logits, int* out_len, int* ar_steps, hipStream_t s) {
+    YMK_CHECK(finalized, "model not finalized");
+    YMK_CHECK(B > 0 && W >= pw_ && W % pw_ == 0 && W <= img_w_, "parseq input width must be a multiple of the patch width, <= img_w");
+    const uint64_t key = ((uint64_t)B << 32) | (uint64_t)W;
+    if (key != shape_key_) {
+      arena.dry_run = true;
+      arena.reset();
+      int a = 0, b2 = 0;
+      run(x, B, W, logits, &a, &b2, s);
+      arena.dry_run = false;
+      const size_t need = arena.used();
+      arena.reset();
+      if (need > arena.capacity()) {
+        YMK_HIP(hipStreamSynchronize(s));
+        arena.reserve(need);
+      }
+      shape_key_ = key;
+    }
+    arena.reset();
+    run(x, B, W, logits, out_len, ar_steps, s);
+  }
+
+ private:
+  void ln(hipStream_t s, const float* x, const float* g, const float* b, float eps, float* y, int M, int D) {
+    layernorm(s, x, D, 0, g, b, eps, y, D, M, D);
+  }
+
+  // query-stream tail shared by the AR step and the refinement pass:
+  //   q (in/out, [M][Dd]) already holds query + self-attention; adds cross attention and the FFN,
+  //   then decoder.norm + head -> out rows (ld_out floats apart)
+  void stream_tail(hipStream_t s, float* q, int M, int B, int Lq, const float* memkv, int L, float* t, float* t2, float* h,
+                   float* out, int ld_out) {
+    const int D = Dd_, hd = D / dh_;
+    const float scale = 1.f / std::sqrt((float)hd);
+    ln(s, q, n1g_, n1b_, 1e-5f, t, M, D);
+    gemm(s, t, M, D, D, ca_q_, ACT_NONE, nullptr, 0, t2, D);
+    if (Lq >= 32)
+      flash_attention(s, t2, memkv, memkv + D, t, B, dh_, Lq, L, hd, D, 2 * D, 2 * D, D, (long)Lq * D, (long)L * 2 * D,
+                      (long)L * 2 * D, (long)Lq * D, scale);
+    else
+      small_attention(s, t2, memkv, memkv + D, t, B, dh_, Lq, L, hd, D, 2 * D, 2 * D, D, (long)Lq * D, (long)L * 2 * D,
+                      (long)L * 2 * D, (long)Lq * D, scale, nullptr, 0, nullptr, 0);
+    gemm(s, t, M, D, D, ca_o_, ACT_NONE, q, D, q, D);
+    ln(s, q, n2g_, n2b_, 1e-5f, t, M, D);
+    gemm(s, t, M, D, D, lin1_, ACT_GELU, nullptr, 0, h, lin1_.cout);
+    gemm(s, h, M, lin1_.cout, lin1_.cout, lin2_, ACT_NONE, q, D, q, D);
+    ln(s, q, dng_, dnb_, 1e-5f, t, M, D);
+    gemm(s, t, M, D, D, head_, ACT_NONE, nullptr, 0, out, ld_out);
+  }
+
+  void run(const float* x, int B, int W, float* logits, int* out_len, int* ar_steps, hipStream_t s) {
+    const bool dry = arena.dry_run;
+    const int D = D_, gw = W / pw_, L = gh_ * gw, M = B * L, hd = D / eh_;
+    const int NS = nsteps_, C = C_;
+    // ---------------- encoder
+    Tensor x4 = arena.tensor(B, img_h_, W, 4);
+    Tensor tk = arena.tensor(B, gh_, gw, D);
+    float* y = arena.alloc_f((size_t)M * D);
+    float* qkv = arena.alloc_f((size_t)M * 3 * D);
+    float* att = arena.alloc_f((size_t)M * D);
+    float* hbuf = arena.alloc_f((size_t)M * blocks_[0].fc1.cout);
+    float* mem = arena.alloc_f((size_t)M * D);
+    float* memkv = arena.alloc_f((size_t)M * 2 * D);
+    // ---------------- decoder buffers
+    const int MR = B * NS;
+    float* qsa = arena.alloc_f((size_t)NS * D);        // W_q(norm_q(pos_queries)) - shared by the batch
+    float* posq_t = arena.alloc_f((size_t)MR * D);     // pos_queries tiled over the batch (refinement residual)
+    float* cn = arena.alloc_f((size_t)MR * D);         // norm_c(content)
+    float* skv = arena.alloc_f((size_t)MR * 2 * D);    // self-attention K|V cache
+    float* qcur = arena.alloc_f((size_t)MR * D);
+    float* t1 = arena.alloc_f((size_t)MR * D);
+    float* t2 = arena.alloc_f((size_t)MR * D);
+    float* hdec = arena.alloc_f((size_t)MR * lin1_.cout);
+    float* arlog = arena.alloc_f((size_t)MR * C);
+    int* tok = (int*)arena.alloc_bytes((size_t)MR * sizeof(int));
+    int* raw = (int*)arena.alloc_bytes((size_t)MR * sizeof(int));
+    int* tok2 = (int*)arena.alloc_bytes((size_t)MR * sizeof(int));
+    int* state = (int*)arena.alloc_bytes((size_t)B * 4 * sizeof(int));
+    int* not_done = (int*)arena.alloc_bytes(256);
+    unsigned char* kpm = (unsigned char*)arena.alloc_bytes((size_t)MR);
+    if (dry) return;
+
+    nchw3_to_nhwc4(s, x, B, img_h_, W, x4);
+    {
+      ConvArgs a;
+      a.stride = ph_;
+      a.stride_w = pw_;
+      conv2d(s, x4, patch_, a, tk);
+    }
+    float* xs = tk.p;  // [M][D] token stream, updated in place
+    add_pos_embed(s, xs, pos_embed_, B, gh_, gw, full_gw_, D);
+    const float scale = 1.f / std::sqrt((float)hd);
+    for (const EncBlock& b : blocks_) {
+      ln(s, xs, b.ln1g, b.ln1b, 1e-6f, y, M, D);
+      gemm(s, y, M, D, D, b.qkv, ACT_NONE, nullptr, 0, qkv, 3 * D);
+      flash_attention(s, qkv, qkv + D, qkv + 2 * D, att, B, eh_, L, L, hd, 3 * D, 3 * D, 3 * D, D, (long)L * 3 * D,
+                      (long)L * 3 * D, (long)L * 3 * D, (long)L * D, scale);
+      gemm(s, att, M, D, D, b.proj, ACT_NONE, xs, D, xs, D);
+      ln(s, xs, b.ln2g, b.ln2b, 1e-6f, y, M, D);
+      gemm(s, y, M, D, D, b.fc1, ACT_GELU, nullptr, 0, hbuf, b.fc1.cout);
+      gemm(s, hbuf, M, b.fc1.cout, b.fc1.cout, b.fc2, ACT_NONE, xs, D, xs, D);
+    }
+    ln(s, xs, enc_ng_, enc_nb_, 1e-6f, mem, M, D);
+
+    // ---------------- decoder: batch-invariant pieces + memory K|V
+    gemm(s, mem, M, D, D, ca_kv_, ACT_NONE, nullptr, 0, memkv, 2 * D);
+    ln(s, posq_, nqg_, nqb_, 1e-5f, t1, NS, D);
+    gemm(s, t1, NS, D, D, sa_q_, ACT_NONE, nullptr, 0, qsa, D);
+    fill_i32(s, tok, pad_, (size_t)MR);
+    {
+      // tok[:, 0] = bos; state = {0, 0, -1, 0}
+      std::vector<int> st((size_t)B * 4, 0);
+      for (int b = 0; b < B; ++b) st[b * 4 + 2] = -1;
+      YMK_HIP(hipMemcpyAsync(state, st.data(), st.size() * sizeof(int), hipMemcpyHostToDevice, s));
+      std::vector<int> col((size_t)B, bos_);
+      YMK_HIP(hipMemcpy2DAsync(tok, (size_t)NS * sizeof(int), col.data(), sizeof(int), sizeof(int), B,
+                               hipMemcpyHostToDevice, s));
+      YMK_HIP(hipStreamSynchronize(s));  // host vectors go out of scope
+    }
+    const int dhd = D / dh_;
+    const float dscale = 1.f / std::sqrt((float)dhd);
+    int steps = 0;
+    for (int i = 0; i < NS; ++i) {
+      // content row i (token tok[:, i]) -> norm_c -> K|V cache row i
+      ctx_embed_ln(s, tok, NS, i, 1, emb_, posq_, ncg_, ncb_, 1e-5f, cn, NS, D, B);
+      gemm(s, cn + (size_t)i * D, B, D, NS * D, sa_kv_, ACT_NONE, nullptr, 0, skv + (size_t)i * 2 * D, NS * 2 * D);
+      // query i attends context 0..i (mask row i of triu(1) blocks nothing among those keys)
+      small_attention(s, qsa + (size_t)i * D, skv, skv + D, t1, B, dh_, 1, i + 1, dhd, D, 2 * D, 2 * D, D, 0,
+                      (long)NS * 2 * D, (long)NS * 2 * D, D, dscale, nullptr, 0, nullptr, 0);
+      gemm(s, t1, B, D, D, sa_o_, ACT_NONE, posq_ + (size_t)i * D, 0, qcur, D);
+      stream_tail(s, qcur, B, B, 1, memkv, L, t1, t2, hdec, arlog + (size_t)i * C, NS * C);
+      YMK_HIP(hipMemsetAsync(not_done, 0, sizeof(int), s));
+      greedy_step(s, arlog + (size_t)i * C, (long)NS * C, C, i, NS, tok, raw, NS, state, eos_, rep_on_, rep_pmax_, rep_p1_,
+                  rep_min_, not_done, B);
+      steps = i + 1;
+      if (i + 1 < NS) {
+        YMK_HIP(hipMemcpyAsync(host_flag_, not_done, sizeof(int), hipMemcpyDeviceToHost, s));
+        YMK_HIP(hipStreamSynchronize(s));
+        if (*host_flag_ == 0) break;  // every row holds an <eos> (models/parseq.py:245-250)
+      }
+    }
+    *ar_steps = steps;
+
+    if (refine_ > 0) {
+      tile_rows(s, posq_, NS, D, posq_t, B);
+      int S_in = steps;
+      const int* prev_raw = raw;
+      for (int it = 0; it < refine_; ++it) {
+        if (it > 0) {
+          row_argmax(s, logits, MR, C, raw);
+          S_in = NS;
+        }
+        refine_prep(s, prev_raw, NS, S_in, bos_, eos_, tok2, kpm, B);
+        ctx_embed_ln(s, tok2, NS, 0, S_in, emb_, posq_, ncg_, ncb_, 1e-5f, cn, NS, D, B);
+        // project every row of the [B][NS] context buffer; rows >= S_in are stale but never attended (Lk = S_in)
+        gemm(s, cn, MR, D, D, sa_kv_, ACT_NONE, nullptr, 0, skv, 2 * D);
+        small_attention(s, qsa, skv, skv + D, t1, B, dh_, NS, S_in, dhd, D, 2 * D, 2 * D, D, 0, (long)NS * 2 * D,
+                        (long)NS * 2 * D, (long)NS * D, dscale, qmask_, NS, kpm, NS);
+        gemm(s, t1, MR, D, D, sa_o_, ACT_NONE, posq_t, D, qcur, D);
+        stream_tail(s, qcur, MR, B, NS, memkv, L, t1, t2, hdec, logits, C);
+      }
+      if (rep_on_) rep_cut(s, logits, (long)NS * C, C, NS, state, eos_, B);
+      *out_len = NS;
+    } else {
+      YMK_HIP(hipMemcpyAsync(logits, arlog, (size_t)MR * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+      if (rep_on_) rep_cut(s, logits, (long)NS * C, C, steps, state, eos_, B);
+      *out_len = steps;
+    }
+  }
+
+  int ph_ = 4, pw_ = 8, img_h_ = 32, img_w_ = 800, D_ = 192, eh_ = 6, depth_ = 12, Dd_ = 192, dh_ = 6;
+  int ntok_ = 7121, maxlen_ = 100, refine_ = 1, rep_on_ = 1, rep_pmax_ = 8, rep_p1_ = 8, rep_min_ = 3;
+  int C_ = 0, eos_ = 0, bos_ = 0, pad_ = 0, nsteps_ = 101, gh_ = 8, full_gw_ = 100;
+  ConvW patch_;
+  float* pos_embed_ = nullptr;
+  std::vector<EncBlock> blocks_;
+  float *enc_ng_ = nullptr, *enc_nb_ = nullptr;
+  ConvW sa_q_, sa_kv_, sa_o_, ca_q_, ca_kv_, ca_o_, lin1_, lin2_, head_;
+  float *n1g_, *n1b_, *n2g_, *n2b_, *nqg_, *nqb_, *ncg_, *ncb_, *dng_, *dnb_;
+  float *emb_ = nullptr, *posq_ = nullptr;
+  unsigned char* qmask_ = nullptr;
+  int* host_flag_ = nullptr;
+  uint64_t shape_key_ = 0;
+};
+
+}  // namespace
+
+Model* create_parseq() { return new ParseqModel(); }
+
+void parseq_forward(Model* m, const float* x, int B, int W, float* logits, int* out_len, int* ar_steps, hipStream_t s) {
+  auto* p = dynamic_cast<ParseqModel*>(m);
+  YMK_CHECK(p != nullptr, "model is not a parseq");
+  p->forward(x, B, W, logits, out_len, ar_steps, s);
+}
+void parseq_dims(Model* m, int* num_steps, int* num_classes) {
+  auto* p = dynamic_cast<ParseqModel*>(m);
+  YMK_CHECK(p != nullptr, "model is not a parseq");
+  *num_steps = p->num_steps();
+  *num_classes = p->num_classes();
+}
+
+}  // namespace ymk

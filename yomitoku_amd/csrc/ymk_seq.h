@@ -1,0 +1,31 @@
+// Declarations of the token-sequence kernels (ymk_seq.hip).
+#pragma once
+#include "ymk_common.h"
+
+namespace ymk {
+
+void layernorm(hipStream_t s, const float* x, int ldx, int in_rows_mod, const float* g, const float* b, float eps,
+               float* y, int ldy, int M, int D);
+void add_pos_embed(hipStream_t s, float* x, const float* pos, int B, int gh, int gw, int full_gw, int D);
+
+// O[b, q, h*hd:(h+1)*hd] = softmax(scale * Q K^T) V   (no mask; keys 0..Lk-1)
+void flash_attention(hipStream_t s, const float* q, const float* k, const float* v, float* o, int B, int H, int Lq, int Lk,
+                     int hd, int ldq, int ldk, int ldv, int ldo, long bsq, long bsk, long bsv, long bso, float scale);
+// same contract plus boolean masks (non-zero = blocked), for few queries / short key lists
+void small_attention(hipStream_t s, const float* q, const float* k, const float* v, float* o, int B, int H, int Lq, int Lk,
+                     int hd, int ldq, int ldk, int ldv, int ldo, long bsq, long bsk, long bsv, long bso, float scale,
+                     const unsigned char* mask_qk, int ld_mask, const unsigned char* kpm, int ld_kpm);
+
+void ctx_embed_ln(hipStream_t s, const int* tok, int ld_tok, int pos0, int npos, const float* emb, const float* posq,
+                  const float* g, const float* be, float eps, float* out, int out_rows, int D, int B);
+void greedy_step(hipStream_t s, const float* logits, long ld_b, int C, int step, int num_steps, int* tok, int* raw,
+                 int ld_tok, int* state, int eos_id, int rep_on, int period_max, int min_run_p1, int min_repeats,
+                 int* not_done, int B);
+void refine_prep(hipStream_t s, const int* raw, int ld_tok, int S, int bos_id, int eos_id, int* tok2, unsigned char* kpm,
+                 int B);
+void row_argmax(hipStream_t s, const float* logits, int rows, int C, int* out);
+void rep_cut(hipStream_t s, float* logits, long ld_b, int C, int S, const int* state, int eos_id, int B);
+void row_maxprob(hipStream_t s, const float* logits, int rows, int C, int* ids, float* probs);
+void fill_i32(hipStream_t s, int* p, int v, size_t n);
+
+}  // namespace ymk

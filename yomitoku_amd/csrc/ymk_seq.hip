@@ -1,0 +1,620 @@
+// Token-sequence kernels for the transformers on the path (PARSeq ViT encoder + AR decoder,
+// RT-DETR AIFI / decoder): LayerNorm, position embedding, fp32-MFMA flash attention, a masked
+// small-query attention, and the on-device greedy-decode bookkeeping of PARSeq.
+#include "ymk_common.h"
+#include "ymk_seq.h"
+
+namespace ymk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------- LayerNorm over the last dim
+// one wave per row; D <= 1024, D % 4 == 0.  torch: (x - mean) / sqrt(var_biased + eps) * g + b
+// `in_rows_mod` > 0 reads row (m % in_rows_mod): a [rows_mod][D] table broadcast over the batch.
+__global__ void k_layernorm(const float* __restrict__ x, int ldx, int in_rows_mod, const float* __restrict__ g,
+                            const float* __restrict__ b, float eps, float* __restrict__ y, int ldy, int M, int D) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* xr = x + (size_t)(in_rows_mod > 0 ? row % in_rows_mod : row) * ldx;
+  float4 v[4];
+  const int nv = D >> 2;  // float4 count, <= 256
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv) {
+      v[i] = *reinterpret_cast<const float4*>(xr + c * 4);
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv) {
+      const float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + bb * bb) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = 1.f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv) {
+      const float4 gg = *reinterpret_cast<const float4*>(g + c * 4);
+      const float4 be = *reinterpret_cast<const float4*>(b + c * 4);
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * gg.x + be.x;
+      o.y = (v[i].y - mean) * rstd * gg.y + be.y;
+      o.z = (v[i].z - mean) * rstd * gg.z + be.z;
+      o.w = (v[i].w - mean) * rstd * gg.w + be.w;
+      *reinterpret_cast<float4*>(y + (size_t)row * ldy + c * 4) = o;
+    }
+  }
+}
+void layernorm(hipStream_t s, const float* x, int ldx, int in_rows_mod, const float* g, const float* b, float eps,
+               float* y, int ldy, int M, int D) {
+  YMK_CHECK(D % 4 == 0 && D <= 1024, "layernorm: D must be a multiple of 4, <= 1024");
+  if (M == 0) return;
+  hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, s, x, ldx, in_rows_mod, g, b, eps, y, ldy, M, D);
+  YMK_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------- x[b, r, c, :] += pos[r*full_gw + c, :]
+__global__ void k_add_pos(float* __restrict__ x, const float* __restrict__ pos, int gh, int gw, int full_gw, int D4,
+                          size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % D4);
+    const size_t tok = i / D4;
+    const int cc = (int)(tok % gw);
+    const int rr = (int)((tok / gw) % gh);
+    float4 v = reinterpret_cast<float4*>(x)[i];
+    const float4 p = reinterpret_cast<const float4*>(pos)[(size_t)(rr * full_gw + cc) * D4 + c4];
+    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    reinterpret_cast<float4*>(x)[i] = v;
+  }
+}
+void add_pos_embed(hipStream_t s, float* x, const float* pos, int B, int gh, int gw, int full_gw, int D) {
+  const size_t total = (size_t)B * gh * gw * (D / 4);
+  size_t g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(k_add_pos, dim3((int)g), dim3(256), 0, s, x, pos, gh, gw, full_gw, D / 4, total);
+  YMK_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------- flash attention, exact fp32 on the MFMA pipe
+// One wave owns 32 queries of one (batch, head); 4 waves per block share K/V tiles of 64 keys in LDS.
+// Scores are computed transposed, S^T = K Q^T, so that a lane's 16 accumulator registers all belong to
+// ITS query (column lane&31): the running max / sum of the online softmax are lane-local plus one
+// exchange with lane^32, and P never leaves registers - register r of S^T is exactly the B operand
+// of step r of O^T += V^T P^T (the k order of that product is free, so it follows the D layout:
+// key(r, half) = (r&3) + 8*(r>>2) + 4*half).
+struct AttnP {
+  const float *q, *k, *v;
+  float* o;
+  int ldq, ldk, ldv, ldo;          // row strides (floats)
+  long bsq, bsk, bsv, bso;         // batch strides (floats)
+  int Lq, Lk, H;
+  float scale;
+};
+
+template <int HD>
+__global__ __launch_bounds__(256, 1) void k_flash_attn(AttnP p) {
+  constexpr int KT = 64;           // keys per LDS tile
+  constexpr int LDH = HD + 4;      // padded row
+  constexpr int NKC = HD / 8;      // k-chunks of 8 in the QK^T product
+  constexpr int NDC = HD / 32;     // 32-wide d chunks of the output
+  constexpr int LPT = (KT * HD / 4) / 256;  // float4 loads per thread per operand
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * KT * LDH];
+
+  const int t = threadIdx.x, wv = t >> 6, lane = t & 63, li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wv * 32;
+  const float* qb = p.q + (size_t)b * p.bsq + h * HD;
+  const float* kb = p.k + (size_t)b * p.bsk + h * HD;
+  const float* vb = p.v + (size_t)b * p.bsv + h * HD;
+
+  // this lane's query row, pre-scaled: Q[q][kc*8 + 4*lh + s]
+  f32x4 qf[NKC];
+  {
+    const int qi = min(q0 + li, p.Lq - 1);
+    const float* qr = qb + (size_t)qi * p.ldq;
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) {
+      qf[kc] = *reinterpret_cast<const f32x4*>(qr + kc * 8 + lh * 4);
+      qf[kc] *= p.scale;
+    }
+  }
+
+  f32x16 oacc[NDC];
+#pragma unroll
+  for (int dc = 0; dc < NDC; ++dc)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[dc][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  f32x4 rk[LPT], rv[LPT];
+  auto load_kv = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+      const int idx = t + 256 * i;
+      const int row = idx / (HD / 4), c4 = idx - row * (HD / 4);
+      const int key = min(k0 + row, p.Lk - 1);
+      rk[i] = *reinterpret_cast<const f32x4*>(kb + (size_t)key * p.ldk + c4 * 4);
+      rv[i] = *reinterpret_cast<const f32x4*>(vb + (size_t)key * p.ldv + c4 * 4);
+    }
+  };
+  auto store_kv = [&](int buf) {
+    float* Ks = lds + buf * (2 * KT * LDH);
+    float* Vs = Ks + KT * LDH;
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+      const int idx = t + 256 * i;
+      const int row = idx / (HD / 4), c4 = idx - row * (HD / 4);
+      *reinterpret_cast<f32x4*>(Ks + row * LDH + c4 * 4) = rk[i];
+      *reinterpret_cast<f32x4*>(Vs + row * LDH + c4 * 4) = rv[i];
+    }
+  };
+
+  const int ntiles = (p.Lk + KT - 1) / KT;
+  load_kv(0);
+  store_kv(0);
+  __syncthreads();
+  for (int tt = 0; tt < ntiles; ++tt) {
+    const int buf = tt & 1;
+    if (tt + 1 < ntiles) load_kv((tt + 1) * KT);
+    const float* Ks = lds + buf * (2 * KT * LDH);
+    const float* Vs = Ks + KT * LDH;
+#pragma unroll
+    for (int sub = 0; sub < KT / 32; ++sub) {
+      const int kbase = tt * KT + sub * 32;
+      if (kbase >= p.Lk) break;  // wave-uniform
+      // ---- S^T[key][q] for 32 keys x 32 queries
+      f32x16 sacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+      const float* kr = Ks + (sub * 32 + li) * LDH + lh * 4;
+#pragma unroll
+      for (int kc = 0; kc < NKC; ++kc) {
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(kr + kc * 8);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[kc].x, sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[kc].y, sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[kc].z, sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[kc].w, sacc, 0, 0, 0);
+      }
+      // ---- online softmax for this lane's query
+      float mt = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (key >= p.Lk) sacc[r] = -INFINITY;
+        mt = fmaxf(mt, sacc[r]);
+      }
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float m_new = fmaxf(m_run, mt);  // finite: every tile has >= 1 valid key
+      const float alpha = __expf(m_run - m_new);
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sacc[r] = __expf(sacc[r] - m_new);
+        ps += sacc[r];
+      }
+      ps += __shfl_xor(ps, 32, 64);
+      l_run = l_run * alpha + ps;
+      m_run = m_new;
+      // ---- O^T[d][q] = alpha * O^T + V^T P^T
+#pragma unroll
+      for (int dc = 0; dc < NDC; ++dc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dc][r] *= alpha;
+        const float* vr = Vs + (sub * 32 + 4 * lh) * LDH + dc * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float vf = vr[((r & 3) + 8 * (r >> 2)) * LDH];
+          oacc[dc] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, sacc[r], oacc[dc], 0, 0, 0);
+        }
+      }
+    }
+    if (tt + 1 < ntiles) store_kv(buf ^ 1);
+    __syncthreads();
+  }
+  // ---- normalise and store: lane holds d = dc*32 + (r&3) + 8*(r>>2) + 4*lh of query q0 + li
+  const int qi = q0 + li;
+  if (qi < p.Lq) {
+    const float inv = 1.f / l_run;
+    float* orow = p.o + (size_t)b * p.bso + (size_t)qi * p.ldo + h * HD;
+#pragma unroll
+    for (int dc = 0; dc < NDC; ++dc)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 w;
+        w.x = oacc[dc][4 * g + 0] * inv;
+        w.y = oacc[dc][4 * g + 1] * inv;
+        w.z = oacc[dc][4 * g + 2] * inv;
+        w.w = oacc[dc][4 * g + 3] * inv;
+        *reinterpret_cast<f32x4*>(orow + dc * 32 + 8 * g + 4 * lh) = w;
+      }
+  }
+}
+
+void flash_attention(hipStream_t s, const float* q, const float* k, const float* v, float* o, int B, int H, int Lq, int Lk,
+                     int hd, int ldq, int ldk, int ldv, int ldo, long bsq, long bsk, long bsv, long bso, float scale) {
+  if (B == 0 || Lq == 0) return;
+  YMK_CHECK(Lk > 0, "attention: no keys");
+  YMK_CHECK(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0, "attention: strides must be multiples of 4");
+  AttnP p{q, k, v, o, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, Lq, Lk, H, scale};
+  dim3 grid((Lq + 127) / 128, H, B);
+  if (hd == 32) hipLaunchKernelGGL(k_flash_attn<32>, grid, dim3(256), 0, s, p);
+  else if (hd == 64) hipLaunchKernelGGL(k_flash_attn<64>, grid, dim3(256), 0, s, p);
+  else if (hd == 96) hipLaunchKernelGGL(k_flash_attn<96>, grid, dim3(256), 0, s, p);
+  else throw Error("attention: unsupported head dim " + std::to_string(hd));
+  YMK_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------- masked attention for a handful of queries
+// One wave per (batch, head, query).  mask_qk[q][k] != 0 blocks key k for query q (shared by the
+// batch, row stride ld_mask); kpm[b][k] != 0 blocks key k for the whole sample.  Lk <= 1024.
+struct SmallAttnP {
+  const float *q, *k, *v;
+  float* o;
+  int ldq, ldk, ldv, ldo;
+  long bsq, bsk, bsv, bso;  // bsq may be 0: queries shared by the batch
+  int Lq, Lk, H, hd;
+  float scale;
+  const unsigned char* mask_qk;
+  int ld_mask;
+  const unsigned char* kpm;
+  int ld_kpm;
+};
+__global__ __launch_bounds__(64) void k_small_attn(SmallAttnP p) {
+  __shared__ float prob[1024];
+  __shared__ float qs[128];
+  const int lane = threadIdx.x;
+  const int qi = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const float* qr = p.q + (size_t)b * p.bsq + (size_t)qi * p.ldq + h * p.hd;
+  for (int d = lane; d < p.hd; d += 64) qs[d] = qr[d] * p.scale;
+  __syncthreads();
+  const float* kb = p.k + (size_t)b * p.bsk + h * p.hd;
+  const float* vb = p.v + (size_t)b * p.bsv + h * p.hd;
+  float mx = -INFINITY;
+  for (int k = lane; k < p.Lk; k += 64) {
+    bool blocked = false;
+    if (p.mask_qk) blocked = p.mask_qk[(size_t)qi * p.ld_mask + k] != 0;
+    if (p.kpm) blocked = blocked || p.kpm[(size_t)b * p.ld_kpm + k] != 0;
+    float sc = -INFINITY;
+    if (!blocked) {
+      const float* kr = kb + (size_t)k * p.ldk;
+      float a = 0.f;
+      for (int d = 0; d < p.hd; d += 4) {
+        const float4 kk = *reinterpret_cast<const float4*>(kr + d);
+        a += qs[d] * kk.x + qs[d + 1] * kk.y + qs[d + 2] * kk.z + qs[d + 3] * kk.w;
+      }
+      sc = a;
+    }
+    prob[k] = sc;
+    mx = fmaxf(mx, sc);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int k = lane; k < p.Lk; k += 64) {
+    const float e = __expf(prob[k] - mx);
+    prob[k] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  __syncthreads();
+  const float inv = 1.f / sum;
+  float* orow = p.o + (size_t)b * p.bso + (size_t)qi * p.ldo + h * p.hd;
+  for (int d = lane; d < p.hd; d += 64) {
+    float a = 0.f;
+    for (int k = 0; k < p.Lk; ++k) a += prob[k] * vb[(size_t)k * p.ldv + d];
+    orow[d] = a * inv;
+  }
+}
+void small_attention(hipStream_t s, const float* q, const float* k, const float* v, float* o, int B, int H, int Lq, int Lk,
+                     int hd, int ldq, int ldk, int ldv, int ldo, long bsq, long bsk, long bsv, long bso, float scale,
+                     const unsigned char* mask_qk, int ld_mask, const unsigned char* kpm, int ld_kpm) {
+  if (B == 0 || Lq == 0) return;
+  YMK_CHECK(Lk > 0 && Lk <= 1024 && hd <= 128 && hd % 4 == 0, "small attention: Lk <= 1024, hd <= 128");
+  SmallAttnP p{q, k, v, o, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, Lq, Lk, H, hd, scale, mask_qk, ld_mask, kpm, ld_kpm};
+  hipLaunchKernelGGL(k_small_attn, dim3(Lq, H, B), dim3(64), 0, s, p);
+  YMK_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------- PARSeq decode bookkeeping
+// content row of position `pos` for every sample (models/parseq.py:143-146), then norm_c:
+//   pos == 0: sqrt(D) * emb[tok]            pos >= 1: pos_queries[pos-1] + sqrt(D) * emb[tok]
+// tokens: [B][ld_tok]; out rows b*out_rows + pos_out.  One wave per (sample, position).
+__global__ void k_ctx_embed_ln(const int* __restrict__ tok, int ld_tok, int pos0, int npos, const float* __restrict__ emb,
+                               const float* __restrict__ posq, const float* __restrict__ g, const float* __restrict__ be,
+                               float eps, float sqrt_d, float* __restrict__ out, int out_rows, int D, int B) {
+  const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (w >= B * npos) return;
+  const int b = w / npos, pos = pos0 + (w - b * npos);
+  const int token = tok[(size_t)b * ld_tok + pos];
+  const float* er = emb + (size_t)token * D;
+  const float* pr = pos > 0 ? posq + (size_t)(pos - 1) * D : nullptr;
+  float v[16];
+  float s = 0.f;
+  const int per = (D + 63) / 64;  // <= 16 (D <= 1024)
+  for (int i = 0; i < per; ++i) {
+    const int c = lane + 64 * i;
+    float x = 0.f;
+    if (c < D) {
+      x = sqrt_d * er[c];
+      if (pr) x = pr[c] + x;
+      s += x;
+    }
+    v[i] = x;
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+  for (int i = 0; i < per; ++i) {
+    const int c = lane + 64 * i;
+    if (c < D) q += (v[i] - mean) * (v[i] - mean);
+  }
+  const float rstd = 1.f / sqrtf(wave_sum(q) / (float)D + eps);
+  float* orow = out + ((size_t)b * out_rows + pos) * D;
+  for (int i = 0; i < per; ++i) {
+    const int c = lane + 64 * i;
+    if (c < D) orow[c] = (v[i] - mean) * rstd * g[c] + be[c];
+  }
+}
+void ctx_embed_ln(hipStream_t s, const int* tok, int ld_tok, int pos0, int npos, const float* emb, const float* posq,
+                  const float* g, const float* be, float eps, float* out, int out_rows, int D, int B) {
+  YMK_CHECK(D <= 1024, "ctx_embed: D <= 1024");
+  const int waves = B * npos;
+  if (waves == 0) return;
+  hipLaunchKernelGGL(k_ctx_embed_ln, dim3((waves + 3) / 4), dim3(256), 0, s, tok, ld_tok, pos0, npos, emb, posq, g, be, eps,
+                     sqrtf((float)D), out, out_rows, D, B);
+  YMK_HIP(hipGetLastError());
+}
+
+// greedy step (models/parseq.py:222-250): argmax over C of logits[b][step][:], write the raw argmax,
+// the context token for position step+1 (forced to <eos> when a repetition loop is detected), and the
+// per-sample flags; one block per sample.  state[b] = {has_eos, rep_done, rep_cut(-1 = none)}.
+__global__ __launch_bounds__(256) void k_greedy_step(const float* __restrict__ logits, long ld_b, int C, int step,
+                                                     int num_steps, int* __restrict__ tok, int* __restrict__ raw,
+                                                     int ld_tok, int* __restrict__ state, int eos_id, int rep_on,
+                                                     int period_max, int min_run_p1, int min_repeats,
+                                                     int* __restrict__ not_done) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* row = logits + (size_t)b * ld_b;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = t; c < C; c += 256) {
+    const float v = row[c];
+    if (v > best) {  // strict: keeps the lowest index among equal values within a thread
+      best = v;
+      bi = c;
+    }
+  }
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  sv[t] = best;
+  si[t] = bi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) {
+      const float v2 = sv[t + o];
+      const int i2 = si[t + o];
+      if (v2 > sv[t] || (v2 == sv[t] && i2 < si[t])) {  // torch.argmax returns the first maximal index
+        sv[t] = v2;
+        si[t] = i2;
+      }
+    }
+    __syncthreads();
+  }
+  if (t != 0) return;
+  const int am = si[0];
+  raw[(size_t)b * ld_tok + step] = am;
+  int* st = state + b * 4;
+  const int j = step + 1;
+  if (j < num_steps) {
+    int* trow = tok + (size_t)b * ld_tok;
+    int next = am;
+    if (rep_on && !st[1] && next != eos_id) {
+      // _detect_repeat_onset on seq = trow[1..j] with trow[j] = next (models/parseq.py:108-128)
+      trow[j] = next;
+      const int* seq = trow + 1;
+      const int n = j;
+      for (int pp = 1; pp <= period_max; ++pp) {
+        if (n < 2 * pp) continue;
+        int k = 1, tpos = n - pp;
+        while (tpos - pp >= 0) {
+          bool same = true;
+          for (int u = 0; u < pp; ++u)
+            if (seq[tpos - pp + u] != seq[n - pp + u]) {
+              same = false;
+              break;
+            }
+          if (!same) break;
+          ++k;
+          tpos -= pp;
+        }
+        if (k >= (pp == 1 ? min_run_p1 : min_repeats)) {
+          st[2] = tpos + pp;  // rep_cut: keep the prefix + one unit
+          st[1] = 1;
+          next = eos_id;
+          break;
+        }
+      }
+    }
+    trow[j] = next;
+    if (next == eos_id) st[0] = 1;
+  }
+  if (!st[0]) atomicAdd(not_done, 1);
+}
+void greedy_step(hipStream_t s, const float* logits, long ld_b, int C, int step, int num_steps, int* tok, int* raw,
+                 int ld_tok, int* state, int eos_id, int rep_on, int period_max, int min_run_p1, int min_repeats,
+                 int* not_done, int B) {
+  hipLaunchKernelGGL(k_greedy_step, dim3(B), dim3(256), 0, s, logits, ld_b, C, step, num_steps, tok, raw, ld_tok, state,
+                     eos_id, rep_on, period_max, min_run_p1, min_repeats, not_done);
+  YMK_HIP(hipGetLastError());
+}
+
+// refinement inputs (models/parseq.py:286-292): tok2 = [bos, raw[0..S-2]]; kpm = cumsum(tok2 == eos) > 0
+__global__ void k_refine_prep(const int* __restrict__ raw, int ld_tok, int S, int bos_id, int eos_id, int* __restrict__ tok2,
+                              unsigned char* __restrict__ kpm, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  bool seen = false;
+  for (int t = 0; t < S; ++t) {
+    const int v = t == 0 ? bos_id : raw[(size_t)b * ld_tok + t - 1];
+    tok2[(size_t)b * ld_tok + t] = v;
+    seen = seen || (v == eos_id);
+    kpm[(size_t)b * ld_tok + t] = seen ? 1 : 0;
+  }
+}
+void refine_prep(hipStream_t s, const int* raw, int ld_tok, int S, int bos_id, int eos_id, int* tok2, unsigned char* kpm,
+                 int B) {
+  hipLaunchKernelGGL(k_refine_prep, dim3((B + 63) / 64), dim3(64), 0, s, raw, ld_tok, S, bos_id, eos_id, tok2, kpm, B);
+  YMK_HIP(hipGetLastError());
+}
+
+// raw[b][t] = argmax(logits[b][t][:]) for t < S (used between refinement iterations)
+__global__ __launch_bounds__(256) void k_row_argmax(const float* __restrict__ logits, int C, int* __restrict__ out) {
+  const size_t rowi = blockIdx.x;
+  const int t = threadIdx.x;
+  const float* row = logits + rowi * C;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = t; c < C; c += 256) {
+    const float v = row[c];
+    if (v > best) {
+      best = v;
+      bi = c;
+    }
+  }
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  sv[t] = best;
+  si[t] = bi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) {
+      const float v2 = sv[t + o];
+      const int i2 = si[t + o];
+      if (v2 > sv[t] || (v2 == sv[t] && i2 < si[t])) {
+        sv[t] = v2;
+        si[t] = i2;
+      }
+    }
+    __syncthreads();
+  }
+  if (t == 0) out[rowi] = si[0];
+}
+void row_argmax(hipStream_t s, const float* logits, int rows, int C, int* out) {
+  if (rows == 0) return;
+  hipLaunchKernelGGL(k_row_argmax, dim3(rows), dim3(256), 0, s, logits, C, out);
+  YMK_HIP(hipGetLastError());
+}
+
+// repetition cut (models/parseq.py:301-309): logits[b][cut][:] = -30, [eos] = +30
+__global__ void k_rep_cut(float* __restrict__ logits, long ld_b, int C, int S, const int* __restrict__ state, int eos_id) {
+  const int b = blockIdx.x;
+  const int cut = state[b * 4 + 2];
+  if (cut < 0 || cut >= S) return;
+  float* row = logits + (size_t)b * ld_b + (size_t)cut * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) row[c] = c == eos_id ? 30.f : -30.f;
+}
+void rep_cut(hipStream_t s, float* logits, long ld_b, int C, int S, const int* state, int eos_id, int B) {
+  hipLaunchKernelGGL(k_rep_cut, dim3(B), dim3(256), 0, s, logits, ld_b, C, S, state, eos_id);
+  YMK_HIP(hipGetLastError());
+}
+
+// softmax statistics the tokenizer needs (postprocessor/parseq_tokenizer.py:79-87): per row the
+// arg-max class and its probability max(softmax(x)) = 1 / sum(exp(x - max)).
+__global__ __launch_bounds__(256) void k_row_maxprob(const float* __restrict__ logits, int C, int* __restrict__ ids,
+                                                     float* __restrict__ probs) {
+  const size_t rowi = blockIdx.x;
+  const int t = threadIdx.x;
+  const float* row = logits + rowi * C;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = t; c < C; c += 256) {
+    const float v = row[c];
+    if (v > best) {
+      best = v;
+      bi = c;
+    }
+  }
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  sv[t] = best;
+  si[t] = bi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) {
+      const float v2 = sv[t + o];
+      const int i2 = si[t + o];
+      if (v2 > sv[t] || (v2 == sv[t] && i2 < si[t])) {
+        sv[t] = v2;
+        si[t] = i2;
+      }
+    }
+    __syncthreads();
+  }
+  const float mx = sv[0];
+  const int am = si[0];
+  __syncthreads();
+  float sum = 0.f;
+  for (int c = t; c < C; c += 256) sum += expf(row[c] - mx);
+  sv[t] = sum;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) sv[t] += sv[t + o];
+    __syncthreads();
+  }
+  if (t == 0) {
+    ids[rowi] = am;
+    probs[rowi] = 1.f / sv[0];
+  }
+}
+void row_maxprob(hipStream_t s, const float* logits, int rows, int C, int* ids, float* probs) {
+  if (rows == 0) return;
+  hipLaunchKernelGGL(k_row_maxprob, dim3(rows), dim3(256), 0, s, logits, C, ids, probs);
+  YMK_HIP(hipGetLastError());
+}
+
+__global__ void k_tile_rows(const float4* __restrict__ src, float4* __restrict__ dst, size_t per, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = src[i % per];
+}
+// dst[b][r][:] = src[r][:] for b < B
+void tile_rows(hipStream_t s, const float* src, int rows, int D, float* dst, int B) {
+  const size_t per = (size_t)rows * D / 4, total = per * B;
+  if (total == 0) return;
+  size_t g = (total + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(k_tile_rows, dim3((int)g), dim3(256), 0, s, (const float4*)src, (float4*)dst, per, total);
+  YMK_HIP(hipGetLastError());
+}
+
+__global__ void k_fill_i32(int* p, int v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+void fill_i32(hipStream_t s, int* p, int v, size_t n) {
+  if (n == 0) return;
+  size_t g = (n + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(k_fill_i32, dim3((int)g), dim3(256), 0, s, p, v, n);
+  YMK_HIP(hipGetLastError());
+}
+
+}  // namespace ymk

@@ -82,3 +82,40 @@ def upsample_bilinear(x, size, add=None):
             "ymk_op_upsample_bilinear",
         )
     return _nchw(y)
+
+
+def layernorm(x, weight, bias, eps):
+    lib = _lib.load()
+    d = x.shape[-1]
+    xs = x.float().contiguous()
+    y = torch.empty_like(xs)
+    g = weight.float().to(x.device).contiguous()
+    b = bias.float().to(x.device).contiguous()
+    with torch.cuda.device(x.device):
+        _lib.check(
+            lib.ymk_op_layernorm(xs.data_ptr(), xs.numel() // d, d, g.data_ptr(), b.data_ptr(), float(eps), y.data_ptr(),
+                                 _lib.current_stream_ptr()),
+            "ymk_op_layernorm",
+        )
+    return y
+
+
+def attention(q, k, v, heads, scale=None, mask_qk=None, key_padding_mask=None, use_small=False):
+    """q [B, Lq, D], k/v [B, Lk, D] on device -> [B, Lq, D]; masks are bool tensors (True = blocked)."""
+    lib = _lib.load()
+    b, lq, d = q.shape
+    lk = k.shape[1]
+    hd = d // heads
+    scale = hd**-0.5 if scale is None else scale
+    qs, ks, vs = q.float().contiguous(), k.float().contiguous(), v.float().contiguous()
+    o = torch.empty_like(qs)
+    m = mask_qk.to(device=q.device, dtype=torch.uint8).contiguous() if mask_qk is not None else None
+    kp = key_padding_mask.to(device=q.device, dtype=torch.uint8).contiguous() if key_padding_mask is not None else None
+    with torch.cuda.device(q.device):
+        _lib.check(
+            lib.ymk_op_attention(qs.data_ptr(), ks.data_ptr(), vs.data_ptr(), o.data_ptr(), b, heads, lq, lk, hd,
+                                 float(scale), _lib.ptr(m), _lib.ptr(kp), 1 if use_small else 0,
+                                 _lib.current_stream_ptr()),
+            "ymk_op_attention",
+        )
+    return o

@@ -127,6 +127,103 @@ class HipNet:
         return net
 
 
+def _cfg_get(cfg, path, default):
+    cur = cfg
+    try:
+        for part in path.split("."):
+            cur = cur[part] if isinstance(cur, dict) else getattr(cur, part)
+        return cur
+    except (AttributeError, KeyError, TypeError):
+        return default
+
+
+class PARSeq(HipNet):
+    """PARSeq text recogniser (reference models/parseq.py:49-311).
+
+    `__call__(images)` keeps the reference contract: fp32 B x 3 x 32 x W in, logits
+    B x S x (num_tokens - 2) out (S = 101 when refine_iters >= 1).  `token_stats(logits)` is the
+    fused replacement for `.softmax(-1)` + the arg-max/max of ParseqTokenizer.decode."""
+
+    kind = "parseq"
+
+    def __init__(self, cfg=None, seed: int = 1235):
+        super().__init__(cfg)
+        self._seed = seed
+        self.tokenizer = None
+        self.export_onnx = False
+        self.refine_iters = int(_cfg_get(cfg, "refine_iters", 1))
+        self.last_ar_steps = 0
+
+    def params(self) -> dict:
+        c = self.cfg
+        patch = list(_cfg_get(c, "encoder.patch_size", [4, 8]))
+        img = list(_cfg_get(c, "data.img_size", [32, 800]))
+        return {
+            "patch_h": patch[0], "patch_w": patch[1], "img_h": img[0], "img_w": img[1],
+            "enc_dim": _cfg_get(c, "encoder.embed_dim", 192), "enc_heads": _cfg_get(c, "encoder.num_heads", 6),
+            "enc_depth": _cfg_get(c, "encoder.depth", 12),
+            "dec_dim": _cfg_get(c, "decoder.embed_dim", 192), "dec_heads": _cfg_get(c, "decoder.num_heads", 6),
+            "dec_depth": _cfg_get(c, "decoder.depth", 1),
+            "num_tokens": _cfg_get(c, "num_tokens", 7121), "max_label_length": _cfg_get(c, "max_label_length", 100),
+            "refine_iters": self.refine_iters, "decode_ar": _cfg_get(c, "decode_ar", 1),
+            "repetition_stop": int(bool(_cfg_get(c, "repetition_stop", True))),
+            "rep_period_max": _cfg_get(c, "rep_period_max", 8), "rep_min_run_p1": _cfg_get(c, "rep_min_run_p1", 8),
+            "rep_min_repeats": _cfg_get(c, "rep_min_repeats", 3),
+        }
+
+    def init_synthetic(self, seed: int | None = None, **kw):
+        from .utils.synth import parseq_state_dict
+
+        p = self.params()
+        self.load_state_dict(
+            parseq_state_dict(
+                self._seed if seed is None else seed, patch=(p["patch_h"], p["patch_w"]), enc_dim=p["enc_dim"],
+                enc_depth=p["enc_depth"], enc_mlp=int(_cfg_get(self.cfg, "encoder.mlp_ratio", 4)), dec_dim=p["dec_dim"],
+                dec_mlp=int(_cfg_get(self.cfg, "decoder.mlp_ratio", 4)), num_tokens=p["num_tokens"],
+                max_label_length=p["max_label_length"], img_size=(p["img_h"], p["img_w"]), **kw,
+            )
+        )
+        return self
+
+    def __call__(self, images: torch.Tensor):
+        import ctypes
+
+        _require_cuda(images, "PARSeq")
+        if self._h is None:
+            self.to(images.device)
+        x = images.to(torch.float32).contiguous()
+        b, c, h, w = x.shape
+        lib = _lib.load()
+        ns, nc = ctypes.c_int(), ctypes.c_int()
+        _lib.check(lib.ymk_parseq_dims(self._h, ctypes.byref(ns), ctypes.byref(nc)), "ymk_parseq_dims")
+        logits = torch.empty((b, ns.value, nc.value), dtype=torch.float32, device=x.device)
+        out_len, ar = ctypes.c_int(), ctypes.c_int()
+        with torch.cuda.device(x.device):
+            _lib.check(
+                lib.ymk_parseq_forward(self._h, x.data_ptr(), b, w, logits.data_ptr(), ctypes.byref(out_len),
+                                       ctypes.byref(ar), _lib.current_stream_ptr()),
+                "ymk_parseq_forward",
+            )
+        self.last_ar_steps = ar.value
+        return logits[:, : out_len.value]
+
+    @staticmethod
+    def token_stats(logits: torch.Tensor):
+        """(ids int32 B x S, probs fp32 B x S): per position arg-max class and max softmax probability."""
+        lib = _lib.load()
+        lg = logits.contiguous()
+        b, s, c = lg.shape
+        ids = torch.empty((b, s), dtype=torch.int32, device=lg.device)
+        probs = torch.empty((b, s), dtype=torch.float32, device=lg.device)
+        with torch.cuda.device(lg.device):
+            _lib.check(
+                lib.ymk_parseq_token_stats(lg.data_ptr(), b * s, c, ids.data_ptr(), probs.data_ptr(),
+                                           _lib.current_stream_ptr()),
+                "ymk_parseq_token_stats",
+            )
+        return ids, probs
+
+
 class DBNet(HipNet):
     """DBNet++ text detector (reference models/dbnet_plus.py:233-246)."""
 
