@@ -67,6 +67,13 @@ int ymk_parseq_forward(ymk_model* m, const float* x_dev, int b, int w, float* lo
 int ymk_parseq_token_stats(const float* logits_dev, int rows, int num_classes, int* ids_dev, float* probs_dev,
                            void* stream);
 
+/* ---- RT-DETRv2 layout parser / table-structure recogniser (replaces RTDETRv2.forward,
+ * models/rtdetr.py:16-21).  x_dev: fp32 [b][3][640][640] in [0,1] (LayoutParser.preprocess,
+ * layout_parser.py:195-199); logits_dev: fp32 [b][num_queries][num_classes] = pred_logits;
+ * boxes_dev: fp32 [b][num_queries][4] = pred_boxes (cxcywh in [0,1]). */
+int ymk_rtdetr_forward(ymk_model* m, const float* x_dev, int b, int h, int w, float* logits_dev, float* boxes_dev,
+                       void* stream);
+
 /* ---- measurement aid for bench.py (not on the product path): between begin/end every launch of
  * the implicit-GEMM convolution kernel is bracketed by HIP events on its own stream; end returns
  * the summed kernel time, the algorithmic FLOPs (2*M*Cout*KH*KW*Cin, unpadded) and launch count.

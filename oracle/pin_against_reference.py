@@ -88,10 +88,49 @@ def pin_parseq():
         )
 
 
+def pin_rtdetr():
+    from yomitoku_amd.utils.synth_rtdetr import rtdetr_state_dict
+
+    from .rtdetr import rtdetr_forward
+
+    mod = ref_import("yomitoku.models.rtdetr")
+    import omegaconf  # the stub: RTDETRTransformerv2 wants num_points as a ListConfig
+
+    for tag, nc, seed in (("layout", 6, 1240), ("table", 3, 1241)):
+        cfg = AttrDict(
+            PResNet={"depth": 50, "variant": "d", "freeze_at": 0, "return_idx": [1, 2, 3], "num_stages": 4,
+                     "freeze_norm": True},
+            HybridEncoder={"in_channels": [512, 1024, 2048], "feat_strides": [8, 16, 32], "hidden_dim": 256,
+                           "use_encoder_idx": [2], "num_encoder_layers": 1, "nhead": 8, "dim_feedforward": 1024,
+                           "dropout": 0.0, "enc_act": "gelu", "expansion": 1.0, "depth_mult": 1, "act": "silu"},
+            RTDETRTransformerv2={"num_classes": nc, "feat_channels": [256, 256, 256], "feat_strides": [8, 16, 32],
+                                 "hidden_dim": 256, "num_levels": 3, "num_layers": 6, "num_queries": 300,
+                                 "num_denoising": 100, "label_noise_ratio": 0.5, "box_noise_scale": 1.0,
+                                 "eval_spatial_size": [640, 640], "eval_idx": -1,
+                                 "num_points": omegaconf.ListConfig([4, 4, 4]), "cross_attn_method": "default",
+                                 "query_select_method": "default"},
+        )
+        sd = rtdetr_state_dict(seed, num_classes=nc)
+        model = mod.RTDETRv2(cfg)
+        res = model.load_state_dict(sd, strict=True)
+        model.eval()
+        x = torch.rand(1, 3, 640, 640, generator=torch.Generator().manual_seed(seed))
+        with torch.inference_mode():
+            ref = model(x)
+        ours = rtdetr_forward(sd, x)
+        e1 = (ref["pred_logits"] - ours["pred_logits"]).abs().max().item()
+        e2 = (ref["pred_boxes"] - ours["pred_boxes"]).abs().max().item()
+        sc = ref["pred_logits"].sigmoid()
+        print(f"[rtdetr/{tag}] reference vs oracle: logits {e1:.3e} boxes {e2:.3e}; scores>0.5: {(sc > 0.5).sum().item()} ({res})")
+        assert e1 < 1e-5 and e2 < 1e-6, (e1, e2)
+        np.savez_compressed(os.path.join(GOLDEN, f"rtdetr_ref_{tag}.npz"), seed=seed, num_classes=nc,
+                            x_seed=seed, logits=ref["pred_logits"].numpy(), boxes=ref["pred_boxes"].numpy())
+
+
 def main(argv):
     what = argv[1] if len(argv) > 1 else "all"
     os.makedirs(GOLDEN, exist_ok=True)
-    todo = {"dbnet": pin_dbnet, "parseq": pin_parseq}
+    todo = {"dbnet": pin_dbnet, "parseq": pin_parseq, "rtdetr": pin_rtdetr}
     for k, fn in todo.items():
         if what in (k, "all"):
             fn()

@@ -9,6 +9,8 @@ void dbnet_forward(Model* m, const float* x, int n, int h, int w, float* prob, h
 void parseq_forward(Model* m, const float* x, int B, int W, float* logits, int* out_len, int* ar_steps, hipStream_t s);
 void parseq_dims(Model* m, int* num_steps, int* num_classes);
 Model* create_parseq();
+Model* create_rtdetr();
+void rtdetr_forward(Model* m, const float* x, int B, int H, int W, float* logits, float* boxes, hipStream_t s);
 void row_maxprob(hipStream_t s, const float* logits, int rows, int C, int* ids, float* probs);
 void prof_begin();
 void prof_end(double* ms, double* flop, int64_t* launches);
@@ -52,6 +54,7 @@ ymk_model* ymk_model_create(const char* kind, int device) {
     ymk::Model* impl = nullptr;
     if (k == "dbnet") impl = ymk::create_dbnet();
     else if (k == "parseq") impl = ymk::create_parseq();
+    else if (k == "rtdetr") impl = ymk::create_rtdetr();
     else throw ymk::Error("unknown model kind: " + k);
     auto* m = new ymk_model();
     m->impl = impl;
@@ -125,6 +128,15 @@ int ymk_parseq_token_stats(const float* logits_dev, int rows, int num_classes, i
   YMK_API_BEGIN
   YMK_CHECK(logits_dev && ids_dev && probs_dev, "null argument");
   ymk::row_maxprob((hipStream_t)stream, logits_dev, rows, num_classes, ids_dev, probs_dev);
+  YMK_API_END
+}
+
+int ymk_rtdetr_forward(ymk_model* m, const float* x_dev, int b, int h, int w, float* logits_dev, float* boxes_dev,
+                       void* stream) {
+  YMK_API_BEGIN
+  YMK_CHECK(m && x_dev && logits_dev && boxes_dev, "null argument");
+  YMK_HIP(hipSetDevice(m->device));
+  ymk::rtdetr_forward(m->impl, x_dev, b, h, w, logits_dev, boxes_dev, (hipStream_t)stream);
   YMK_API_END
 }
 

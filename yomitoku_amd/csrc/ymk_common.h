@@ -93,7 +93,8 @@ struct ConvArgs {
   int stride_w = 0;  // 0: same as stride (vertical); PARSeq-tiny patchify is 4 x 8
   int act = ACT_NONE;
   int epi = EPI_STORE;
-  const Tensor* res = nullptr;  // residual added before the activation
+  const Tensor* res = nullptr;  // residual added before the activation ...
+  bool res_post = false;        // ... or after it (y = res + act(conv))
 };
 
 // out must be pre-shaped (n, oh, ow, cout[, ld]); for EPI_DECONV2X2 out is (n, 2h, 2w, cout/4).

@@ -35,7 +35,7 @@ struct ConvK {
   const float* res;
   float* out;
   int H, W, C, in_ld;
-  int OH, OW, Cout, out_ld, res_ld;
+  int OH, OW, Cout, out_ld, res_ld, res_post;
   int KH, KW, stride, stride_w, pad, dil;
   int Kpad, ctiles, mode;
   int M;        // n*oh*ow
@@ -48,7 +48,7 @@ struct ConvK {
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
     case ACT_RELU: return fmaxf(v, 0.f);
-    case ACT_SILU: return v / (1.f + __expf(-v));
+    case ACT_SILU: return v / (1.f + expf(-v));
     case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
     case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
     default: return v;
@@ -251,10 +251,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvK p) {
       v.z = v.z * sc.z + bi.z;
       v.w = v.w * sc.w + bi.w;
       size_t o;
+      float4 rr = zero4;
       if (p.epi == EPI_STORE) {
         if (p.res) {
-          const float4 rr = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.res_ld + co);
-          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+          rr = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.res_ld + co);
+          if (!p.res_post) {
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+          }
         }
         o = (size_t)m * p.out_ld + co;
       } else {  // ConvTranspose2d(k=2, s=2): co = (a2*2+b2)*Cq + cq -> pixel (2oh+a2, 2ow+b2)
@@ -267,6 +270,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvK p) {
       v.y = apply_act(v.y, p.act);
       v.z = apply_act(v.z, p.act);
       v.w = apply_act(v.w, p.act);
+      if (p.res_post) {  // y = res + act(conv): CSPRep "x_1 + conv2(x)" (rtdetr_hybrid_encoder.py:209-213)
+        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+      }
       *reinterpret_cast<float4*>(p.out + o) = v;
     }
   } else {  // ragged Cout / unaligned rows: scalar stores (EPI_STORE only)
@@ -276,8 +282,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvK p) {
       for (int e = 0; e < 4 && co + e < p.Cout; ++e) {
         float v = Cs[row * LDC + c4 * 4 + e];
         v = v * (p.scale ? p.scale[co + e] : 1.f) + (p.bias ? p.bias[co + e] : 0.f);
-        if (p.res) v += p.res[(size_t)m * p.res_ld + co + e];
-        p.out[(size_t)m * p.out_ld + co + e] = apply_act(v, p.act);
+        const float rr = p.res ? p.res[(size_t)m * p.res_ld + co + e] : 0.f;
+        if (!p.res_post) v += rr;
+        v = apply_act(v, p.act);
+        if (p.res_post) v += rr;
+        p.out[(size_t)m * p.out_ld + co + e] = v;
       }
     }
   }
@@ -352,6 +361,7 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
   k.bias = w.bias;
   k.res = a.res ? a.res->p : nullptr;
   k.res_ld = a.res ? a.res->ld : 0;
+  k.res_post = a.res_post ? 1 : 0;
   k.out = out.p;
   k.H = in.h;
   k.W = in.w;

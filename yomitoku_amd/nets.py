@@ -224,6 +224,64 @@ class PARSeq(HipNet):
         return ids, probs
 
 
+class RTDETRv2(HipNet):
+    """RT-DETRv2 (reference models/rtdetr.py:9-22): fp32 N x 3 x 640 x 640 ->
+    {"pred_logits": N x 300 x nc, "pred_boxes": N x 300 x 4}."""
+
+    kind = "rtdetr"
+
+    def __init__(self, cfg=None, seed: int = 1240):
+        super().__init__(cfg)
+        self._seed = seed
+
+    def params(self) -> dict:
+        c = self.cfg
+        return {
+            "num_classes": _cfg_get(c, "RTDETRTransformerv2.num_classes", 6),
+            "num_queries": _cfg_get(c, "RTDETRTransformerv2.num_queries", 300),
+            "num_layers": _cfg_get(c, "RTDETRTransformerv2.num_layers", 6),
+            "hidden_dim": _cfg_get(c, "RTDETRTransformerv2.hidden_dim", 256),
+        }
+
+    def init_synthetic(self, seed: int | None = None):
+        from .utils.synth_rtdetr import rtdetr_state_dict
+
+        p = self.params()
+        self.load_state_dict(rtdetr_state_dict(self._seed if seed is None else seed, num_classes=int(p["num_classes"])))
+        return self
+
+    def load_state_dict(self, sd, strict: bool = False):
+        from .utils.synth_rtdetr import generate_anchors, sincos_pos_embed
+
+        sd = OrderedDict(sd.items())
+        size = list(_cfg_get(self.cfg, "RTDETRTransformerv2.eval_spatial_size", [640, 640]))
+        if "decoder.anchors" not in sd:  # registered buffers of the reference (rtdetrv2_decoder.py:565-568)
+            sd["decoder.anchors"], sd["decoder.valid_mask"] = generate_anchors(size)
+        sd["decoder.valid_mask"] = sd["decoder.valid_mask"].to(torch.float32)
+        # AIFI position table: the reference rebuilds it every forward (rtdetr_hybrid_encoder.py:375-378)
+        sd["__aifi_pos_embed"] = sincos_pos_embed(size[1] // 32, size[0] // 32, 256)[0]
+        return super().load_state_dict(sd, strict)
+
+    def __call__(self, x: torch.Tensor, targets=None):
+        _require_cuda(x, "RTDETRv2")
+        if self._h is None:
+            self.to(x.device)
+        x = x.to(torch.float32).contiguous()
+        n, c, h, w = x.shape
+        p = self.params()
+        nq, nc = int(p["num_queries"]), int(p["num_classes"])
+        logits = torch.empty((n, nq, nc), dtype=torch.float32, device=x.device)
+        boxes = torch.empty((n, nq, 4), dtype=torch.float32, device=x.device)
+        lib = _lib.load()
+        with torch.cuda.device(x.device):
+            _lib.check(
+                lib.ymk_rtdetr_forward(self._h, x.data_ptr(), n, h, w, logits.data_ptr(), boxes.data_ptr(),
+                                       _lib.current_stream_ptr()),
+                "ymk_rtdetr_forward",
+            )
+        return {"pred_logits": logits, "pred_boxes": boxes}
+
+
 class DBNet(HipNet):
     """DBNet++ text detector (reference models/dbnet_plus.py:233-246)."""
 
