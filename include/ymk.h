@@ -74,6 +74,14 @@ int ymk_parseq_token_stats(const float* logits_dev, int rows, int num_classes, i
 int ymk_rtdetr_forward(ymk_model* m, const float* x_dev, int b, int h, int w, float* logits_dev, float* boxes_dev,
                        void* stream);
 
+/* ---- DB post-processing on the host (replaces DBnetPostProcessor.boxes_from_bitmap,
+ * postprocessor/dbnet_postporcessor.py:32-82: threshold, border following, min-area rectangles,
+ * polygon-mean score, unclip, scaling to the original page).  prob_host: fp32 [h][w] HOST pointer
+ * (the map after D2H); quads_out: int16 [capacity][4][2]; scores_out: double [capacity]. */
+int ymk_db_postprocess(const float* prob_host, int h, int w, float thresh, float box_thresh, int min_size,
+                       int max_candidates, float unclip_ratio, int dest_w, int dest_h, int16_t* quads_out,
+                       double* scores_out, int capacity, int* count);
+
 /* ---- measurement aid for bench.py (not on the product path): between begin/end every launch of
  * the implicit-GEMM convolution kernel is bracketed by HIP events on its own stream; end returns
  * the summed kernel time, the algorithmic FLOPs (2*M*Cout*KH*KW*Cin, unpadded) and launch count.

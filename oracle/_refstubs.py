@@ -209,6 +209,8 @@ def install_stubs():
         tv = _module("torchvision")
         tv.models = _module("torchvision.models", resnet50=lambda **kw: _ResNet50(**kw))
         tv.models._utils = _module("torchvision.models._utils", IntermediateLayerGetter=_IntermediateLayerGetter)
+    if "cv2" not in sys.modules:  # imported at module level by reading_order.py / utils/misc.py, unused on the paths we call
+        _module("cv2")
     if "timm" not in sys.modules:
         tm = _module("timm")
         tm.models = _module("timm.models")

@@ -127,10 +127,69 @@ def pin_rtdetr():
                             x_seed=seed, logits=ref["pred_logits"].numpy(), boxes=ref["pred_boxes"].numpy())
 
 
+def _random_layout(rng, n, page=(1200, 1600)):
+    """Boxes that look like page elements: columns of stacked blocks plus a few strays/overlaps."""
+    boxes = []
+    ncol = int(rng.integers(1, 4))
+    col_w = page[0] // ncol
+    for c in range(ncol):
+        y = int(rng.integers(20, 120))
+        while y < page[1] - 80 and len(boxes) < n:
+            h = int(rng.integers(20, 260))
+            x1 = c * col_w + int(rng.integers(5, 60))
+            x2 = (c + 1) * col_w - int(rng.integers(5, 60))
+            if rng.random() < 0.25:  # short block
+                x2 = x1 + int(rng.integers(40, max(41, (x2 - x1) // 2)))
+            boxes.append([x1, y, max(x1 + 10, x2), y + h])
+            y += h + int(rng.integers(-10, 60))
+    while len(boxes) < n:
+        x1, y1 = int(rng.integers(0, page[0] - 50)), int(rng.integers(0, page[1] - 50))
+        boxes.append([x1, y1, x1 + int(rng.integers(10, 400)), y1 + int(rng.integers(10, 200))])
+    rng.shuffle(boxes)
+    return [list(map(int, b)) for b in boxes[:n]]
+
+
+def pin_host_logic():
+    """Golden answers of the reference's pure-Python stages (reading order, containment filters,
+    table cell grid) on seeded random layouts -> tests/golden/host_logic.json."""
+    import json
+    from types import SimpleNamespace
+
+    ro = ref_import("yomitoku.reading_order")
+    misc = ref_import("yomitoku.utils.misc")
+
+    class El(SimpleNamespace):
+        def dict(self):
+            return {"box": self.box, "order": self.order}
+
+    rng = np.random.default_rng(2024)
+    cases = []
+    for k in range(240):
+        n = int(rng.integers(2, 40))
+        boxes = _random_layout(rng, n)
+        direction = ["top2bottom", "right2left", "left2right"][k % 3]
+        els = [El(box=b, order=0) for b in boxes]
+        ro.prediction_reading_order(els, direction)
+        cases.append({"direction": direction, "boxes": boxes, "order": [int(e.order) for e in els]})
+    pairs = []
+    for _ in range(300):
+        a = _random_layout(rng, 1)[0]
+        b = [a[0] + int(rng.integers(-30, 30)), a[1] + int(rng.integers(-30, 30)), a[2] + int(rng.integers(-30, 30)),
+             a[3] + int(rng.integers(-30, 30))]
+        if b[2] <= b[0] or b[3] <= b[1]:
+            continue
+        ratio, inter = misc.calc_overlap_ratio(a, b)
+        pairs.append({"a": a, "b": b, "ratio": float(ratio), "inter": inter, "contained": bool(misc.is_contained(a, b)),
+                      "ih": bool(misc.is_intersected_horizontal(a, b)), "iv": bool(misc.is_intersected_vertical(a, b))})
+    with open(os.path.join(GOLDEN, "host_logic.json"), "w") as f:
+        json.dump({"reading_order": cases, "pairs": pairs}, f)
+    print(f"[host] wrote {len(cases)} reading-order cases, {len(pairs)} box pairs")
+
+
 def main(argv):
     what = argv[1] if len(argv) > 1 else "all"
     os.makedirs(GOLDEN, exist_ok=True)
-    todo = {"dbnet": pin_dbnet, "parseq": pin_parseq, "rtdetr": pin_rtdetr}
+    todo = {"dbnet": pin_dbnet, "parseq": pin_parseq, "rtdetr": pin_rtdetr, "host": pin_host_logic}
     for k, fn in todo.items():
         if what in (k, "all"):
             fn()

@@ -30,6 +30,11 @@ SIGNATURES = {
     "ymk_parseq_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, POINTER(c_int), POINTER(c_int), c_void_p]),
     "ymk_parseq_token_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ymk_rtdetr_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ymk_db_postprocess": (
+        c_int,
+        [c_void_p, c_int, c_int, c_float, c_float, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_int,
+         POINTER(c_int)],
+    ),
     "ymk_prof_begin": (c_int, []),
     "ymk_prof_end": (c_int, [POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
     "ymk_op_conv2d": (

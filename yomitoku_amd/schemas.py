@@ -1,0 +1,105 @@
+"""Result types of the path (reference schemas/document_analyzer.py:9-254): same class names, field
+names, types and validation (extra fields forbidden, validate on assignment)."""
+
+from __future__ import annotations
+
+from typing import List, Optional
+
+from pydantic import conlist
+
+from .base import BaseSchema
+
+Box = conlist(int, min_length=4, max_length=4)
+Quad = conlist(conlist(int, min_length=2, max_length=2), min_length=4, max_length=4)
+
+
+class Element(BaseSchema):
+    id: Optional[str]
+    box: Box
+    score: float
+    role: Optional[str]
+    contents: Optional[str]
+
+
+class ParagraphSchema(BaseSchema):
+    box: Box
+    contents: Optional[str]
+    direction: Optional[str]
+    order: Optional[int]
+    role: Optional[str]
+
+
+class TableCellSchema(BaseSchema):
+    col: int
+    row: int
+    col_span: int
+    row_span: int
+    box: Box
+    contents: Optional[str]
+
+
+class TableLineSchema(BaseSchema):
+    box: Box
+    score: float
+
+
+class TableStructureRecognizerSchema(BaseSchema):
+    box: Box
+    n_row: int
+    n_col: int
+    rows: List[TableLineSchema]
+    cols: List[TableLineSchema]
+    spans: List[TableLineSchema]
+    cells: List[TableCellSchema]
+    order: int
+
+
+class LayoutAnalyzerSchema(BaseSchema):
+    paragraphs: List[Element]
+    tables: List[TableStructureRecognizerSchema]
+    figures: List[Element]
+
+
+class WordPrediction(BaseSchema):
+    points: Quad
+    content: str
+    direction: str
+    rec_score: float
+    det_score: float
+
+
+class TextDetectorSchema(BaseSchema):
+    points: List[Quad]
+    scores: List[float]
+
+
+class OCRSchema(BaseSchema):
+    words: List[WordPrediction]
+
+
+class LayoutParserSchema(BaseSchema):
+    paragraphs: List[Element]
+    tables: List[Element]
+    figures: List[Element]
+
+
+class FigureSchema(BaseSchema):
+    box: Box
+    order: Optional[int]
+    paragraphs: List[ParagraphSchema]
+    direction: Optional[str]
+    figure_path: Optional[str] = None
+
+
+class DocumentAnalyzerSchema(BaseSchema):
+    paragraphs: List[ParagraphSchema]
+    tables: List[TableStructureRecognizerSchema]
+    words: List[WordPrediction]
+    figures: List[FigureSchema]
+
+
+class TextRecognizerSchema(BaseSchema):
+    contents: List[str]
+    directions: List[str]
+    scores: List[float]
+    points: List[Quad]
