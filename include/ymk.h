@@ -74,6 +74,26 @@ int ymk_parseq_token_stats(const float* logits_dev, int rows, int num_classes, i
 int ymk_rtdetr_forward(ymk_model* m, const float* x_dev, int b, int h, int w, float* logits_dev, float* boxes_dev,
                        void* stream);
 
+/* ---- fused pre-processing kernels (uint8 BGR page resident in HBM -> network input tensors) ----
+ * ymk_det_preprocess: TextDetector.preprocess (text_detector.py:99-107; resize_shortest_edge's
+ *   cv2.resize(INTER_AREA) + standardization_image, data/functions.py:196-247).  bgr_dev: uint8
+ *   [h][w][3]; x_dev: fp32 [3][oh][ow] (oh, ow from resize_shortest_edge, computed by the caller).
+ * ymk_pil_resize_to_chw: LayoutParser / TableStructureRecognizer.preprocess (layout_parser.py:195-199,
+ *   table_structure_recognizer.py:169-186): BGR->RGB, PIL bilinear antialiased resize of the crop at
+ *   (x0, y0) to oh x ow, ToTensor.  Coefficient tables follow Pillow's precompute_coeffs /
+ *   normalize_coeffs_8bpc (bounds: [o][2] = first tap, count; coefs: [o][ksize] 22-bit ints).
+ * ymk_crop_batch: ParseqDataset crops (data/dataset.py:105-124): perspective warp, optional 90 deg
+ *   rotation, down-scale-only INTER_AREA to the 32 px canvas, ToTensor + Normalize(0.5, 0.5), -1
+ *   padding to batch_w.  descs_dev: array of n records of ymk_crop_desc_size() bytes (layout in
+ *   yomitoku_amd/csrc/ymk_image.hip: CropDesc); out_dev: fp32 [slots][3][out_h][batch_w]. */
+int ymk_det_preprocess(const unsigned char* bgr_dev, int h, int w, int oh, int ow, float* x_dev, void* stream);
+int ymk_pil_resize_to_chw(const unsigned char* page_dev, int page_w, int x0, int y0, const int* xbounds_dev,
+                          const int* xcoef_dev, int ksize_x, const int* ybounds_dev, const int* ycoef_dev, int ksize_y,
+                          int oh, int ow, float* x_dev, void* stream);
+int ymk_crop_batch(const unsigned char* page_dev, int page_h, int page_w, const void* descs_dev, int n, int max_warp_w,
+                   int max_warp_h, unsigned char* scratch_dev, float* out_dev, int batch_w, int out_h, void* stream);
+int ymk_crop_desc_size(void);
+
 /* ---- DB post-processing on the host (replaces DBnetPostProcessor.boxes_from_bitmap,
  * postprocessor/dbnet_postporcessor.py:32-82: threshold, border following, min-area rectangles,
  * polygon-mean score, unclip, scaling to the original page).  prob_host: fp32 [h][w] HOST pointer

@@ -72,10 +72,13 @@ def resize_area(img: np.ndarray, dsize_wh) -> np.ndarray:
     scale_x, scale_y = sw / dw, sh / dh
     if scale_x >= 1 and scale_y >= 1:
         ix, iy = round(scale_x), round(scale_y)
-        if is_u8 and abs(scale_x - ix) < 2.3e-16 and abs(scale_y - iy) < 2.3e-16 and ix == 2 and iy == 2:
-            # ResizeAreaFastVec: 2x2 integer mean with round-half-up
-            s = img.astype(np.int32)
-            out = (s[0:2 * dh:2, 0:2 * dw:2] + s[0:2 * dh:2, 1:2 * dw:2] + s[1:2 * dh:2, 0:2 * dw:2] + s[1:2 * dh:2, 1:2 * dw:2] + 2) >> 2
+        if is_u8 and abs(scale_x - ix) < 2.3e-16 and abs(scale_y - iy) < 2.3e-16 and not (ix == 1 and iy == 1):
+            # ResizeAreaFast: integer block sums; 2x2 rounds half up, other factors rint(sum * (1.f / area))
+            s = img.astype(np.int32).reshape(dh, iy, dw, ix, -1).sum(axis=(1, 3))
+            if ix == 2 and iy == 2:
+                out = (s + 2) >> 2
+            else:
+                out = np.clip(np.rint(s.astype(np.float32) * np.float32(1.0 / (ix * iy))), 0, 255)
             return out.astype(np.uint8).reshape((dh, dw) + img.shape[2:])
         xtab, ytab = _area_tab(sw, dw, scale_x), _area_tab(sh, dh, scale_y)
         # horizontal pass per source row (float32 accumulation in table order)

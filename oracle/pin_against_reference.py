@@ -186,10 +186,132 @@ def pin_host_logic():
     print(f"[host] wrote {len(cases)} reading-order cases, {len(pairs)} box pairs")
 
 
+def _ref_document_analyzer():
+    """Import the reference's document_analyzer.py with its heavy siblings (module classes that pull
+    cv2 / onnx / torchvision) replaced by empty stand-ins: only the pure aggregation code is used."""
+    import sys
+    import types
+
+    from ._refstubs import install_stubs
+
+    install_stubs()
+    for name, attrs in (
+        ("yomitoku.text_detector", {"TextDetector": object}),
+        ("yomitoku.text_recognizer", {"TextRecognizer": object}),
+        ("yomitoku.layout_analyzer", {"LayoutAnalyzer": object}),
+        ("yomitoku.utils.visualizer", {"det_visualizer": None, "reading_order_visualizer": None}),
+        ("yomitoku.export", {"export_csv": None, "export_html": None, "export_markdown": None, "export_json": None}),
+    ):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            for k, v in attrs.items():
+                setattr(m, k, v)
+            sys.modules[name] = m
+    if not hasattr(sys.modules["omegaconf"], "OmegaConf"):
+        sys.modules["omegaconf"].OmegaConf = object
+    for pkg in ("yomitoku.schemas",):
+        if pkg in sys.modules and not hasattr(sys.modules[pkg], "__file__"):
+            del sys.modules[pkg]
+    return ref_import("yomitoku.document_analyzer")
+
+
+def _random_page_results(rng, da, page=(1200, 1600)):
+    """Synthetic OCR + layout results shaped like a real page: text lines inside paragraph / cell /
+    figure boxes plus strays, a ruled table with a span, vertical lines, page header / footer."""
+    import types
+
+    sch = __import__("yomitoku.schemas", fromlist=["x"])
+    words = []
+
+    def add_line(x1, y1, x2, y2, vertical=False):
+        pts = [[x1, y1], [x2, y1], [x2, y2], [x1, y2]]
+        text = "".join(rng.choice(list("あいうカキク漢字abc 12"), size=int(rng.integers(1, 9))))
+        if rng.random() < 0.15:
+            text = "".join(rng.choice(list("ふりがなカタ"), size=int(rng.integers(1, 5))))
+        words.append(sch.WordPrediction(points=pts, content=text, direction="vertical" if vertical else "horizontal",
+                                        rec_score=float(rng.random()), det_score=float(rng.random())))
+
+    paragraphs, figures, tables = [], [], []
+    y = 40
+    for k in range(int(rng.integers(2, 7))):
+        x1 = int(rng.integers(30, 200))
+        x2 = int(rng.integers(600, 1150))
+        nl = int(rng.integers(1, 6))
+        lh = int(rng.integers(14, 40))
+        role = [None, None, "section_headings", "page_header", "page_footer"][int(rng.integers(0, 5))]
+        paragraphs.append(sch.Element(id=None, box=[x1 - 5, y - 4, x2 + 5, y + nl * (lh + 6)], score=0.9, role=role,
+                                      contents=None))
+        for i in range(nl):
+            add_line(x1, y + i * (lh + 6), int(rng.integers(x1 + 60, x2)), y + i * (lh + 6) + lh)
+            if rng.random() < 0.3:  # furigana-sized line above
+                add_line(x1 + 10, y + i * (lh + 6) - 7, x1 + 60, y + i * (lh + 6) - 1)
+        y += nl * (lh + 6) + int(rng.integers(20, 80))
+    if rng.random() < 0.8:  # a table
+        tx, ty = int(rng.integers(40, 200)), y
+        nr, ncol = int(rng.integers(2, 5)), int(rng.integers(2, 5))
+        cw, ch = int(rng.integers(90, 220)), int(rng.integers(36, 70))
+        rows = [sch.TableLineSchema(box=[tx, ty + r * ch, tx + ncol * cw, ty + (r + 1) * ch], score=0.9) for r in range(nr)]
+        cols = [sch.TableLineSchema(box=[tx + c * cw, ty, tx + (c + 1) * cw, ty + nr * ch], score=0.9) for c in range(ncol)]
+        cells = [sch.TableCellSchema(col=c + 1, row=r + 1, col_span=1, row_span=1,
+                                     box=[tx + c * cw, ty + r * ch, tx + (c + 1) * cw, ty + (r + 1) * ch], contents=None)
+                 for r in range(nr) for c in range(ncol)]
+        tables.append(sch.TableStructureRecognizerSchema(box=[tx, ty, tx + ncol * cw, ty + nr * ch], n_row=nr, n_col=ncol,
+                                                         rows=rows, cols=cols, spans=[], cells=cells, order=0))
+        for r in range(nr):
+            for c in range(ncol):
+                if rng.random() < 0.8:
+                    add_line(tx + c * cw + 6, ty + r * ch + 8, tx + (c + 1) * cw - int(rng.integers(6, 40)), ty + r * ch + 30)
+        if rng.random() < 0.5:  # a line spanning two cells
+            add_line(tx + 10, ty + 10, tx + 2 * cw - 10, ty + 32)
+        y += nr * ch + 40
+    if rng.random() < 0.6:  # figure with a caption inside
+        fx, fy = int(rng.integers(50, 500)), y
+        figures.append(sch.Element(id=None, box=[fx, fy, fx + 400, fy + 250], score=0.8, role=None, contents=None))
+        add_line(fx + 20, fy + 200, fx + 300, fy + 225)
+        y += 290
+    for _ in range(int(rng.integers(0, 4))):  # vertical text column + strays
+        vx = int(rng.integers(900, 1150))
+        add_line(vx, 100, vx + 30, int(rng.integers(300, 900)), vertical=True)
+    for _ in range(int(rng.integers(0, 4))):
+        sx, sy = int(rng.integers(0, 1000)), int(rng.integers(0, 1500))
+        add_line(sx, sy, sx + int(rng.integers(20, 180)), sy + int(rng.integers(12, 40)))
+    order = rng.permutation(len(words)).tolist()
+    words = [words[i] for i in order]
+    ocr = sch.OCRSchema(words=words)
+    layout = sch.LayoutAnalyzerSchema(paragraphs=paragraphs, tables=tables, figures=figures)
+    return ocr, layout
+
+
+def pin_aggregate():
+    """Golden answers of the reference's DocumentAnalyzer.aggregate / _split_text_across_cells on seeded
+    synthetic page results -> tests/golden/aggregate.json (inputs and outputs as plain JSON)."""
+    import json
+    from types import SimpleNamespace
+
+    da = _ref_document_analyzer()
+    sch = __import__("yomitoku.schemas", fromlist=["x"])
+    rng = np.random.default_rng(77)
+    cases = []
+    for k in range(60):
+        ocr, layout = _random_page_results(rng, da)
+        opts = dict(ignore_ruby=bool(k % 3 == 0), ruby_threshold=2.0, ignore_meta=bool(k % 4 == 1),
+                    reading_order=["auto", "auto", "left2right", "top2bottom", "right2left"][k % 5])
+        inp = {"ocr": ocr.model_dump(), "layout": layout.model_dump(), "opts": opts}
+        det = sch.TextDetectorSchema(points=[w.points for w in ocr.words], scores=[w.det_score for w in ocr.words])
+        split = da._split_text_across_cells(det.model_copy(deep=True), layout.model_copy(deep=True))
+        self = SimpleNamespace(img=None, **opts)
+        out = da.DocumentAnalyzer.aggregate(self, ocr.model_copy(deep=True), layout.model_copy(deep=True))
+        res = sch.DocumentAnalyzerSchema(**out)
+        cases.append({"input": inp, "output": res.model_dump(), "split": split.model_dump()})
+    with open(os.path.join(GOLDEN, "aggregate.json"), "w") as f:
+        json.dump(cases, f, ensure_ascii=False)
+    print(f"[aggregate] wrote {len(cases)} cases; paragraphs in case 0: {len(cases[0]['output']['paragraphs'])}")
+
+
 def main(argv):
     what = argv[1] if len(argv) > 1 else "all"
     os.makedirs(GOLDEN, exist_ok=True)
-    todo = {"dbnet": pin_dbnet, "parseq": pin_parseq, "rtdetr": pin_rtdetr, "host": pin_host_logic}
+    todo = {"dbnet": pin_dbnet, "parseq": pin_parseq, "rtdetr": pin_rtdetr, "host": pin_host_logic, "aggregate": pin_aggregate}
     for k, fn in todo.items():
         if what in (k, "all"):
             fn()

@@ -1,0 +1,67 @@
+"""CPU parity of the page aggregation (word -> cell / paragraph assignment, furigana filter, figure
+capture, header / footer split, reading order) and of split_text_across_cells against answers
+produced by the REFERENCE's DocumentAnalyzer.aggregate / _split_text_across_cells
+(oracle/pin_against_reference.py aggregate -> tests/golden/aggregate.json).  Everything here is
+integer / string data: equality is exact."""
+import json
+import os
+from types import SimpleNamespace
+
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "aggregate.json")
+
+
+@pytest.fixture(scope="module")
+def cases():
+    with open(GOLD, encoding="utf-8") as f:
+        return json.load(f)
+
+
+def test_aggregate_matches_reference(cases):
+    from yomitoku_amd import document_analyzer as da
+    from yomitoku_amd import schemas as sch
+
+    assert len(cases) >= 50
+    for case in cases:
+        ocr = sch.OCRSchema(**case["input"]["ocr"])
+        layout = sch.LayoutAnalyzerSchema(**case["input"]["layout"])
+        me = SimpleNamespace(img=None, **case["input"]["opts"])
+        out = sch.DocumentAnalyzerSchema(**da.DocumentAnalyzer.aggregate(me, ocr, layout)).model_dump()
+        assert out == case["output"]
+
+
+def test_split_text_across_cells_matches_reference(cases):
+    from yomitoku_amd import document_analyzer as da
+    from yomitoku_amd import schemas as sch
+
+    for case in cases:
+        ocr = case["input"]["ocr"]
+        det = sch.TextDetectorSchema(points=[w["points"] for w in ocr["words"]], scores=[w["det_score"] for w in ocr["words"]])
+        layout = sch.LayoutAnalyzerSchema(**case["input"]["layout"])
+        assert da._split_text_across_cells(det, layout).model_dump() == case["split"]
+
+
+def test_known_answers_from_the_reference_unit_tests():
+    """Spot values the reference's own tests pin (tests/test_document_analyzer.py:116-607)."""
+    from yomitoku_amd import document_analyzer as da
+    from yomitoku_amd import schemas as sch
+
+    assert da.combine_flags([True, False, False], [False, False, True]) == [True, False, True]
+    assert da.is_vertical([[0, 0], [10, 0], [10, 30], [0, 30]]) and not da.is_vertical([[0, 0], [30, 0], [30, 10], [0, 10]])
+    assert da.is_noise([[0, 0], [10, 0], [10, 30], [0, 30]]) and not da.is_noise([[0, 0], [20, 0], [20, 30], [0, 30]])
+    assert da.recursive_update({"a": {"b": 1, "c": 2}, "d": 3}, {"a": {"b": 9}, "e": 4}) == {"a": {"b": 9, "c": 2}, "d": 3, "e": 4}
+    hp = [sch.ParagraphSchema(box=[0, 0, 100, 10], contents="x", direction="horizontal", order=0, role=None)]
+    vp = [sch.ParagraphSchema(box=[0, 0, 10, 200], contents="y", direction="vertical", order=0, role=None)]
+    assert da.judge_page_direction(hp) == "horizontal" and da.judge_page_direction(hp + vp) == "vertical"
+    line = lambda b: SimpleNamespace(box=b)  # noqa: E731
+    words = [{"points": [[0, 0], [10, 0], [10, 10], [0, 10]]}, {"points": [[0, 5], [10, 5], [10, 15], [0, 15]]}]
+    assert da._calc_overlap_words_on_lines([line([0, 0, 10, 10]), line([0, 20, 10, 30])], words) == [[1.0, 0.0], [0.5, 0.0]]
+
+
+def test_configs_must_be_dicts():
+    from yomitoku_amd.document_analyzer import OCR, DocumentAnalyzer, LayoutAnalyzer
+
+    for cls in (OCR, LayoutAnalyzer, DocumentAnalyzer):
+        with pytest.raises(ValueError):
+            cls(configs="not-a-dict")

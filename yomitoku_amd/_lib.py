@@ -30,6 +30,17 @@ SIGNATURES = {
     "ymk_parseq_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, POINTER(c_int), POINTER(c_int), c_void_p]),
     "ymk_parseq_token_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ymk_rtdetr_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ymk_det_preprocess": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ymk_pil_resize_to_chw": (
+        c_int,
+        [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+         c_void_p],
+    ),
+    "ymk_crop_batch": (
+        c_int,
+        [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    ),
+    "ymk_crop_desc_size": (c_int, []),
     "ymk_db_postprocess": (
         c_int,
         [c_void_p, c_int, c_int, c_float, c_float, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_int,

@@ -1,0 +1,252 @@
+"""Host-side geometry for the pre-processing kernels: everything here is integer / small-matrix
+work on the CPU (sizes, coefficient tables, per-quad warp matrices); the pixels never leave HBM.
+
+Mirrors data/functions.py:196-439 and data/dataset.py:105-124 of the reference for the geometry,
+and Pillow's Resample.c for the bilinear coefficient tables.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+# ---------------------------------------------------------------------------------------------
+def resize_shortest_edge_dims(h: int, w: int, shortest_edge_length: int, max_length: int):
+    """Output (height, width) of resize_shortest_edge (data/functions.py:196-227)."""
+    scale = shortest_edge_length / min(h, w)
+    if h < w:
+        new_h, new_w = shortest_edge_length, int(w * scale)
+    else:
+        new_h, new_w = int(h * scale), shortest_edge_length
+    if max(new_h, new_w) > max_length:
+        scale = float(max_length) / max(new_h, new_w)
+        new_h, new_w = int(new_h * scale), int(new_w * scale)
+    return max(int(new_h / 32) * 32, 32), max(int(new_w / 32) * 32, 32)
+
+
+def page_to_device(img: np.ndarray, device) -> torch.Tensor:
+    """uint8 H x W x 3 BGR page -> contiguous device tensor (one H2D copy per page)."""
+    if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
+        raise ValueError("page must be a uint8 H x W x 3 BGR array")
+    return torch.from_numpy(np.ascontiguousarray(img)).to(device, non_blocking=True)
+
+
+def detector_tensor(page_dev: torch.Tensor, shortest: int, limit: int) -> torch.Tensor:
+    """TextDetector.preprocess on the device: fp32 1 x 3 x H' x W'."""
+    h, w = page_dev.shape[:2]
+    oh, ow = resize_shortest_edge_dims(h, w, shortest, limit)
+    out = torch.empty((1, 3, oh, ow), dtype=torch.float32, device=page_dev.device)
+    lib = _lib.load()
+    with torch.cuda.device(page_dev.device):
+        _lib.check(
+            lib.ymk_det_preprocess(page_dev.data_ptr(), h, w, oh, ow, out.data_ptr(), _lib.current_stream_ptr()),
+            "ymk_det_preprocess",
+        )
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Pillow bilinear resample coefficients (Resample.c: precompute_coeffs + normalize_coeffs_8bpc)
+def pil_bilinear_coeffs(in_size: int, out_size: int):
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    coefs = np.zeros((out_size, ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        k = []
+        ww = 0.0
+        for x in range(xmax):
+            a = abs((x + xmin - center + 0.5) * ss)
+            w = 1.0 - a if a < 1.0 else 0.0
+            k.append(w)
+            ww += w
+        if ww != 0.0:
+            k = [v / ww for v in k]
+        for x, v in enumerate(k):
+            coefs[xx, x] = int(-0.5 + v * (1 << 22)) if v < 0 else int(0.5 + v * (1 << 22))
+        bounds[xx] = (xmin, xmax)
+    return bounds, coefs, ksize
+
+
+_COEF_CACHE = {}
+
+
+def _coeffs_on_device(in_size, out_size, device):
+    key = (in_size, out_size, str(device))
+    hit = _COEF_CACHE.get(key)
+    if hit is None:
+        b, c, k = pil_bilinear_coeffs(in_size, out_size)
+        hit = (torch.from_numpy(b).to(device), torch.from_numpy(c).to(device), k)
+        if len(_COEF_CACHE) > 256:
+            _COEF_CACHE.clear()
+        _COEF_CACHE[key] = hit
+    return hit
+
+
+def rtdetr_tensor(page_dev: torch.Tensor, box: Optional[Sequence[int]], out_hw=(640, 640), out: torch.Tensor = None):
+    """LayoutParser / TableStructureRecognizer preprocess on the device: crop `box` (x1, y1, x2, y2) or
+    the whole page, BGR->RGB, PIL-style antialiased bilinear resize, /255 -> fp32 3 x H x W."""
+    H, W = page_dev.shape[:2]
+    if box is None:
+        x1, y1, x2, y2 = 0, 0, W, H
+    else:
+        x1, y1, x2, y2 = (int(v) for v in box)
+        # numpy slicing semantics of img[y1:y2, x1:x2] for in-range non-negative indices
+        x1, y1, x2, y2 = max(x1, 0), max(y1, 0), min(x2, W), min(y2, H)
+    cw, ch = x2 - x1, y2 - y1
+    if cw <= 0 or ch <= 0:
+        raise ValueError(f"empty crop {box}")
+    oh, ow = out_hw
+    xb, xk, ksx = _coeffs_on_device(cw, ow, page_dev.device)
+    yb, yk, ksy = _coeffs_on_device(ch, oh, page_dev.device)
+    if out is None:
+        out = torch.empty((3, oh, ow), dtype=torch.float32, device=page_dev.device)
+    lib = _lib.load()
+    with torch.cuda.device(page_dev.device):
+        _lib.check(
+            lib.ymk_pil_resize_to_chw(page_dev.data_ptr(), W, x1, y1, xb.data_ptr(), xk.data_ptr(), ksx, yb.data_ptr(),
+                                      yk.data_ptr(), ksy, oh, ow, out.data_ptr(), _lib.current_stream_ptr()),
+            "ymk_pil_resize_to_chw",
+        )
+    return out, (ch, cw), (x1, y1)
+
+
+# ---------------------------------------------------------------------------------------------
+# recogniser crops
+class CropDesc(ctypes.Structure):
+    _fields_ = [
+        ("minv", ctypes.c_double * 9),
+        ("bx", ctypes.c_int), ("by", ctypes.c_int), ("bw", ctypes.c_int), ("bh", ctypes.c_int),
+        ("ww", ctypes.c_int), ("wh", ctypes.c_int), ("rot", ctypes.c_int),
+        ("rw", ctypes.c_int), ("rh", ctypes.c_int), ("nw", ctypes.c_int), ("nh", ctypes.c_int),
+        ("fast_x", ctypes.c_int), ("fast_y", ctypes.c_int),
+        ("warp_off", ctypes.c_longlong),
+        ("slot", ctypes.c_int),
+    ]
+
+
+@dataclass
+class CropPlan:
+    index: int              # position in the caller's quad list
+    desc: CropDesc
+    content_width: int      # calc_resize_without_padding width (batch bucketing key)
+    canvas_width: int       # width of this crop's own tensor (800, or the dynamic canvas)
+
+
+def validate_quad(shape_hw, quad) -> bool:
+    """validate_quads (data/functions.py:267-298): 4 points of 2, bbox inside the image."""
+    if len(quad) != 4 or any(len(p) != 2 for p in quad):
+        return False
+    q = np.array(quad, dtype=int)
+    h, w = shape_hw
+    return not (q[:, 0].min() < 0 or q[:, 0].max() > w or q[:, 1].min() < 0 or q[:, 1].max() > h)
+
+
+def perspective_matrix(src4: np.ndarray, dst4: np.ndarray) -> np.ndarray:
+    """cv2.getPerspectiveTransform: 8 x 8 linear solve in double."""
+    a = np.zeros((8, 8), dtype=np.float64)
+    b = np.zeros(8, dtype=np.float64)
+    for i in range(4):
+        x, y = float(src4[i][0]), float(src4[i][1])
+        u, v = float(dst4[i][0]), float(dst4[i][1])
+        a[i, 0], a[i, 1], a[i, 2] = x, y, 1.0
+        a[i + 4, 3], a[i + 4, 4], a[i + 4, 5] = x, y, 1.0
+        a[i, 6], a[i, 7] = -x * u, -y * u
+        a[i + 4, 6], a[i + 4, 7] = -x * v, -y * v
+        b[i], b[i + 4] = u, v
+    return np.append(np.linalg.solve(a, b), 1.0).reshape(3, 3)
+
+
+def _int_scale(src: int, dst: int) -> int:
+    s = src / dst
+    i = round(s)
+    return i if abs(s - i) < 2.220446049250313e-16 else 0
+
+
+def plan_crops(shape_hw, quads, img_size=(32, 800), dynamic_width=False, align=8, margin=64) -> List[Optional[CropPlan]]:
+    """Integer geometry of every text-line crop (extract_roi_with_perspective, rotate_text_image,
+    calc_resize_without_padding, resize_with[_dynamic]_padding).  None for quads that fail validation."""
+    plans: List[Optional[CropPlan]] = []
+    th, tw = int(img_size[0]), int(img_size[1])
+    for i, quad in enumerate(quads):
+        if not validate_quad(shape_hw, quad):
+            plans.append(None)
+            continue
+        q = np.array(quad, dtype=np.int64)
+        bx, by = int(q[:, 0].min()), int(q[:, 1].min())
+        bx2, by2 = int(q[:, 0].max()), int(q[:, 1].max())
+        rel = q.copy()
+        rel[:, 0] -= bx
+        rel[:, 1] -= by
+        width = int(np.linalg.norm(rel[0] - rel[1]))
+        height = int(np.linalg.norm(rel[1] - rel[2]))
+        if width <= 0 or height <= 0:
+            raise ValueError(f"degenerate text quad {quad}")
+        M = perspective_matrix(np.float32(rel), np.float32([[0, 0], [width, 0], [width, height], [0, height]]))
+        minv = np.linalg.inv(M)
+        rot = 1 if height > 2 * width else 0
+        rw, rh = (height, width) if rot else (width, height)
+        scale_w = tw / rw if rw > tw else 1.0
+        scale_h = th / rh if rh > th else 1.0
+        s = min(scale_w, scale_h)
+        nw, nh = max(1, int(rw * s)), max(1, int(rh * s))
+        canvas = min(tw, ((nw + margin + align - 1) // align) * align) if dynamic_width else tw
+        d = CropDesc()
+        for k in range(9):
+            d.minv[k] = float(minv.flat[k])
+        d.bx, d.by, d.bw, d.bh = bx, by, bx2 - bx, by2 - by
+        d.ww, d.wh, d.rot, d.rw, d.rh, d.nw, d.nh = width, height, rot, rw, rh, nw, nh
+        fx, fy = _int_scale(rw, nw), _int_scale(rh, nh)
+        d.fast_x, d.fast_y = (fx, fy) if fx and fy else (0, 0)
+        plans.append(CropPlan(index=i, desc=d, content_width=nw, canvas_width=canvas))
+    return plans
+
+
+def build_crop_batch(page_dev: torch.Tensor, plans: Sequence[CropPlan], out_h: int = 32, batch_w: Optional[int] = None):
+    """Run the warp + resize kernels for one mini-batch: fp32 B x 3 x out_h x batch_w on the device."""
+    lib = _lib.load()
+    assert ctypes.sizeof(CropDesc) == lib.ymk_crop_desc_size(), "CropDesc layout mismatch"
+    n = len(plans)
+    if batch_w is None:
+        batch_w = max(p.canvas_width for p in plans)
+    arr = (CropDesc * n)()
+    off = 0
+    max_w = max_h = 1
+    for slot, p in enumerate(plans):
+        ctypes.memmove(ctypes.byref(arr[slot]), ctypes.byref(p.desc), ctypes.sizeof(CropDesc))
+        arr[slot].slot = slot
+        arr[slot].warp_off = off
+        off += p.desc.ww * p.desc.wh * 3
+        off = (off + 15) & ~15
+        max_w, max_h = max(max_w, p.desc.ww), max(max_h, p.desc.wh)
+    dev = page_dev.device
+    descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    scratch = torch.empty(max(off, 16), dtype=torch.uint8, device=dev)
+    out = torch.empty((n, 3, out_h, batch_w), dtype=torch.float32, device=dev)
+    H, W = page_dev.shape[:2]
+    with torch.cuda.device(dev):
+        _lib.check(
+            lib.ymk_crop_batch(page_dev.data_ptr(), H, W, descs.data_ptr(), n, max_w, max_h, scratch.data_ptr(),
+                               out.data_ptr(), batch_w, out_h, _lib.current_stream_ptr()),
+            "ymk_crop_batch",
+        )
+    return out

@@ -1,0 +1,172 @@
+"""LayoutParser module (reference layout_parser.py:24-274) and the RT-DETR output post-processor
+(postprocessor/rtdetr_postprocessor.py:60-123).  Resize + ToTensor and the RT-DETRv2 forward run on
+the MI355X; the 300-query post-processing is integer/box logic on the host."""
+
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from . import imaging
+from .base import BaseModelCatalog, BaseModule, load_config, logger
+from .configs import LayoutParserRTDETRv2Config, LayoutParserRTDETRv2V2Config
+from .geometry import filter_by_flag, is_contained
+from .nets import RTDETRv2
+from .schemas import LayoutParserSchema
+
+
+class RTDETRPostProcessor:
+    """Focal-loss branch of rtdetr_postprocessor.py:60-123 for one image at a time: sigmoid scores,
+    top-`num_top_queries` over the flattened (query, class) grid, label = idx % nc, query = idx // nc,
+    boxes cxcywh -> xyxy scaled to the original size, score threshold, clamp to the image."""
+
+    def __init__(self, num_classes=80, num_top_queries=300):
+        self.num_classes = int(num_classes)
+        self.num_top_queries = int(num_top_queries)
+
+    def __call__(self, outputs, orig_size_wh, threshold):
+        logits = outputs["pred_logits"]
+        boxes = outputs["pred_boxes"]
+        if isinstance(logits, torch.Tensor):
+            logits = logits.detach().to("cpu", torch.float32).numpy()
+            boxes = boxes.detach().to("cpu", torch.float32).numpy()
+        w, h = int(orig_size_wh[0]), int(orig_size_wh[1])
+        results = []
+        for lg, bx in zip(logits, boxes):
+            half = np.float32(0.5)
+            xyxy = np.stack([bx[:, 0] - half * bx[:, 2], bx[:, 1] - half * bx[:, 3], bx[:, 0] + half * bx[:, 2],
+                             bx[:, 1] + half * bx[:, 3]], axis=-1).astype(np.float32)
+            xyxy = xyxy * np.array([w, h, w, h], dtype=np.float32)
+            scores = (np.float32(1.0) / (np.float32(1.0) + np.exp(-lg.astype(np.float32)))).reshape(-1)
+            k = min(self.num_top_queries, scores.shape[0])
+            index = np.argsort(-scores, kind="stable")[:k]
+            sc = scores[index]
+            labels = index - index // self.num_classes * self.num_classes
+            bsel = xyxy[index // self.num_classes]
+            keep = sc > threshold
+            lab, sco, box = labels[keep], sc[keep], bsel[keep].copy()
+            box[:, 0] = np.maximum(box[:, 0], 0)
+            box[:, 1] = np.maximum(box[:, 1], 0)
+            box[:, 2] = np.clip(box[:, 2], 0, w)
+            box[:, 3] = np.clip(box[:, 3], 0, h)
+            results.append(dict(labels=lab, boxes=box, scores=sco))
+        return results
+
+
+def filter_contained_rectangles_within_category(category_elements):
+    """Per category, drop every box more than 80 % inside another one (mutual containment keeps the
+    larger) - layout_parser.py:31-61."""
+    for category, elements in category_elements.items():
+        boxes = [e["box"] for e in elements]
+        keep = [True] * len(boxes)
+        for i in range(len(boxes)):
+            for j in range(i + 1, len(boxes)):
+                bi, bj = boxes[i], boxes[j]
+                j_in_i, i_in_j = is_contained(bi, bj), is_contained(bj, bi)
+                if j_in_i and i_in_j:
+                    area_i = (bi[2] - bi[0]) * (bi[3] - bi[1])
+                    area_j = (bj[2] - bj[0]) * (bj[3] - bj[1])
+                    if area_i > area_j:
+                        keep[j] = False
+                    else:
+                        keep[i] = False
+                elif j_in_i:
+                    keep[j] = False
+                elif i_in_j:
+                    keep[i] = False
+        category_elements[category] = filter_by_flag(elements, keep)
+    return category_elements
+
+
+def filter_contained_rectangles_across_categories(category_elements, source, target):
+    """Drop `target` boxes that lie inside a `source` box - layout_parser.py:64-77."""
+    src = [e["box"] for e in category_elements[source]]
+    tgt = [e["box"] for e in category_elements[target]]
+    keep = [not any(is_contained(s, t) for s in src) for t in tgt]
+    category_elements[target] = filter_by_flag(category_elements[target], keep)
+    return category_elements
+
+
+class LayoutParserModelCatalog(BaseModelCatalog):
+    def __init__(self):
+        super().__init__()
+        self.register("rtdetrv2", LayoutParserRTDETRv2Config, RTDETRv2)
+        self.register("rtdetrv2v2", LayoutParserRTDETRv2V2Config, RTDETRv2)
+
+
+def load_local_checkpoint(model, weights_path, weights_key="ema"):
+    """layout_parser.py:177-193: rtdetrv2_pytorch training checkpoint (.pth) -> the net."""
+    ckpt = torch.load(weights_path, map_location="cpu")
+    if weights_key == "ema" and "ema" in ckpt:
+        state = ckpt["ema"]["module"]
+    elif "model" in ckpt:
+        state = ckpt["model"]
+    else:
+        state = ckpt
+    model.load_state_dict(state, strict=False)
+    logger.info(f"Loaded local layout-parser weights from {weights_path}")
+
+
+class LayoutParser(BaseModule):
+    model_catalog = LayoutParserModelCatalog()
+
+    def __init__(self, model_name="rtdetrv2v2", path_cfg=None, device="cuda", visualize=False, from_pretrained=True,
+                 infer_onnx=False):
+        super().__init__()
+        if infer_onnx:
+            raise NotImplementedError("the ONNX backend is out of scope of the MI355X path (infer_onnx=False only)")
+        # layout_parser.py:97-112 peeks `weights_path` / `weights_key` in the merged config; neither key is
+        # declared by the structured defaults, so that branch is only reachable through
+        # load_local_checkpoint() called by the user after construction.
+        default_cfg, _ = self.model_catalog.get(model_name)
+        peek = load_config(default_cfg, path_cfg)
+        weights_path = getattr(peek, "weights_path", None)
+        use_local = bool(weights_path) and os.path.exists(weights_path)
+        self.load_model(model_name, path_cfg, from_pretrained=(from_pretrained and not use_local))
+        if use_local:
+            load_local_checkpoint(self.model, weights_path, getattr(self._cfg, "weights_key", "ema"))
+        self.device = device
+        self.visualize = visualize
+        self.model.eval()
+        self.postprocessor = RTDETRPostProcessor(
+            num_classes=self._cfg.RTDETRTransformerv2.num_classes,
+            num_top_queries=self._cfg.RTDETRTransformerv2.num_queries,
+        )
+        self.thresh_score = self._cfg.thresh_score
+        self.label_mapper = {i: c for i, c in enumerate(self._cfg.category)}
+        self.role = self._cfg.role
+        self.infer_onnx = False
+        self.model.to(self.device)
+
+    def preprocess(self, img):
+        page = img if isinstance(img, torch.Tensor) else imaging.page_to_device(img, self.device)
+        t, _, _ = imaging.rtdetr_tensor(page, None, tuple(self._cfg.data.img_size))
+        return t[None]
+
+    def postprocess(self, preds, image_size):
+        h, w = image_size
+        outputs = self.postprocessor(preds, (w, h), self.thresh_score)
+        return LayoutParserSchema(**self.filtering_elements(outputs[0]))
+
+    def filtering_elements(self, preds):
+        category_elements = {c: [] for c in self.label_mapper.values() if c not in self.role}
+        for box, score, label in zip(preds["boxes"], preds["scores"], preds["labels"]):
+            category = self.label_mapper[int(label)]
+            role = None
+            if category in self.role:
+                role, category = category, "paragraphs"
+            category_elements[category].append(
+                {"id": None, "box": box.astype(int).tolist(), "score": float(score), "role": role, "contents": None}
+            )
+        category_elements = filter_contained_rectangles_within_category(category_elements)
+        return filter_contained_rectangles_across_categories(category_elements, "tables", "paragraphs")
+
+    def __call__(self, img):
+        ori_h, ori_w = img.shape[:2]
+        preds = self.model(self.preprocess(img))
+        results = self.postprocess(preds, (ori_h, ori_w))
+        if self.visualize:
+            raise NotImplementedError("visualisation is out of scope of the MI355X path (visualize=False only)")
+        return results, None

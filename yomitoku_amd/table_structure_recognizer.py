@@ -1,0 +1,127 @@
+"""TableStructureRecognizer module (reference table_structure_recognizer.py:21-290).
+
+One difference in *how*: the reference runs the RT-DETRv2 once per table, serially, batch 1
+(:261-278); here every table crop of the page goes through ONE batched forward (results are
+per-image independent, tests/test_rtdetr_gpu.py::test_batch_of_pages_matches_oracle)."""
+
+from __future__ import annotations
+
+import torch
+
+from . import imaging
+from .base import BaseModelCatalog, BaseModule
+from .configs import TableStructureRecognizerRTDETRv2Config
+from .geometry import calc_intersection, filter_by_flag, is_contained
+from .layout_parser import RTDETRPostProcessor, filter_contained_rectangles_within_category
+from .nets import RTDETRv2
+from .schemas import TableStructureRecognizerSchema
+
+
+class TableStructureRecognizerModelCatalog(BaseModelCatalog):
+    def __init__(self):
+        super().__init__()
+        self.register("rtdetrv2", TableStructureRecognizerRTDETRv2Config, RTDETRv2)
+
+
+def extract_cells(row_boxes, col_boxes):
+    """Cell grid = every non-empty row x column intersection, 1-based (row, col) - :27-46."""
+    cells = []
+    for i, row_box in enumerate(row_boxes):
+        for j, col_box in enumerate(col_boxes):
+            inter = calc_intersection(row_box, col_box)
+            if inter is not None:
+                cells.append({"col": j + 1, "row": i + 1, "col_span": 1, "row_span": 1, "box": inter, "contents": None})
+    return cells
+
+
+def filter_contained_cells_within_spancell(cells, span_boxes):
+    """Merge the grid cells inside each detected span into one spanning cell - :49-85."""
+    keep = [True] * len(cells)
+    members = [[] for _ in span_boxes]
+    for i, span_box in enumerate(span_boxes):
+        for j, cell in enumerate(cells):
+            if is_contained(span_box, cell["box"]):
+                keep[j] = False
+                members[i].append(cell)
+    cells = filter_by_flag(cells, keep)
+    for span_box, group in zip(span_boxes, members):
+        if not group:
+            continue
+        rows = [c["row"] for c in group]
+        cols = [c["col"] for c in group]
+        cells.append({"col": min(cols), "row": min(rows), "col_span": max(cols) - min(cols) + 1,
+                      "row_span": max(rows) - min(rows) + 1, "box": [int(v) for v in span_box], "contents": None})
+    return sorted(cells, key=lambda c: (c["row"], c["col"]))
+
+
+class TableStructureRecognizer(BaseModule):
+    model_catalog = TableStructureRecognizerModelCatalog()
+
+    def __init__(self, model_name="rtdetrv2", path_cfg=None, device="cuda", visualize=False, from_pretrained=True,
+                 infer_onnx=False):
+        super().__init__()
+        if infer_onnx:
+            raise NotImplementedError("the ONNX backend is out of scope of the MI355X path (infer_onnx=False only)")
+        self.load_model(model_name, path_cfg, from_pretrained=from_pretrained)
+        self.device = device
+        self.visualize = visualize
+        self.model.eval()
+        self.postprocessor = RTDETRPostProcessor(
+            num_classes=self._cfg.RTDETRTransformerv2.num_classes,
+            num_top_queries=self._cfg.RTDETRTransformerv2.num_queries,
+        )
+        self.thresh_score = self._cfg.thresh_score
+        self.label_mapper = {i: c for i, c in enumerate(self._cfg.category)}
+        self.infer_onnx = False
+        self.model.to(self.device)
+
+    def preprocess(self, img, boxes):
+        """All table crops of the page as one N x 3 x 640 x 640 device tensor + per-crop metadata."""
+        page = img if isinstance(img, torch.Tensor) else imaging.page_to_device(img, self.device)
+        oh, ow = self._cfg.data.img_size
+        batch = torch.empty((len(boxes), 3, oh, ow), dtype=torch.float32, device=page.device)
+        metas = []
+        for i, box in enumerate(boxes):
+            _, size, offset = imaging.rtdetr_tensor(page, box, (oh, ow), out=batch[i])
+            metas.append({"size": size, "offset": offset})
+        return batch, metas
+
+    def postprocess(self, preds, data):
+        h, w = data["size"]
+        outputs = self.postprocessor(preds, (w, h), self.thresh_score)[0]
+        ox, oy = data["offset"]
+        category_elements = {c: [] for c in self.label_mapper.values()}
+        for box, score, label in zip(outputs["boxes"], outputs["scores"], outputs["labels"]):
+            b = box.astype(int).tolist()
+            category_elements[self.label_mapper[int(label)]].append(
+                {"box": [b[0] + ox, b[1] + oy, b[2] + ox, b[3] + oy], "score": float(score)}
+            )
+        category_elements = filter_contained_rectangles_within_category(category_elements)
+        cells, rows, cols, spans = self.extract_cell_elements(category_elements)
+        table = {"box": [ox, oy, ox + w, oy + h], "n_row": len(rows), "n_col": len(cols), "rows": rows, "cols": cols,
+                 "spans": spans, "cells": cells, "order": 0}
+        return TableStructureRecognizerSchema(**table)
+
+    def extract_cell_elements(self, elements):
+        row_boxes = sorted((e["box"] for e in elements["row"]), key=lambda b: b[1])
+        col_boxes = sorted((e["box"] for e in elements["col"]), key=lambda b: b[0])
+        span_boxes = [e["box"] for e in elements["span"]]
+        cells = filter_contained_cells_within_spancell(extract_cells(row_boxes, col_boxes), span_boxes)
+        rows = sorted(elements["row"], key=lambda e: e["box"][1])
+        cols = sorted(elements["col"], key=lambda e: e["box"][0])
+        spans = sorted(elements["span"], key=lambda e: e["box"][1])
+        return cells, rows, cols, spans
+
+    def __call__(self, img, table_boxes, vis=None):
+        outputs = []
+        if len(table_boxes) > 0:
+            batch, metas = self.preprocess(img, table_boxes)
+            preds = self.model(batch)
+            for i, data in enumerate(metas):
+                one = {"pred_logits": preds["pred_logits"][i : i + 1], "pred_boxes": preds["pred_boxes"][i : i + 1]}
+                table = self.postprocess(one, data)
+                if table.n_row > 0 and table.n_col > 0:
+                    outputs.append(table)
+        if self.visualize:
+            raise NotImplementedError("visualisation is out of scope of the MI355X path (visualize=False only)")
+        return outputs, vis

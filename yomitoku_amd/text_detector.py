@@ -1,0 +1,89 @@
+"""TextDetector module (reference text_detector.py:26-146): same constructor, catalog names,
+config keys and `__call__(img) -> (TextDetectorSchema, vis)` contract.  Pre-processing and the
+DBNet forward run on the MI355X; the DB box extraction runs in the C++ host code of libymk_hip.so."""
+
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, imaging
+from .base import BaseModelCatalog, BaseModule
+from .configs import TextDetectorDBNetConfig, TextDetectorDBNetV2_1Config, TextDetectorDBNetV2Config
+from .nets import DBNet
+from .schemas import TextDetectorSchema
+
+
+class TextDetectorModelCatalog(BaseModelCatalog):
+    def __init__(self):
+        super().__init__()
+        self.register("dbnet", TextDetectorDBNetConfig, DBNet)
+        self.register("dbnetv2", TextDetectorDBNetV2Config, DBNet)
+        self.register("dbnetv2_1", TextDetectorDBNetV2_1Config, DBNet)
+
+
+class DBnetPostProcessor:
+    """postprocessor/dbnet_postporcessor.py:8-27 with the box extraction delegated to ymk_db_postprocess."""
+
+    def __init__(self, min_size, thresh, box_thresh, max_candidates, unclip_ratio):
+        self.min_size = min_size
+        self.thresh = thresh
+        self.box_thresh = box_thresh
+        self.max_candidates = max_candidates
+        self.unclip_ratio = unclip_ratio
+
+    def __call__(self, preds, image_size):
+        pred = preds["binary"][0, 0]
+        if isinstance(pred, torch.Tensor):
+            pred = pred.detach().to("cpu", torch.float32).contiguous().numpy()
+        pred = np.ascontiguousarray(pred, dtype=np.float32)
+        h, w = pred.shape
+        height, width = image_size
+        cap = int(self.max_candidates)
+        quads = np.empty((cap, 4, 2), dtype=np.int16)
+        scores = np.empty(cap, dtype=np.float64)
+        n = ctypes.c_int()
+        _lib.check(
+            _lib.load().ymk_db_postprocess(pred.ctypes.data, h, w, float(self.thresh), float(self.box_thresh),
+                                           int(self.min_size), cap, float(self.unclip_ratio), int(width), int(height),
+                                           quads.ctypes.data, scores.ctypes.data, cap, ctypes.byref(n)),
+            "ymk_db_postprocess",
+        )
+        return quads[: n.value].tolist(), scores[: n.value].tolist()
+
+
+class TextDetector(BaseModule):
+    model_catalog = TextDetectorModelCatalog()
+
+    def __init__(self, model_name="dbnetv2_1", path_cfg=None, device="cuda", visualize=False, from_pretrained=True,
+                 infer_onnx=False):
+        super().__init__()
+        if infer_onnx:
+            raise NotImplementedError("the ONNX backend is out of scope of the MI355X path (infer_onnx=False only)")
+        self.load_model(model_name, path_cfg, from_pretrained=from_pretrained)
+        self.device = device
+        self.visualize = visualize
+        self.model.eval()
+        self.post_processor = DBnetPostProcessor(**self._cfg.post_process)
+        self.infer_onnx = False
+        self.model.to(self.device)
+
+    def preprocess(self, img):
+        """BGR uint8 page -> fp32 1 x 3 x H' x W' on the device (one H2D copy of the uint8 page)."""
+        page = img if isinstance(img, torch.Tensor) else imaging.page_to_device(img, self.device)
+        return imaging.detector_tensor(page, self._cfg.data.shortest_size, self._cfg.data.limit_size)
+
+    def postprocess(self, preds, image_size):
+        return self.post_processor(preds, image_size)
+
+    def __call__(self, img):
+        ori_h, ori_w = img.shape[:2]
+        tensor = self.preprocess(img)
+        preds = self.model(tensor)
+        quads, scores = self.postprocess(preds, (ori_h, ori_w))
+        results = TextDetectorSchema(points=quads, scores=scores)
+        if self.visualize:
+            raise NotImplementedError("visualisation is out of scope of the MI355X path (visualize=False only)")
+        return results, None
