@@ -20,7 +20,7 @@ def test_detector_preprocess(dev, h, w):
     from oracle.preprocess import detector_preprocess
     from yomitoku_amd import imaging
 
-    img = _page(h + w, max(h, 200), max(w, 200))[:h, :w]
+    img = np.ascontiguousarray(_page(h + w, max(h, 600), max(w, 600))[:h, :w])
     ref = detector_preprocess(img)
     out = imaging.detector_tensor(imaging.page_to_device(img, dev), 1280, 1600).cpu()
     assert out.shape == ref.shape

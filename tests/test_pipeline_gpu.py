@@ -1,0 +1,146 @@
+"""Module-level parity on a synthetic page, stage by stage, through the product classes.
+
+Tolerance policy (SURVEY §7 "bit-exact indices vs 1e-3 maps"): a continuous stage is compared with
+the oracle within its tolerance; a discrete stage (thresholds, contours, top-k, arg-max, integer
+boxes) is compared bit-exactly with the oracle applied to THE SAME upstream tensor the product
+produced, so that a 1e-6 wobble of a probability sitting on a threshold cannot masquerade as a
+post-processing bug (or hide one)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def page():
+    from yomitoku_amd.utils.synth import synthetic_page_with_truth
+
+    return synthetic_page_with_truth(3, 1000, 1400)
+
+
+def test_text_detector_stages(dev, page):
+    from oracle import pipeline as op
+    from oracle.dbnet import dbnet_forward
+    from oracle.preprocess import detector_preprocess
+    from yomitoku_amd.text_detector import TextDetector
+    from yomitoku_amd.utils.synth import dbnet_state_dict
+
+    img = page[0]
+    det = TextDetector(from_pretrained=False, device="cuda:0")
+    sd = dbnet_state_dict(1234, out_bias=-2.0)
+    det.model.load_state_dict(sd)
+    t = det.preprocess(img)
+    ref_t = detector_preprocess(img)
+    assert (t.cpu() - ref_t).abs().max().item() < 2e-5
+    prob = det.model(t)["binary"]
+    assert (prob.cpu() - dbnet_forward(sd, ref_t)["binary"]).abs().max().item() < 1e-3
+    res, _ = det(img)
+    _, quads, scores = op.detect(sd, img, prob=prob.cpu())
+    assert len(quads) >= 5
+    assert res.points == quads
+    assert np.allclose(res.scores, scores, atol=1e-9)
+
+
+def test_text_recognizer_lite_config(dev, page):
+    """--lite recogniser (parseq-tiny-dynw-v4, dynamic_width + batch_bucketing): crops, batching,
+    forward, decode, un-permutation."""
+    from oracle import pipeline as op
+    from oracle.parseq import PRESETS, make_cfg
+    from yomitoku_amd.text_recognizer import TextRecognizer
+    from yomitoku_amd.utils.synth import parseq_state_dict
+
+    img, quads, _ = page
+    quads = quads[:26]
+    rec = TextRecognizer(model_name="parseq-tiny-dynw-v4", from_pretrained=False, device="cuda:0", dynamic_width=True,
+                         batch_bucketing=True)
+    sd = parseq_state_dict(1235, eos_bias=6.0)
+    rec.model.load_state_dict(sd)
+    res, _ = rec(img, quads)
+    ocfg = make_cfg(**PRESETS["parseq-tiny-dynw-v4"])
+    contents, scores, directions = op.recognize(sd, ocfg, img, quads, rec.charset, dynamic_width=True,
+                                                batch_bucketing=True, width_budget=8000, max_batch_size=64, batch_size=10)
+    assert res.contents == contents
+    assert res.directions == directions
+    assert np.allclose(res.scores, scores, rtol=1e-3, atol=1e-6)
+    assert res.points == quads
+
+
+def test_layout_and_table_stages(dev, page):
+    from oracle import pipeline as op
+    from oracle.rtdetr import rtdetr_forward
+    from tests.test_rtdetr_gpu import assert_same_detections
+    from yomitoku_amd.layout_parser import LayoutParser
+    from yomitoku_amd.table_structure_recognizer import TableStructureRecognizer
+    from yomitoku_amd.utils.synth_rtdetr import rtdetr_state_dict
+
+    img, _, tables = page
+    lp = LayoutParser(from_pretrained=False, device="cuda:0")
+    sd = rtdetr_state_dict(1240, num_classes=6, score_bias=-1.5)
+    lp.model.load_state_dict(sd)
+    x = lp.preprocess(img)
+    preds = lp.model(x)
+    ref_preds, _ = op.layout(sd, img)
+    assert_same_detections(preds["pred_logits"].cpu().numpy(), preds["pred_boxes"].cpu().numpy(),
+                           ref_preds["pred_logits"].numpy(), ref_preds["pred_boxes"].numpy())
+    h, w = img.shape[:2]
+    mine = lp.postprocessor(preds, (w, h), lp.thresh_score)[0]
+    ref = op.rtdetr_post(preds["pred_logits"].cpu(), preds["pred_boxes"].cpu(), (w, h), lp.thresh_score, 6)[0]
+    assert len(ref["scores"]) >= 3
+    assert np.array_equal(mine["labels"], ref["labels"])
+    assert np.array_equal(mine["boxes"].astype(int), ref["boxes"].astype(int))
+    assert np.allclose(mine["scores"], ref["scores"], atol=1e-6)
+    results, _ = lp(img)
+    assert len(results.paragraphs) + len(results.tables) + len(results.figures) > 0
+
+    ts = TableStructureRecognizer(from_pretrained=False, device="cuda:0")
+    sd_t = rtdetr_state_dict(1241, num_classes=3, score_bias=-1.0)
+    ts.model.load_state_dict(sd_t)
+    batch, metas = ts.preprocess(img, tables)
+    preds_t = ts.model(batch)
+    for i, (box, meta) in enumerate(zip(tables, metas)):
+        (rp, _), = op.tables(sd_t, img, [box])
+        assert_same_detections(preds_t["pred_logits"][i : i + 1].cpu().numpy(), preds_t["pred_boxes"][i : i + 1].cpu().numpy(),
+                               rp["pred_logits"].numpy(), rp["pred_boxes"].numpy())
+    out, _ = ts(img, tables)
+    for t in out:
+        assert t.n_row > 0 and t.n_col > 0 and len(t.cells) > 0
+
+
+def test_document_analyzer_end_to_end(dev, page):
+    """The orchestrator returns exactly what its stages return when run one by one (two worker threads
+    on separate HIP streams must not perturb results), and the schema is well formed."""
+    from yomitoku_amd import DocumentAnalyzer
+    from yomitoku_amd.document_analyzer import ocr_aggregate
+    from yomitoku_amd.schemas import DocumentAnalyzerSchema, OCRSchema
+
+    img = page[0]
+    configs = {
+        "ocr": {
+            "text_detector": {"from_pretrained": False},
+            "text_recognizer": {"model_name": "parseq-tiny-dynw-v4", "from_pretrained": False, "dynamic_width": True,
+                                "batch_bucketing": True},
+        },
+        "layout_analyzer": {"layout_parser": {"from_pretrained": False},
+                            "table_structure_recognizer": {"from_pretrained": False}},
+    }
+    an = DocumentAnalyzer(configs=configs, device="cuda:0")
+    from yomitoku_amd.utils.synth import dbnet_state_dict
+
+    from yomitoku_amd.utils.synth_rtdetr import rtdetr_state_dict
+
+    an.text_detector.model.load_state_dict(dbnet_state_dict(1234, out_bias=-3.0))
+    an.layout.layout_parser.model.load_state_dict(rtdetr_state_dict(1240, num_classes=6, score_bias=-2.0))
+    an.layout.table_structure_recognizer.model.load_state_dict(rtdetr_state_dict(1241, num_classes=3, score_bias=-1.0))
+    results, ocr_vis, layout_vis = an(img)
+    assert isinstance(results, DocumentAnalyzerSchema) and ocr_vis is None
+    det, _ = an.text_detector(img)
+    rec, _ = an.text_recognizer(img, det.points)
+    lay, _ = an.layout(img)
+    an.img = img
+    expect = DocumentAnalyzerSchema(**an.aggregate(OCRSchema(words=ocr_aggregate(det, rec)), lay))
+    assert results.model_dump() == expect.model_dump()
+    again, _, _ = an(img)
+    assert again.model_dump() == results.model_dump()
+    orders = sorted([p.order for p in results.paragraphs] + [t.order for t in results.tables] + [f.order for f in results.figures])
+    assert orders == list(range(len(orders)))

@@ -11,6 +11,10 @@
 //                         ToTensor + Normalize(0.5, 0.5), right padding with -1 to the batch width
 #include "ymk_common.h"
 
+// The resamplers round to uint8 (or feed thresholds) after short float sums; cv2 / NumPy evaluate them
+// with separate multiplies and adds, so fused multiply-add contraction is switched off in this file.
+#pragma clang fp contract(off)
+
 namespace ymk {
 
 // ------------------------------------------------------------------ cv2 INTER_AREA tap generator

@@ -56,6 +56,7 @@ def filter_contained_cells_within_spancell(cells, span_boxes):
 
 class TableStructureRecognizer(BaseModule):
     model_catalog = TableStructureRecognizerModelCatalog()
+    MAX_TABLES_PER_FORWARD = 8  # bounds the activation workspace (80x80x512 fp32 maps per table)
 
     def __init__(self, model_name="rtdetrv2", path_cfg=None, device="cuda", visualize=False, from_pretrained=True,
                  infer_onnx=False):
@@ -114,8 +115,8 @@ class TableStructureRecognizer(BaseModule):
 
     def __call__(self, img, table_boxes, vis=None):
         outputs = []
-        if len(table_boxes) > 0:
-            batch, metas = self.preprocess(img, table_boxes)
+        for start in range(0, len(table_boxes), self.MAX_TABLES_PER_FORWARD):
+            batch, metas = self.preprocess(img, table_boxes[start : start + self.MAX_TABLES_PER_FORWARD])
             preds = self.model(batch)
             for i, data in enumerate(metas):
                 one = {"pred_logits": preds["pred_logits"][i : i + 1], "pred_boxes": preds["pred_boxes"][i : i + 1]}

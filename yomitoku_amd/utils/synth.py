@@ -46,8 +46,10 @@ def _bn(sd, d, name, c, gamma=(0.8, 1.2)):
     sd[name + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.int64)
 
 
-def dbnet_state_dict(seed: int = 1234, hidden: int = 256) -> "OrderedDict[str, torch.Tensor]":
-    """State dict of DBNet (reference models/dbnet_plus.py; torchvision resnet50 naming)."""
+def dbnet_state_dict(seed: int = 1234, hidden: int = 256, out_bias: float = 0.0) -> "OrderedDict[str, torch.Tensor]":
+    """State dict of DBNet (reference models/dbnet_plus.py; torchvision resnet50 naming).
+    `out_bias` shifts the last logit: a strongly negative value leaves only sparse blobs above the
+    binarisation threshold (a realistic contour count for the post-processor under random weights)."""
     d = _Draw(seed)
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     bb = "backbone.body."
@@ -86,6 +88,7 @@ def dbnet_state_dict(seed: int = 1234, hidden: int = 256) -> "OrderedDict[str, t
         sd[prefix + ".6.bias"] = d.normal((1,), std=0.05) - 0.5
 
     head(dec + "binarize", hidden)
+    sd[dec + "binarize.6.bias"] += out_bias
     # the `thresh` head exists in the checkpoint (adaptive=True, serial=True) but never runs in forward
     _conv(sd, d, dec + "thresh.0", q, hidden + 1, 3)
     _bn(sd, d, dec + "thresh.1", q)
@@ -146,6 +149,69 @@ def synthetic_page(seed: int = 0, height: int = 1600, width: int = 1200) -> np.n
         fy, fx = int(rng.integers(0, height - fh)), int(rng.integers(0, width - fw))
         img[fy : fy + fh, fx : fx + fw] = rng.integers(0, 256, size=(fh, fw, 3), dtype=np.uint8)
     return img
+
+
+def synthetic_page_with_truth(seed: int = 0, height: int = 1600, width: int = 1200):
+    """(page, line_quads, table_boxes): a page laid out like a form - rows of text segments whose widths
+    follow the crop-width distribution the reference quotes (log-normal, median ~120 px, cli/main.py:508),
+    about a hundred segments per 1600x1200 page, plus 1-2 ruled tables.  The ground-truth quads let the
+    benchmark drive the recogniser / table stages with a realistic unit count even though the seeded
+    random detector / layout weights detect noise."""
+    rng = np.random.default_rng(seed + 7919)
+    img = np.clip(rng.normal(245.0, 3.0, size=(height, width, 3)), 0, 255).astype(np.uint8)
+    lines, tables = [], []
+    n_tables = int(rng.integers(1, 3))
+    table_rows = []
+    for _ in range(n_tables):
+        th, tw = int(rng.integers(140, 300)), int(rng.integers(400, width - 120))
+        ty, tx = int(rng.integers(60, height - th - 60)), int(rng.integers(20, width - tw - 20))
+        if any(not (ty + th < a or ty > b) for a, b in table_rows):
+            continue
+        table_rows.append((ty - 10, ty + th + 10))
+        rows, cols = int(rng.integers(3, 7)), int(rng.integers(2, 6))
+        img[ty : ty + th, tx : tx + tw] = 250
+        for r in range(rows + 1):
+            yy = ty + (th - 2) * r // rows
+            img[yy : yy + 2, tx : tx + tw] = 30
+        for c in range(cols + 1):
+            xx = tx + (tw - 2) * c // cols
+            img[ty : ty + th, xx : xx + 2] = 30
+        tables.append([tx, ty, tx + tw, ty + th])
+        ch, cw = (th - 2) // rows, (tw - 2) // cols
+        for r in range(rows):
+            for c in range(cols):
+                if rng.random() < 0.7 and ch >= 24 and cw >= 50:
+                    lh = int(min(ch - 10, rng.integers(14, 27)))
+                    lw = int(min(cw - 12, max(16, rng.lognormal(math.log(70), 0.5))))
+                    x0, y0 = tx + c * cw + 6, ty + r * ch + 6
+                    lines.append((x0, y0, lw, lh))
+    y = int(rng.integers(20, 50))
+    while y < height - 60:
+        lh = int(rng.integers(16, 40))
+        if any(a <= y + lh and y <= b for a, b in table_rows):
+            y += lh + 8
+            continue
+        x = int(rng.integers(20, 80))
+        while x < width - 60:
+            lw = int(np.clip(rng.lognormal(math.log(120), 0.8), 16, 800))
+            if x + lw > width - 20:
+                break
+            lines.append((x, y, lw, lh))
+            x += lw + int(rng.integers(18, 120))
+            if rng.random() < 0.35:
+                break
+        y += lh + int(rng.integers(6, 26))
+    quads = []
+    for x0, y0, lw, lh in lines:
+        x = x0
+        while x < x0 + lw:
+            gw = int(rng.integers(max(4, lh // 3), lh + 1))
+            gx1 = min(x + gw, x0 + lw)
+            block = img[y0 : y0 + lh, x:gx1]
+            block[rng.random((lh, gx1 - x)) < 0.55] = int(rng.integers(10, 70))
+            x = gx1 + int(rng.integers(2, max(3, lh // 4)))
+        quads.append([[x0 - 2, y0 - 2], [x0 + lw + 2, y0 - 2], [x0 + lw + 2, y0 + lh + 2], [x0 - 2, y0 + lh + 2]])
+    return img, quads, tables
 
 
 # ---------------------------------------------------------------------------------------------
