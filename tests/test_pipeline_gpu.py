@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 def page():
     from yomitoku_amd.utils.synth import synthetic_page_with_truth
 
-    return synthetic_page_with_truth(3, 1000, 1400)
+    return synthetic_page_with_truth(3, 1000, 1400)[:3]
 
 
 def test_text_detector_stages(dev, page):

@@ -1,0 +1,19 @@
+// Fused PARSeq decoder step (ymk_decstep.hip).
+#pragma once
+#include "ymk_common.h"
+
+namespace ymk {
+
+// device pointers; *_t matrices are transposed nn.Linear weights: [in][out]
+struct DecStepW {
+  const float *emb, *posq, *qsa;
+  const float *ncg, *ncb, *n1g, *n1b, *n2g, *n2b, *dng, *dnb;
+  const float *Wkv_t, *bkv, *Wo1_t, *bo1, *Wq_t, *bq, *Wo2_t, *bo2, *W1_t, *b1, *W2_t, *b2;
+  int D, H, F;
+};
+
+bool parseq_dec_step_supported(int D, int H, int F, int L, int NS);
+void parseq_dec_step(hipStream_t s, const DecStepW& W, const int* tok, int ld_tok, int step, float* skv, int NS,
+                     const float* memkv, int L, float* out, const int* prev_not_done, int B);
+
+}  // namespace ymk

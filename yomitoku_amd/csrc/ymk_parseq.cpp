@@ -10,6 +10,7 @@
 //     int per step (the "every row has an <eos>" flag, models/parseq.py:245-250).
 #include "ymk_common.h"
 #include "ymk_seq.h"
+#include "ymk_decstep.h"
 
 namespace ymk {
 
@@ -89,6 +90,35 @@ class ParseqModel : public Model {
     };
     split_mha("self_attn", sa_q_, sa_kv_, sa_o_);
     split_mha("cross_attn", ca_q_, ca_kv_, ca_o_);
+    {
+      // transposed copies ([in][out]) for the fused one-kernel decoder step (ymk_decstep.hip)
+      auto tr = [&](const float* w, int out, int in) {
+        std::vector<float> t((size_t)out * in);
+        for (int o = 0; o < out; ++o)
+          for (int k = 0; k < in; ++k) t[(size_t)k * out + o] = w[(size_t)o * in + k];
+        return pool.upload(t);
+      };
+      const HostTensor& sw = ws.get(d + "self_attn.in_proj_weight");
+      const HostTensor& sb = ws.get(d + "self_attn.in_proj_bias");
+      const HostTensor& cw = ws.get(d + "cross_attn.in_proj_weight");
+      const HostTensor& cb = ws.get(d + "cross_attn.in_proj_bias");
+      const int D = Dd_, F = (int)ws.get(d + "linear1.weight").dims[0];
+      fw_.D = D;
+      fw_.H = dh_;
+      fw_.F = F;
+      fw_.Wkv_t = tr(sw.data.data() + (size_t)D * D, 2 * D, D);
+      fw_.bkv = pool.upload(sb.data.data() + D, 2 * D);
+      fw_.Wo1_t = tr(ws.get(d + "self_attn.out_proj.weight").data.data(), D, D);
+      fw_.bo1 = pool.upload(ws.get(d + "self_attn.out_proj.bias").data);
+      fw_.Wq_t = tr(cw.data.data(), D, D);
+      fw_.bq = pool.upload(cb.data.data(), D);
+      fw_.Wo2_t = tr(ws.get(d + "cross_attn.out_proj.weight").data.data(), D, D);
+      fw_.bo2 = pool.upload(ws.get(d + "cross_attn.out_proj.bias").data);
+      fw_.W1_t = tr(ws.get(d + "linear1.weight").data.data(), F, D);
+      fw_.b1 = pool.upload(ws.get(d + "linear1.bias").data);
+      fw_.W2_t = tr(ws.get(d + "linear2.weight").data.data(), D, F);
+      fw_.b2 = pool.upload(ws.get(d + "linear2.bias").data);
+    }
     lin1_ = make_linear(pool, ws, d + "linear1");
     lin2_ = make_linear(pool, ws, d + "linear2");
     auto up = [&](const std::string& n) { return pool.upload(ws.get(n).data); };
@@ -106,6 +136,10 @@ class ParseqModel : public Model {
       const HostTensor& pq = ws.get("pos_queries");
       YMK_CHECK((int)pq.numel() == nsteps_ * Dd_, "pos_queries shape");
       posq_ = pool.upload(pq.data);
+      fw_.emb = emb_;
+      fw_.posq = posq_;
+      fw_.ncg = ncg_; fw_.ncb = ncb_; fw_.n1g = n1g_; fw_.n1b = n1b_; fw_.n2g = n2g_; fw_.n2b = n2b_;
+      fw_.dng = dng_; fw_.dnb = dnb_;
     }
     {
       // refinement query mask (models/parseq.py:267-277): triu(1) with rows 0 and 1 cleared
@@ -117,7 +151,8 @@ class ParseqModel : public Model {
       YMK_HIP(hipMalloc(&dm, m.size()));
       YMK_HIP(hipMemcpy(dm, m.data(), m.size(), hipMemcpyHostToDevice));
       qmask_ = (unsigned char*)dm;
-      YMK_HIP(hipHostMalloc((void**)&host_flag_, sizeof(int)));
+      YMK_HIP(hipHostMalloc((void**)&host_flags_, (size_t)nsteps_ * sizeof(int), hipHostMallocMapped));
+      YMK_HIP(hipHostGetDevicePointer((void**)&host_flags_dev_, host_flags_, 0));
     }
     ws.clear();
     finalized = true;
@@ -125,7 +160,7 @@ class ParseqModel : public Model {
 
   ~ParseqModel() override {
     if (qmask_) (void)hipFree(qmask_);
-    if (host_flag_) (void)hipHostFree(host_flag_);
+    if (host_flags_) (void)hipHostFree(host_flags_);
   }
 
   int num_classes() const { return C_; }
@@ -210,7 +245,7 @@ class ParseqModel : public Model {
     int* raw = (int*)arena.alloc_bytes((size_t)MR * sizeof(int));
     int* tok2 = (int*)arena.alloc_bytes((size_t)MR * sizeof(int));
     int* state = (int*)arena.alloc_bytes((size_t)B * 4 * sizeof(int));
-    int* not_done = (int*)arena.alloc_bytes(256);
+    int* not_done = (int*)arena.alloc_bytes((size_t)2 * NS * sizeof(int));
     unsigned char* kpm = (unsigned char*)arena.alloc_bytes((size_t)MR);
     if (dry) return;
 
@@ -253,25 +288,64 @@ class ParseqModel : public Model {
     }
     const int dhd = D / dh_;
     const float dscale = 1.f / std::sqrt((float)dhd);
-    int steps = 0;
-    for (int i = 0; i < NS; ++i) {
-      // content row i (token tok[:, i]) -> norm_c -> K|V cache row i
-      ctx_embed_ln(s, tok, NS, i, 1, emb_, posq_, ncg_, ncb_, 1e-5f, cn, NS, D, B);
-      gemm(s, cn + (size_t)i * D, B, D, NS * D, sa_kv_, ACT_NONE, nullptr, 0, skv + (size_t)i * 2 * D, NS * 2 * D);
-      // query i attends context 0..i (mask row i of triu(1) blocks nothing among those keys)
-      small_attention(s, qsa + (size_t)i * D, skv, skv + D, t1, B, dh_, 1, i + 1, dhd, D, 2 * D, 2 * D, D, 0,
-                      (long)NS * 2 * D, (long)NS * 2 * D, D, dscale, nullptr, 0, nullptr, 0);
-      gemm(s, t1, B, D, D, sa_o_, ACT_NONE, posq_ + (size_t)i * D, 0, qcur, D);
-      stream_tail(s, qcur, B, B, 1, memkv, L, t1, t2, hdec, arlog + (size_t)i * C, NS * C);
-      YMK_HIP(hipMemsetAsync(not_done, 0, sizeof(int), s));
-      greedy_step(s, arlog + (size_t)i * C, (long)NS * C, C, i, NS, tok, raw, NS, state, eos_, rep_on_, rep_pmax_, rep_p1_,
-                  rep_min_, not_done, B);
-      steps = i + 1;
-      if (i + 1 < NS) {
-        YMK_HIP(hipMemcpyAsync(host_flag_, not_done, sizeof(int), hipMemcpyDeviceToHost, s));
-        YMK_HIP(hipStreamSynchronize(s));
-        if (*host_flag_ == 0) break;  // every row holds an <eos> (models/parseq.py:245-250)
+    // Early stop without stalling the queue: step i counts the rows still lacking an <eos> into
+    // not_done[i] and publishes it to mapped pinned host memory; the host reads the flag of step
+    // i - LAG, so up to LAG speculative steps are in flight.  A speculative step's greedy kernel sees
+    // not_done[i-1] == 0 and leaves tokens / repetition state untouched, hence `steps` and every
+    // result are exactly those of the reference's step-by-step test (models/parseq.py:245-250).
+    constexpr int LAG = 2;
+    YMK_HIP(hipMemsetAsync(not_done, 0, (size_t)2 * NS * sizeof(int), s));  // not_done[NS] | arrived[NS]
+    int* arrived = not_done + NS;
+    // host_flags_ is mapped pinned memory the last-arriving block of step i's greedy kernel writes
+    // (count + 1, so 0 = "not reported yet"): no copy-engine hop, no event per step.  Only
+    // non-speculative steps write, and all of those have completed before a forward returns.
+    for (int i = 0; i < NS; ++i) host_flags_[i] = 0;
+    auto wait_flag = [&](int i) -> int {
+      for (long spin = 0;; ++spin) {
+        const int v = __atomic_load_n(&host_flags_[i], __ATOMIC_ACQUIRE);
+        if (v != 0) return v - 1;
+        if ((spin & 0xFFFF) == 0xFFFF) {  // the step may have faulted: do not spin forever
+          hipError_t e = hipStreamQuery(s);
+          if (e != hipSuccess && e != hipErrorNotReady) YMK_HIP(e);
+          if (e == hipSuccess && __atomic_load_n(&host_flags_[i], __ATOMIC_ACQUIRE) == 0)
+            throw Error("parseq: AR step " + std::to_string(i) + " never reported its <eos> count");
+        }
       }
+    };
+    int steps = NS;
+    const bool fused = parseq_dec_step_supported(D, dh_, lin1_.cout, L, NS) && !getenv("YMK_PARSEQ_UNFUSED");
+    for (int i = 0; i < NS; ++i) {
+      const int* prev = i > 0 ? not_done + i - 1 : nullptr;
+      if (fused) {
+        // the whole query stream of step i in one launch, then the vocabulary head as a GEMM
+        DecStepW w = fw_;
+        w.qsa = qsa;
+        parseq_dec_step(s, w, tok, NS, i, skv, NS, memkv, L, t1, prev, B);
+        gemm(s, t1, B, D, D, head_, ACT_NONE, nullptr, 0, arlog + (size_t)i * C, NS * C);
+      } else {
+        // content row i (token tok[:, i]) -> norm_c -> K|V cache row i
+        ctx_embed_ln(s, tok, NS, i, 1, emb_, posq_, ncg_, ncb_, 1e-5f, cn, NS, D, B);
+        gemm(s, cn + (size_t)i * D, B, D, NS * D, sa_kv_, ACT_NONE, nullptr, 0, skv + (size_t)i * 2 * D, NS * 2 * D);
+        // query i attends context 0..i (mask row i of triu(1) blocks nothing among those keys)
+        small_attention(s, qsa + (size_t)i * D, skv, skv + D, t1, B, dh_, 1, i + 1, dhd, D, 2 * D, 2 * D, D, 0,
+                        (long)NS * 2 * D, (long)NS * 2 * D, D, dscale, nullptr, 0, nullptr, 0);
+        gemm(s, t1, B, D, D, sa_o_, ACT_NONE, posq_ + (size_t)i * D, 0, qcur, D);
+        stream_tail(s, qcur, B, B, 1, memkv, L, t1, t2, hdec, arlog + (size_t)i * C, NS * C);
+      }
+      greedy_step(s, arlog + (size_t)i * C, (long)NS * C, C, i, NS, tok, raw, NS, state, eos_, rep_on_, rep_pmax_, rep_p1_,
+                  rep_min_, not_done + i, i > 0 ? not_done + i - 1 : nullptr, arrived + i,
+                  i + 1 < NS ? host_flags_dev_ + i : nullptr /* the last step's count is never read */, B);
+      if (i + 1 < NS && i >= LAG && wait_flag(i - LAG) == 0) {  // every row held an <eos> after step i - LAG
+        steps = i - LAG + 1;
+        break;
+      }
+    }
+    if (steps == NS) {  // not stopped inside the loop: the last LAG flags have not been looked at yet
+      for (int i = std::max(0, NS - 1 - LAG); i + 1 < NS; ++i)
+        if (wait_flag(i) == 0) {
+          steps = i + 1;
+          break;
+        }
     }
     *ar_steps = steps;
 
@@ -310,10 +384,12 @@ class ParseqModel : public Model {
   std::vector<EncBlock> blocks_;
   float *enc_ng_ = nullptr, *enc_nb_ = nullptr;
   ConvW sa_q_, sa_kv_, sa_o_, ca_q_, ca_kv_, ca_o_, lin1_, lin2_, head_;
+  DecStepW fw_{};  // transposed decoder weights for the fused step
   float *n1g_, *n1b_, *n2g_, *n2b_, *nqg_, *nqb_, *ncg_, *ncb_, *dng_, *dnb_;
   float *emb_ = nullptr, *posq_ = nullptr;
   unsigned char* qmask_ = nullptr;
-  int* host_flag_ = nullptr;
+  int* host_flags_ = nullptr;      // mapped pinned: (rows still open) + 1 per AR step
+  int* host_flags_dev_ = nullptr;  // the same words as the device addresses them
   uint64_t shape_key_ = 0;
 };
 

@@ -392,8 +392,11 @@ __global__ __launch_bounds__(256) void k_greedy_step(const float* __restrict__ l
                                                      int num_steps, int* __restrict__ tok, int* __restrict__ raw,
                                                      int ld_tok, int* __restrict__ state, int eos_id, int rep_on,
                                                      int period_max, int min_run_p1, int min_repeats,
-                                                     int* __restrict__ not_done) {
+                                                     int* __restrict__ not_done, const int* __restrict__ prev_not_done,
+                                                     int* __restrict__ arrived, int* __restrict__ host_flag) {
   const int b = blockIdx.x, t = threadIdx.x;
+  // speculative step issued after every row already held an <eos>: change nothing (not_done stays 0)
+  if (prev_not_done && *prev_not_done == 0) return;
   const float* row = logits + (size_t)b * ld_b;
   float best = -INFINITY;
   int bi = 0x7fffffff;
@@ -459,12 +462,20 @@ __global__ __launch_bounds__(256) void k_greedy_step(const float* __restrict__ l
     if (next == eos_id) st[0] = 1;
   }
   if (!st[0]) atomicAdd(not_done, 1);
+  if (host_flag) {
+    // the last block to arrive publishes (rows still open) + 1 to the mapped host word the AR loop polls
+    __threadfence();
+    if (atomicAdd(arrived, 1) == (int)gridDim.x - 1) {
+      const int open = atomicAdd(not_done, 0);
+      __hip_atomic_store(host_flag, open + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 void greedy_step(hipStream_t s, const float* logits, long ld_b, int C, int step, int num_steps, int* tok, int* raw,
                  int ld_tok, int* state, int eos_id, int rep_on, int period_max, int min_run_p1, int min_repeats,
-                 int* not_done, int B) {
+                 int* not_done, const int* prev_not_done, int* arrived, int* host_flag, int B) {
   hipLaunchKernelGGL(k_greedy_step, dim3(B), dim3(256), 0, s, logits, ld_b, C, step, num_steps, tok, raw, ld_tok, state,
-                     eos_id, rep_on, period_max, min_run_p1, min_repeats, not_done);
+                     eos_id, rep_on, period_max, min_run_p1, min_repeats, not_done, prev_not_done, arrived, host_flag);
   YMK_HIP(hipGetLastError());
 }
 

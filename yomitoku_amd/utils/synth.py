@@ -152,7 +152,7 @@ def synthetic_page(seed: int = 0, height: int = 1600, width: int = 1200) -> np.n
 
 
 def synthetic_page_with_truth(seed: int = 0, height: int = 1600, width: int = 1200):
-    """(page, line_quads, table_boxes): a page laid out like a form - rows of text segments whose widths
+    """(page, line_quads, table_boxes, paragraph_boxes): a page laid out like a form - rows of text segments whose widths
     follow the crop-width distribution the reference quotes (log-normal, median ~120 px, cli/main.py:508),
     about a hundred segments per 1600x1200 page, plus 1-2 ruled tables.  The ground-truth quads let the
     benchmark drive the recogniser / table stages with a realistic unit count even though the seeded
@@ -186,21 +186,31 @@ def synthetic_page_with_truth(seed: int = 0, height: int = 1600, width: int = 12
                     x0, y0 = tx + c * cw + 6, ty + r * ch + 6
                     lines.append((x0, y0, lw, lh))
     y = int(rng.integers(20, 50))
+    paragraphs = []  # blocks of consecutive text rows (what a layout model would call a paragraph)
+    block, block_left = None, 0
     while y < height - 60:
         lh = int(rng.integers(16, 40))
         if any(a <= y + lh and y <= b for a, b in table_rows):
             y += lh + 8
+            block = None
             continue
+        if block is None or block_left == 0:
+            block = [width, y, 0, y]
+            paragraphs.append(block)
+            block_left = int(rng.integers(2, 7))
+        block_left -= 1
         x = int(rng.integers(20, 80))
         while x < width - 60:
             lw = int(np.clip(rng.lognormal(math.log(120), 0.8), 16, 800))
             if x + lw > width - 20:
                 break
             lines.append((x, y, lw, lh))
+            block[0], block[2], block[3] = min(block[0], x - 6), max(block[2], x + lw + 6), y + lh + 4
             x += lw + int(rng.integers(18, 120))
             if rng.random() < 0.35:
                 break
         y += lh + int(rng.integers(6, 26))
+    paragraphs = [[max(b[0], 0), max(b[1] - 4, 0), min(b[2], width), min(b[3], height)] for b in paragraphs if b[2] > b[0]]
     quads = []
     for x0, y0, lw, lh in lines:
         x = x0
@@ -211,7 +221,7 @@ def synthetic_page_with_truth(seed: int = 0, height: int = 1600, width: int = 12
             block[rng.random((lh, gx1 - x)) < 0.55] = int(rng.integers(10, 70))
             x = gx1 + int(rng.integers(2, max(3, lh // 4)))
         quads.append([[x0 - 2, y0 - 2], [x0 + lw + 2, y0 - 2], [x0 + lw + 2, y0 + lh + 2], [x0 - 2, y0 + lh + 2]])
-    return img, quads, tables
+    return img, quads, tables, paragraphs
 
 
 # ---------------------------------------------------------------------------------------------

@@ -43,7 +43,7 @@ def sincos_pos_embed(w: int, h: int, dim: int = 256, temperature: float = 10000.
 
 
 def rtdetr_state_dict(seed: int = 1240, num_classes: int = 6, hidden: int = 256, num_layers: int = 6, ffn: int = 1024,
-                      num_queries: int = 300, score_bias: float = 0.0) -> "OrderedDict[str, torch.Tensor]":
+                      num_queries: int = 300, score_bias: float = 0.0, score_gain: float = 1.0) -> "OrderedDict[str, torch.Tensor]":
     d = _Draw(seed)
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
 
@@ -142,9 +142,10 @@ def rtdetr_state_dict(seed: int = 1240, num_classes: int = 6, hidden: int = 256,
         linear(f"{t}dec_score_head.{i}", num_classes, hidden, gain=1.5, bias_std=0.5)
     for i in range(num_layers):
         mlp3(f"{t}dec_bbox_head.{i}")
-    if score_bias:
-        # shift the final class logits so that only a realistic handful of the 300 queries clear the
-        # score threshold (random heads would otherwise "detect" hundreds of boxes per page)
+    if score_bias or score_gain != 1.0:
+        # widen / shift the final class logits so that only a realistic handful of the 300 queries clear
+        # the score threshold (random heads would otherwise "detect" hundreds of boxes per page, or none)
+        sd[f"{t}dec_score_head.{num_layers - 1}.weight"] *= score_gain
         sd[f"{t}dec_score_head.{num_layers - 1}.bias"] += score_bias
     anchors, valid = generate_anchors()
     sd[t + "anchors"] = anchors
