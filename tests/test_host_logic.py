@@ -16,14 +16,54 @@ def gold():
         return json.load(f)
 
 
-def test_reading_order_matches_reference(gold):
-    from yomitoku_amd.reading_order import prediction_reading_order
+@pytest.mark.parametrize("vector_min", [2, 6, 10 ** 9], ids=["numpy-graph", "default", "scalar-graph"])
+def test_reading_order_matches_reference(gold, vector_min, monkeypatch):
+    from yomitoku_amd import reading_order as ro
 
+    monkeypatch.setattr(ro, "VECTOR_MIN_BOXES", vector_min)  # both graph builders must give the reference's order
     assert len(gold["reading_order"]) >= 200
     for case in gold["reading_order"]:
         els = [SimpleNamespace(box=b, order=0) for b in case["boxes"]]
-        prediction_reading_order(els, case["direction"])
+        ro.prediction_reading_order(els, case["direction"])
         assert [e.order for e in els] == case["order"], case["direction"]
+
+
+def test_vector_graph_equals_scalar_graph_on_dense_pages():
+    """Pages far bigger than the golden cases: the numpy edge list must equal the scalar double loop's."""
+    import random
+
+    from yomitoku_amd import reading_order as ro
+
+    rng = random.Random(5)
+    for trial in range(30):
+        n = rng.randint(6, 90)
+        boxes = []
+        for _ in range(n):
+            x, y = rng.randint(0, 1500), rng.randint(0, 1100)
+            boxes.append([x, y, x + rng.randint(1, 400), y + rng.randint(1, 120)])
+        for direction in ("top2bottom", "right2left", "left2right"):
+            fast = ro._build([list(b) for b in boxes], direction)
+            ro.VECTOR_MIN_BOXES, keep = 10 ** 9, ro.VECTOR_MIN_BOXES
+            try:
+                slow = ro._build([list(b) for b in boxes], direction)
+            finally:
+                ro.VECTOR_MIN_BOXES = keep
+            assert fast.children == slow.children and fast.distance == slow.distance
+            assert [sorted(p) for p in fast.parents] == [sorted(p) for p in slow.parents]
+
+
+def test_containment_matrix_equals_scalar_predicate(gold):
+    import numpy as np
+
+    from yomitoku_amd import geometry as g
+
+    a = [p["a"] for p in gold["pairs"]]
+    b = [p["b"] for p in gold["pairs"]]
+    for thr in (0.5, 0.7, 0.8):
+        m = g.containment_matrix(a, b, thr)
+        want = np.array([[g.is_contained(x, y, thr) for y in b] for x in a])
+        assert (m == want).all()
+    assert g.containment_matrix([], b, 0.5).shape == (0, len(b))
 
 
 def test_reading_order_small_inputs():

@@ -44,13 +44,25 @@ CASES = [
     (1, 4, 5, 7, 36, 1, 1, 0, 1),         # tiny K
     (3, 256, 40, 48, 64, 3, 1, 1, 1),     # wide-M path (128x64 tiles)
     (1, 1024, 26, 30, 2048, 1, 1, 0, 1),  # 128x128 tiles
+    (1, 512, 20, 20, 512, 3, 1, 1, 1),    # RT-DETR res5: 400 pixels, 144 K tiles (grid-starved, split-K)
+    (1, 256, 1, 300, 96, 1, 1, 0, 1),     # decoder linear: 300 queries
+    (1, 192, 1, 42, 1000, 1, 1, 0, 1),    # PARSeq head shape: few rows, wide N, 6 K tiles
+    (1, 64, 1, 3, 8, 1, 1, 0, 1),         # fewer K tiles than waves
 ]
 
 
+# kernel routing: the library's own choice, conv_igemm only, or one fixed split-K shape
+# (ymk_conv.hip try_splitk candidates: 64x64/4, 64x32/4, 64x32/8, 32x32/4, 32x32/8 waves)
+ROUTES = [("auto", {}), ("igemm", {"YMK_NO_SPLITK": "1"})] + [(f"splitk{i}", {"YMK_SPLITK_FORCE": str(i)}) for i in range(5)]
+
+
+@pytest.mark.parametrize("route", ROUTES, ids=[r[0] for r in ROUTES])
 @pytest.mark.parametrize("case", CASES)
-def test_conv2d_matches_torch(dev, case):
+def test_conv2d_matches_torch(dev, case, route, monkeypatch):
     from yomitoku_amd import hipops
 
+    for key, val in route[1].items():
+        monkeypatch.setenv(key, val)
     n, cin, h, w, cout, k, stride, pad, dil = case
     g = torch.Generator().manual_seed(hash(case) % (2**31))
     x = torch.randn(n, cin, h, w, generator=g)

@@ -63,6 +63,80 @@ constexpr int LDK = 36;  // padded K-tile row (floats)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in SSA registers
 constexpr unsigned OOB_OFFSET = 0xFFFFFFF0u;
+constexpr unsigned SPLITK_OOB_ROW = 0xC0000000u;  // conv_splitk: row base of a masked pixel (+ channel bytes, no wrap)
+
+// ---- epilogue over a block tile staged in LDS as Cs[BM][BN + 4]: scale/bias, residual (before or after
+// the activation), activation, plain or 2x2 pixel-shuffle store; NT threads, 16 B per lane, full rows coalesced.
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void epilogue_tile(const ConvK& p, const float* Cs, int m0, int n0, int t) {
+  constexpr int LDC = BN + 4;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int TPR = BN / 4;        // threads per output row
+  constexpr int RPP = NT / TPR;     // rows per pass
+  const int c4 = t % TPR, r0 = t / TPR;
+  const int co = n0 + c4 * 4;
+  if (co >= p.Cout) return;
+  const int ohw = p.OH * p.OW;
+  if (p.vec) {
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = zero4;
+    if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + co);
+    if (p.bias) bi = *reinterpret_cast<const float4*>(p.bias + co);
+    int cq = co, ab = 0;
+    if (p.epi == EPI_DECONV2X2) {
+      const int cq_n = p.Cout >> 2;
+      ab = co / cq_n;
+      cq = co - ab * cq_n;
+    }
+#pragma unroll 4
+    for (int row = r0; row < BM; row += RPP) {
+      const int m = m0 + row;
+      if (m >= p.M) break;
+      float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + c4 * 4);
+      v.x = v.x * sc.x + bi.x;
+      v.y = v.y * sc.y + bi.y;
+      v.z = v.z * sc.z + bi.z;
+      v.w = v.w * sc.w + bi.w;
+      size_t o;
+      float4 rr = zero4;
+      if (p.epi == EPI_STORE) {
+        if (p.res) {
+          rr = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.res_ld + co);
+          if (!p.res_post) {
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+          }
+        }
+        o = (size_t)m * p.out_ld + co;
+      } else {  // ConvTranspose2d(k=2, s=2): co = (a2*2+b2)*Cq + cq -> pixel (2oh+a2, 2ow+b2)
+        const int n = m / ohw, rem = m - n * ohw;
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        const size_t opix = ((size_t)n * (2 * p.OH) + 2 * oh + (ab >> 1)) * (2 * p.OW) + 2 * ow + (ab & 1);
+        o = opix * p.out_ld + cq;
+      }
+      v.x = apply_act(v.x, p.act);
+      v.y = apply_act(v.y, p.act);
+      v.z = apply_act(v.z, p.act);
+      v.w = apply_act(v.w, p.act);
+      if (p.res_post) {  // y = res + act(conv): CSPRep "x_1 + conv2(x)" (rtdetr_hybrid_encoder.py:209-213)
+        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+      }
+      *reinterpret_cast<float4*>(p.out + o) = v;
+    }
+  } else {  // ragged Cout / unaligned rows: scalar stores (EPI_STORE only)
+    for (int row = r0; row < BM; row += RPP) {
+      const int m = m0 + row;
+      if (m >= p.M) break;
+      for (int e = 0; e < 4 && co + e < p.Cout; ++e) {
+        float v = Cs[row * LDC + c4 * 4 + e];
+        v = v * (p.scale ? p.scale[co + e] : 1.f) + (p.bias ? p.bias[co + e] : 0.f);
+        const float rr = p.res ? p.res[(size_t)m * p.res_ld + co + e] : 0.f;
+        if (!p.res_post) v += rr;
+        v = apply_act(v, p.act);
+        if (p.res_post) v += rr;
+        p.out[(size_t)m * p.out_ld + co + e] = v;
+      }
+    }
+  }
+}
 
 template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_igemm(ConvK p) {
@@ -110,7 +184,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvK p) {
 
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
   f32x4 ra[APASS], rb[BPASS];
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // K-tile cursor (wave-uniform, kept in scalar registers): tap (kh, kw) and channel tile cc
   int cur_kh = 0, cur_kw = 0, cur_cc = 0;
@@ -225,71 +298,166 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvK p) {
       }
   __syncthreads();
 
-  constexpr int TPR = BN / 4;        // threads per output row
-  constexpr int RPP = 256 / TPR;     // rows per pass
-  const int c4 = t % TPR, r0 = t / TPR;
-  const int co = n0 + c4 * 4;
-  if (co >= p.Cout) return;
-  const int ohw = p.OH * p.OW;
-  if (p.vec) {
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = zero4;
-    if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + co);
-    if (p.bias) bi = *reinterpret_cast<const float4*>(p.bias + co);
-    int cq = co, ab = 0;
-    if (p.epi == EPI_DECONV2X2) {
-      const int cq_n = p.Cout >> 2;
-      ab = co / cq_n;
-      cq = co - ab * cq_n;
-    }
-#pragma unroll 4
-    for (int row = r0; row < BM; row += RPP) {
-      const int m = m0 + row;
-      if (m >= p.M) break;
-      float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + c4 * 4);
-      v.x = v.x * sc.x + bi.x;
-      v.y = v.y * sc.y + bi.y;
-      v.z = v.z * sc.z + bi.z;
-      v.w = v.w * sc.w + bi.w;
-      size_t o;
-      float4 rr = zero4;
-      if (p.epi == EPI_STORE) {
-        if (p.res) {
-          rr = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.res_ld + co);
-          if (!p.res_post) {
-            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-          }
-        }
-        o = (size_t)m * p.out_ld + co;
-      } else {  // ConvTranspose2d(k=2, s=2): co = (a2*2+b2)*Cq + cq -> pixel (2oh+a2, 2ow+b2)
-        const int n = m / ohw, rem = m - n * ohw;
-        const int oh = rem / p.OW, ow = rem - oh * p.OW;
-        const size_t opix = ((size_t)n * (2 * p.OH) + 2 * oh + (ab >> 1)) * (2 * p.OW) + 2 * ow + (ab & 1);
-        o = opix * p.out_ld + cq;
-      }
-      v.x = apply_act(v.x, p.act);
-      v.y = apply_act(v.y, p.act);
-      v.z = apply_act(v.z, p.act);
-      v.w = apply_act(v.w, p.act);
-      if (p.res_post) {  // y = res + act(conv): CSPRep "x_1 + conv2(x)" (rtdetr_hybrid_encoder.py:209-213)
-        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-      }
-      *reinterpret_cast<float4*>(p.out + o) = v;
-    }
-  } else {  // ragged Cout / unaligned rows: scalar stores (EPI_STORE only)
-    for (int row = r0; row < BM; row += RPP) {
-      const int m = m0 + row;
-      if (m >= p.M) break;
-      for (int e = 0; e < 4 && co + e < p.Cout; ++e) {
-        float v = Cs[row * LDC + c4 * 4 + e];
-        v = v * (p.scale ? p.scale[co + e] : 1.f) + (p.bias ? p.bias[co + e] : 0.f);
-        const float rr = p.res ? p.res[(size_t)m * p.res_ld + co + e] : 0.f;
-        if (!p.res_post) v += rr;
-        v = apply_act(v, p.act);
-        if (p.res_post) v += rr;
-        p.out[(size_t)m * p.out_ld + co + e] = v;
-      }
+  epilogue_tile<BM, BN, 256>(p, Cs, m0, n0, t);
+}
+
+// ---- grid-starved shapes (batch-1 RT-DETR stages, decoder linears, the PARSeq head): split K over the
+// waves of a block.  conv_igemm gives such a launch fewer than one 4-wave block per CU, and each wave
+// then walks the whole K extent with one global->LDS round trip per K tile (measured ~0.9 us per tile,
+// twice its MFMA time).  Here a block owns a (32 TM) x (32 TN) tile and wave w takes K tiles
+// w, w + NW, ...: NW x more waves in flight, and no LDS in the main loop at all - with the in-chunk K
+// permutation each lane's MFMA operands for 4 consecutive k are one 16 B global load (A: its pixel row,
+// B: its weight row), PF K tiles deep in registers.  The NW partial tiles are summed pairwise through
+// LDS in a fixed order (deterministic), then the usual epilogue runs on the block tile.
+template <int TM, int TN, int NW, int PF>
+__global__ __launch_bounds__(64 * NW) void conv_splitk(ConvK p) {
+  constexpr int BM = 32 * TM, BN = 32 * TN, NT = 64 * NW;
+  constexpr int LDC = BN + 4;
+  constexpr int PART = TM * TN * 16 * 64;  // floats of one wave's accumulators
+  constexpr int RED = (NW / 2) * PART > BM * LDC ? (NW / 2) * PART : BM * LDC;
+  __shared__ __attribute__((aligned(16))) float red[RED];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, li = lane & 31, lh = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  int tile;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = tile / p.ntiles_n, tile_n = tile - tile_m * p.ntiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  int pixb[TM], ih0[TM], iw0[TM];
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const int m = m0 + 32 * a + li;
+    if (m < p.M) {
+      const int ohw = p.OH * p.OW;
+      const int n = m / ohw, rem = m - n * ohw;
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      pixb[a] = n * p.H * p.W;
+      ih0[a] = oh * p.stride - p.pad;
+      iw0[a] = ow * p.stride_w - p.pad;
+    } else {
+      pixb[a] = 0;
+      ih0[a] = -(1 << 20);
+      iw0[a] = 0;
     }
   }
+  const float* wrow = p.w + (size_t)(n0 + li) * p.Kpad + lh * 4;  // panel rows are padded to 128: always in range
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+
+  const int ktiles = p.Kpad >> 5;
+  const int nt = wv < ktiles ? (ktiles - wv + NW - 1) / NW : 0;  // K tiles of this wave
+  f32x4 sa[PF][TM][4], sb[PF][TN][4];
+
+  // K tile j of this wave -> registers of stage s; j past the end re-reads the last tile (never consumed)
+  auto load = [&](int s, int j) {
+    int kt = wv + NW * j;
+    kt = kt < ktiles ? kt : ktiles - 1;
+    const int tap = kt / p.ctiles, cc = kt - tap * p.ctiles;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int dh = kh * p.dil, dw = kw * p.dil;
+    const int c0 = cc * 32 + lh * 4;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const int ih = ih0[a] + dh, iw = iw0[a] + dw;
+      const bool ok = (unsigned)ih < (unsigned)p.H & (unsigned)iw < (unsigned)p.W;
+      // padding taps / tail rows: a row base past the descriptor's range, so all four loads return zeros
+      const unsigned row = ok ? (unsigned)(pixb[a] + ih * p.W + iw) * (unsigned)p.in_ld * 4u : SPLITK_OOB_ROW;
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+        // chunks past C (C % 32 != 0) re-read the last real chunk: finite data against zero-padded weights
+        const int c = min(c0 + kc * 8, p.C - 4);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(row + (unsigned)c * 4u), 0, 0);
+        sa[s][a][kc] = __builtin_bit_cast(f32x4, v);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc)
+        sb[s][b][kc] = *reinterpret_cast<const f32x4*>(wrow + (size_t)(32 * b) * p.Kpad + kt * 32 + kc * 8);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  auto compute = [&](int s) {
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[s][a][kc].x, sb[s][b][kc].x, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[s][a][kc].y, sb[s][b][kc].y, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[s][a][kc].z, sb[s][b][kc].z, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[s][a][kc].w, sb[s][b][kc].w, acc[a][b], 0, 0, 0);
+        }
+  };
+
+#pragma unroll
+  for (int s = 0; s < PF; ++s) load(s, s);
+  int j0 = 0;
+  for (; j0 + PF <= nt; j0 += PF) {  // full groups: one basic block, so the load waits stay precise
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+      compute(s);
+      load(s, j0 + s + PF);
+    }
+  }
+  {
+    const int rem = nt - j0;
+#pragma unroll
+    for (int s = 0; s < PF - 1; ++s)
+      if (s < rem) compute(s);
+  }
+
+  // ---- sum the NW partial tiles: upper half of the live waves hands its registers to the lower half
+#pragma unroll
+  for (int half = NW / 2; half >= 1; half >>= 1) {
+    if (wv >= half && wv < 2 * half) {
+      float* dst = red + (wv - half) * PART + lane;
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[((a * TN + b) * 16 + r) * 64] = acc[a][b][r];
+    }
+    __syncthreads();
+    if (wv < half) {
+      const float* src = red + wv * PART + lane;
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][b][r] += src[((a * TN + b) * 16 + r) * 64];
+    }
+    __syncthreads();
+  }
+  if (wv == 0) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          red[row * LDC + b * 32 + li] = acc[a][b][r];
+        }
+  }
+  __syncthreads();
+  epilogue_tile<BM, BN, NT>(p, red, m0, n0, t);
 }
 
 // ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream
@@ -302,6 +470,17 @@ struct ProfState {
   std::vector<double> lflop;
 };
 static ProfState g_prof;
+
+// conv_igemm launches with fewer blocks than this go to the split-K kernel (1.5 blocks per CU)
+constexpr int SPLITK_MAX_GRID = 384;
+static int splitk_forced() {  // YMK_SPLITK_FORCE=<candidate index>: that split-K shape for every launch (kernel tests)
+  const char* e = getenv("YMK_SPLITK_FORCE");
+  return e && e[0] >= '0' && e[0] <= '9' ? e[0] - '0' : -1;
+}
+static bool no_splitk() {  // YMK_NO_SPLITK=1: every launch through conv_igemm (A/B profiling, kernel tests)
+  const char* e = getenv("YMK_NO_SPLITK");
+  return e && e[0] == '1';
+}
 
 void prof_begin() {
   g_prof.on = true;
@@ -325,10 +504,8 @@ void prof_end(double* ms, double* flop, int64_t* launches) {
   g_prof.on = false;
 }
 
-template <int BM, int BN, int WM, int WN, int MODE = 0>
-static void launch(hipStream_t s, ConvK& k) {
-  const int mt = (k.M + BM - 1) / BM, nt = (k.Cout + BN - 1) / BN;
-  k.ntiles_n = nt;
+// open a timed span for one launch when profiling is on (returns the event pair to close it with)
+static std::pair<hipEvent_t, hipEvent_t>* prof_open(hipStream_t s, const ConvK& k, int BM, int BN, int grid, int ksplit) {
   std::pair<hipEvent_t, hipEvent_t>* e = nullptr;
   if (g_prof.on) {
     if (g_prof.used == g_prof.ev.size()) {
@@ -342,13 +519,63 @@ static void launch(hipStream_t s, ConvK& k) {
     const double fl = 2.0 * (double)k.M * (double)k.Cout * (double)(k.KH * k.KW * creal);
     g_prof.flop += fl;
     char buf[160];
-    snprintf(buf, sizeof buf, "M=%7d Cin=%4d Cout=%4d k=%dx%d s=%d d=%d tile=%dx%d grid=%d", k.M, k.C, k.Cout, k.KH, k.KW,
-             k.stride, k.dil, BM, BN, mt * nt);
+    snprintf(buf, sizeof buf, "M=%7d Cin=%4d Cout=%4d k=%dx%d s=%d d=%d tile=%dx%d ksplit=%d grid=%d", k.M, k.C, k.Cout, k.KH,
+             k.KW, k.stride, k.dil, BM, BN, ksplit, grid);
     if (g_prof.desc.size() < g_prof.used) { g_prof.desc.resize(g_prof.used); g_prof.lflop.resize(g_prof.used); }
     g_prof.desc[g_prof.used - 1] = buf;
     g_prof.lflop[g_prof.used - 1] = fl;
     YMK_HIP(hipEventRecord(e->first, s));
   }
+  return e;
+}
+
+template <int TM, int TN, int NW, int PF>
+static void launch_splitk(hipStream_t s, ConvK& k) {
+  const int mt = (k.M + 32 * TM - 1) / (32 * TM), nt = (k.Cout + 32 * TN - 1) / (32 * TN);
+  k.ntiles_n = nt;
+  auto* e = prof_open(s, k, 32 * TM, 32 * TN, mt * nt, NW);
+  hipLaunchKernelGGL((conv_splitk<TM, TN, NW, PF>), dim3(mt * nt), dim3(64 * NW), 0, s, k);
+  if (e) YMK_HIP(hipEventRecord(e->second, s));
+}
+
+// Pick the split-K shape for a launch conv_igemm cannot spread over the chip.  Cost model: a wave issues
+// one 32x32x2 MFMA per 64 cycles, so its time is (its K tiles) x TM x TN x 1024 cycles plus a fixed
+// prologue / reduction / epilogue cost, and the 1024 SIMDs take ceil(waves / 1024) waves each.
+static bool try_splitk(hipStream_t s, ConvK& k) {
+  struct Cand {
+    int tm, tn, nw;
+    void (*fn)(hipStream_t, ConvK&);
+  };
+  static const Cand cands[] = {
+      {2, 2, 4, launch_splitk<2, 2, 4, 2>}, {2, 1, 4, launch_splitk<2, 1, 4, 3>}, {2, 1, 8, launch_splitk<2, 1, 8, 3>},
+      {1, 1, 4, launch_splitk<1, 1, 4, 4>}, {1, 1, 8, launch_splitk<1, 1, 8, 4>},
+  };
+  if (k.in_bytes >= SPLITK_OOB_ROW) return false;  // masked rows must stay out of the descriptor's range
+  const int ktiles = k.Kpad >> 5;
+  const Cand* best = nullptr;
+  double best_cost = 0.0;
+  for (const Cand& c : cands) {
+    const long blocks = (long)((k.M + 32 * c.tm - 1) / (32 * c.tm)) * ((k.Cout + 32 * c.tn - 1) / (32 * c.tn));
+    const long waves = blocks * c.nw;
+    const double per_wave = (double)((ktiles + c.nw - 1) / c.nw) * c.tm * c.tn * 1024.0 + 3000.0 + (c.nw == 8 ? 1800.0 : 1200.0);
+    const double cost = (double)((waves + 1023) / 1024) * per_wave;
+    if (!best || cost < best_cost * 0.97) {  // candidates are listed widest tile first: ties keep the fewer loads
+      best = &c;
+      best_cost = cost;
+    }
+  }
+  const int forced = splitk_forced();
+  if (forced >= 0) best = &cands[forced % (int)(sizeof(cands) / sizeof(cands[0]))];
+  best->fn(s, k);
+  return true;
+}
+
+template <int BM, int BN, int WM, int WN, int MODE = 0>
+static void launch(hipStream_t s, ConvK& k) {
+  const int mt = (k.M + BM - 1) / BM, nt = (k.Cout + BN - 1) / BN;
+  k.ntiles_n = nt;
+  if (MODE == 0 && (mt * nt < SPLITK_MAX_GRID || splitk_forced() >= 0) && !no_splitk() && try_splitk(s, k)) return;
+  auto* e = prof_open(s, k, BM, BN, mt * nt, 1);
   hipLaunchKernelGGL((conv_igemm<BM, BN, WM, WN, MODE>), dim3(mt * nt), dim3(256), 0, s, k);
   if (e) YMK_HIP(hipEventRecord(e->second, s));
 }

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import imaging
-from .geometry import calc_overlap_ratio, is_contained, quad_to_xyxy
+from .geometry import calc_overlap_ratio, containment_matrix, is_contained, quad_to_xyxy
 from .layout_parser import LayoutParser
 from .reading_order import prediction_reading_order
 from .schemas import (
@@ -189,13 +189,16 @@ def filter_ruby(contained_words, element_direction, ruby_threshold):
 def extract_words_within_element(pred_words, element, ignore_ruby=False, ruby_threshold=2.0):
     """Words at least 50 % inside `element`, joined in reading order (:175-217).
     Returns (text or None, direction or None, per-word membership flags)."""
-    inside = []
-    flags = [False] * len(pred_words)
-    for i, word in enumerate(pred_words):
-        word_box = quad_to_xyxy(word.points)
-        if is_contained(element.box, word_box, threshold=0.5):
-            flags[i] = True
-            inside.append(ParagraphSchema(box=word_box, contents=word.content, direction=word.direction, order=0, role=None))
+    word_boxes = [quad_to_xyxy(word.points) for word in pred_words]
+    flags = containment_matrix([element.box], word_boxes, 0.5)[0].tolist()
+    return _words_of_element(pred_words, word_boxes, flags, ignore_ruby, ruby_threshold)
+
+
+def _words_of_element(pred_words, word_boxes, flags, ignore_ruby, ruby_threshold):
+    """Second half of extract_words_within_element, given the element's membership flags (aggregate()
+    computes them for all cells and paragraphs of the page in one containment_matrix call)."""
+    inside = [ParagraphSchema(box=word_boxes[i], contents=pred_words[i].content, direction=pred_words[i].direction,
+                              order=0, role=None) for i in np.flatnonzero(flags).tolist()]
     if not inside:
         return None, None, flags
     dirs = [w.direction for w in inside]
@@ -326,19 +329,20 @@ class DocumentAnalyzer:
     # ---- aggregation (:487-601)
     def aggregate(self, ocr_res, layout_res):
         paragraphs = []
-        used = [False] * len(ocr_res.words)
-        for table in layout_res.tables:
-            for cell in table.cells:
-                words, _, flags = extract_words_within_element(ocr_res.words, cell, ignore_ruby=self.ignore_ruby,
-                                                               ruby_threshold=self.ruby_threshold)
-                cell.contents = "" if words is None else words
-                used = combine_flags(used, flags)
-        for paragraph in layout_res.paragraphs:
-            words, direction, flags = extract_words_within_element(ocr_res.words, paragraph, ignore_ruby=self.ignore_ruby,
-                                                                   ruby_threshold=self.ruby_threshold)
+        cells = [cell for table in layout_res.tables for cell in table.cells]
+        word_boxes = [quad_to_xyxy(word.points) for word in ocr_res.words]
+        # word -> cell / paragraph membership for the whole page at once (same flags as the per-element form)
+        member = containment_matrix([e.box for e in cells] + [p.box for p in layout_res.paragraphs], word_boxes, 0.5)
+        used = np.zeros(len(ocr_res.words), dtype=bool)
+        for cell, flags in zip(cells, member):
+            words, _, _ = _words_of_element(ocr_res.words, word_boxes, flags, self.ignore_ruby, self.ruby_threshold)
+            cell.contents = "" if words is None else words
+            used |= flags
+        for paragraph, flags in zip(layout_res.paragraphs, member[len(cells):]):
+            words, direction, _ = _words_of_element(ocr_res.words, word_boxes, flags, self.ignore_ruby, self.ruby_threshold)
             if words is None:
                 continue
-            used = combine_flags(used, flags)
+            used |= flags
             paragraphs.append(ParagraphSchema(contents=words, box=paragraph.box, direction=direction, order=0,
                                               role=paragraph.role))
         for word, taken in zip(ocr_res.words, used):

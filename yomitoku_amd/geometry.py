@@ -50,6 +50,27 @@ def is_intersected_vertical(rect_a, rect_b):
     return max(0, min(ax2, bx2) - max(ax1, bx1)) != 0
 
 
+def containment_matrix(boxes_a, boxes_b, threshold):
+    """[len(a)][len(b)] bool: is_contained(a, b, threshold) for every pair in one shot.  Same integer
+    truncation and the same float64 quotient as the scalar form, so the flags are identical."""
+    import numpy as np
+
+    if len(boxes_a) == 0 or len(boxes_b) == 0:
+        return np.zeros((len(boxes_a), len(boxes_b)), dtype=bool)
+    raw_b = np.asarray(boxes_b, dtype=np.float64).reshape(-1, 4)
+    a = np.trunc(np.asarray(boxes_a, dtype=np.float64).reshape(-1, 4)).astype(np.int64)
+    b = np.trunc(raw_b).astype(np.int64)
+    w = np.minimum(a[:, None, 2], b[None, :, 2]) - np.maximum(a[:, None, 0], b[None, :, 0])
+    h = np.minimum(a[:, None, 3], b[None, :, 3]) - np.maximum(a[:, None, 1], b[None, :, 1])
+    hit = (w > 0) & (h > 0)
+    area_b = (raw_b[:, 2] - raw_b[:, 0]) * (raw_b[:, 3] - raw_b[:, 1])  # the scalar form divides by the raw extent
+    if np.any(hit & (area_b[None, :] == 0)):
+        raise ZeroDivisionError("division by zero")  # what the scalar form does for a degenerate box
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = (w * h) / area_b[None, :]
+    return hit & (ratio > threshold)
+
+
 def quad_to_xyxy(quad):
     xs = [p[0] for p in quad]
     ys = [p[1] for p in quad]

@@ -182,9 +182,77 @@ def _int_scale(src: int, dst: int) -> int:
     return i if abs(s - i) < 2.220446049250313e-16 else 0
 
 
+_CROP_DTYPE = np.dtype(CropDesc)  # the ctypes layout as a numpy record: descriptors are filled column-wise
+
+
 def plan_crops(shape_hw, quads, img_size=(32, 800), dynamic_width=False, align=8, margin=64) -> List[Optional[CropPlan]]:
     """Integer geometry of every text-line crop (extract_roi_with_perspective, rotate_text_image,
-    calc_resize_without_padding, resize_with[_dynamic]_padding).  None for quads that fail validation."""
+    calc_resize_without_padding, resize_with[_dynamic]_padding).  None for quads that fail validation.
+    All quads of the page at once: one stacked 8 x 8 solve + 3 x 3 inverse (LAPACK per matrix, so the
+    doubles are those of the per-quad form, `_plan_crops_scalar`)."""
+    n = len(quads)
+    plans: List[Optional[CropPlan]] = [None] * n
+    shaped = [i for i, quad in enumerate(quads) if len(quad) == 4 and all(len(p) == 2 for p in quad)]
+    if not shaped:
+        return plans
+    th, tw = int(img_size[0]), int(img_size[1])
+    q = np.array([quads[i] for i in shaped], dtype=np.int64)  # m x 4 x 2, truncated like np.array(quad, dtype=int)
+    h, w = shape_hw
+    bx, by = q[:, :, 0].min(1), q[:, :, 1].min(1)
+    bx2, by2 = q[:, :, 0].max(1), q[:, :, 1].max(1)
+    inside = ~((bx < 0) | (bx2 > w) | (by < 0) | (by2 > h))
+    if not inside.all():
+        shaped = [i for i, ok in zip(shaped, inside.tolist()) if ok]
+        q, bx, by, bx2, by2 = q[inside], bx[inside], by[inside], bx2[inside], by2[inside]
+        if not shaped:
+            return plans
+    m = len(shaped)
+    rel = q - np.stack([bx, by], axis=1)[:, None, :]
+    width = np.sqrt(((rel[:, 0] - rel[:, 1]) ** 2).sum(1).astype(np.float64)).astype(np.int64)
+    height = np.sqrt(((rel[:, 1] - rel[:, 2]) ** 2).sum(1).astype(np.float64)).astype(np.int64)
+    bad = (width <= 0) | (height <= 0)
+    if bad.any():
+        raise ValueError(f"degenerate text quad {quads[shaped[int(np.flatnonzero(bad)[0])]]}")
+    # cv2.getPerspectiveTransform(rel -> [[0,0],[w,0],[w,h],[0,h]]) for every quad
+    x, y = rel[:, :, 0].astype(np.float64), rel[:, :, 1].astype(np.float64)
+    wf, hf = width.astype(np.float64), height.astype(np.float64)
+    zero = np.zeros(m)
+    u, v = np.stack([zero, wf, wf, zero], 1), np.stack([zero, zero, hf, hf], 1)
+    a = np.zeros((m, 8, 8), dtype=np.float64)
+    a[:, :4, 0], a[:, :4, 1], a[:, :4, 2] = x, y, 1.0
+    a[:, 4:, 3], a[:, 4:, 4], a[:, 4:, 5] = x, y, 1.0
+    a[:, :4, 6], a[:, :4, 7] = -x * u, -y * u
+    a[:, 4:, 6], a[:, 4:, 7] = -x * v, -y * v
+    sol = np.linalg.solve(a, np.concatenate([u, v], 1)[:, :, None])[:, :, 0]
+    minv = np.linalg.inv(np.concatenate([sol, np.ones((m, 1))], 1).reshape(m, 3, 3))
+    rot = height > 2 * width
+    rw, rh = np.where(rot, height, width), np.where(rot, width, height)
+    s = np.minimum(np.where(rw > tw, tw / rw, 1.0), np.where(rh > th, th / rh, 1.0))
+    nw = np.maximum(1, (rw * s).astype(np.int64))
+    nh = np.maximum(1, (rh * s).astype(np.int64))
+    canvas = np.minimum(tw, ((nw + margin + align - 1) // align) * align) if dynamic_width else np.full(m, tw)
+
+    def int_scale(src, dst):
+        sc = src / dst
+        r = np.rint(sc)
+        return np.where(np.abs(sc - r) < 2.220446049250313e-16, r, 0).astype(np.int64)
+
+    fx, fy = int_scale(rw, nw), int_scale(rh, nh)
+    fast = (fx != 0) & (fy != 0)
+    rec = np.zeros(m, dtype=_CROP_DTYPE)
+    rec["minv"] = minv.reshape(m, 9)
+    rec["bx"], rec["by"], rec["bw"], rec["bh"] = bx, by, bx2 - bx, by2 - by
+    rec["ww"], rec["wh"], rec["rot"], rec["rw"], rec["rh"], rec["nw"], rec["nh"] = width, height, rot, rw, rh, nw, nh
+    rec["fast_x"], rec["fast_y"] = np.where(fast, fx, 0), np.where(fast, fy, 0)
+    descs = (CropDesc * m).from_buffer(rec)  # views into `rec`; each element keeps the buffer alive
+    for k, (i, cw, cv) in enumerate(zip(shaped, nw.tolist(), canvas.tolist())):
+        plans[i] = CropPlan(index=i, desc=descs[k], content_width=cw, canvas_width=cv)
+    return plans
+
+
+def _plan_crops_scalar(shape_hw, quads, img_size=(32, 800), dynamic_width=False, align=8, margin=64) -> List[Optional[CropPlan]]:
+    """One quad at a time, statement for statement after the reference's helpers; the batched form above
+    is tested against it (tests/test_imaging_host.py)."""
     plans: List[Optional[CropPlan]] = []
     th, tw = int(img_size[0]), int(img_size[1])
     for i, quad in enumerate(quads):

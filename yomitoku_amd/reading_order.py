@@ -9,6 +9,8 @@ Elements are addressed by index; the graph is two adjacency lists.
 
 from __future__ import annotations
 
+import numpy as np
+
 from .geometry import is_intersected_horizontal, is_intersected_vertical
 
 
@@ -47,10 +49,73 @@ def _something_between(g, a, b, axis):
     return False
 
 
+VECTOR_MIN_BOXES = 6  # below this the scalar double loop is cheaper than the numpy set-up
+
+
+def _adjacent_pairs(boxes, axis):
+    """All (i, j), i != j, in row-major order, for which the scalar loop's test
+    `shares(box i, box j) and not _something_between(i, j)` holds - computed with numpy: an n x n
+    share matrix, then the in-between test only for the sharing pairs (P x n).  Returns None when a
+    degenerate box would make the scalar form raise, so that the caller takes that path and raises too."""
+    raw = np.asarray(boxes, dtype=np.float64)
+    t = np.trunc(raw).astype(np.int64)
+    n = len(boxes)
+    if axis == 1:  # is_intersected_vertical: any overlap along x
+        ov = np.minimum(t[:, None, 2], t[None, :, 2]) - np.maximum(t[:, None, 0], t[None, :, 0])
+        share = np.maximum(ov, 0) != 0
+    else:  # is_intersected_horizontal: >= half of the shorter box's height
+        h = t[:, 3] - t[:, 1]
+        if np.any(h == 0):
+            return None
+        ov = np.maximum(0, np.minimum(t[:, None, 3], t[None, :, 3]) - np.maximum(t[:, None, 1], t[None, :, 1]))
+        share = ~((ov / np.minimum(h[:, None], h[None, :])) < 0.5)
+    np.fill_diagonal(share, False)
+    pa, pb = np.nonzero(share)  # row-major: the order the scalar loops visit the pairs in
+    if len(pa) == 0:
+        return []
+    lo, hi = raw[:, axis], raw[:, axis + 2]
+    a_lo, a_hi, b_lo, b_hi = lo[pa, None], hi[pa, None], lo[pb, None], hi[pb, None]
+    s_lo, s_hi = lo[None, :], hi[None, :]
+    gap = ((a_hi < s_lo) & (s_lo < b_lo) & (a_hi < s_hi) & (s_hi < b_lo)) | \
+          ((b_hi < s_lo) & (s_lo < a_lo) & (b_hi < s_hi) & (s_hi < a_lo))
+    gap &= share[pa]  # share is symmetric: third box s overlaps a; its diagonal already excludes s == a
+    gap[np.arange(len(pb)), pb] = False  # s == b
+    keep = ~gap.any(axis=1)
+    return list(zip(pa[keep].tolist(), pb[keep].tolist()))
+
+
 def _build(boxes, direction):
     g = _Graph(boxes)
     n = len(boxes)
-    if direction == "top2bottom":
+    pairs = None
+    if n >= VECTOR_MIN_BOXES and direction in ("top2bottom", "right2left", "left2right"):
+        pairs = _adjacent_pairs(boxes, 1 if direction == "top2bottom" else 0)
+    if pairs is not None:
+        if direction == "top2bottom":
+            for i, j in pairs:
+                if boxes[i][1] < boxes[j][1]:
+                    g.link(i, j)
+                else:
+                    g.link(j, i)
+            for i in range(n):
+                g.distance[i] = boxes[i][0] + boxes[i][1]
+            sib_key = 0
+        else:
+            max_x = max(b[2] for b in boxes)
+            for i, j in pairs:
+                ti, tj = boxes[i][2], boxes[j][2]
+                if direction == "right2left":
+                    first, second = (j, i) if ti < tj else (i, j)
+                else:
+                    first, second = (j, i) if tj < ti else (i, j)
+                g.link(first, second)
+            for i in range(n):
+                if direction == "right2left":
+                    g.distance[i] = (max_x - boxes[i][2]) + boxes[i][1]
+                else:
+                    g.distance[i] = boxes[i][0] * 1 + boxes[i][1] * 5
+            sib_key = 1
+    elif direction == "top2bottom":
         for i in range(n):
             for j in range(n):
                 if i == j:
