@@ -34,13 +34,17 @@ def test_prob_map_matches_oracle(dev, nets, shape):
 
 
 def test_batch_consistency(dev, nets):
-    """A page's map does not depend on its batch mates (pages shard independently)."""
+    """A page's map does not depend on its batch mates (pages shard independently).  The
+    GEMM shape picks the kernel (conv_igemm, or split-K for grid-starved launches), so the K summation
+    order - not the data - may differ between batch sizes: equal to fp32 rounding, and bit-equal for
+    a repeated call on the same shape."""
     _, net = nets
     x = torch.randn(3, 3, 96, 128, generator=torch.Generator().manual_seed(5)).to(dev)
     full = net(x)["binary"]
+    assert torch.equal(net(x)["binary"], full)
     for i in range(3):
         single = net(x[i : i + 1])["binary"]
-        assert torch.equal(single[0], full[i])
+        assert (single[0] - full[i]).abs().max().item() < 1e-5
 
 
 def test_golden_fixture(dev, nets):
