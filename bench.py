@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the MI355X DocumentAnalyzer hot path (contract: task prompt / DESIGN.md §8).
 
-    python bench.py --gpus N --steps K --warmup W [--workload analyzer|detector] [--pages 16] [--workers 4]
+    python bench.py --gpus N --steps K --warmup W [--workload analyzer|detector] [--pages 64] [--procs 4] [--workers 2]
 
 One rank per GPU (torchrun env).  A "step" is one pass of the hot path over one batch of synthetic
 1600x1200 pages that are already resident in HBM (uint8 BGR, as `cv2.imread` would hand them over).
@@ -12,8 +12,9 @@ and, at N=1, the CPU baseline (oracle restatement of the reference's PyTorch-CPU
 workload analyzer (default; BASELINE.json configs[3], `--lite` model set): DBNet text detector,
   PARSeq tiny-dynw recogniser (dynamic_width + batch_bucketing), RT-DETRv2 layout parser, RT-DETRv2
   table-structure recogniser, host post-processing and aggregation.  Every page goes through
-  `DocumentAnalyzer.__call__` on its own, as in the reference (cli/main.py:116-120); `--workers`
-  pages are in flight per GPU (yomitoku_amd/parallel.py).  Weights are seeded random draws (no
+  `DocumentAnalyzer.__call__` on its own, as in the reference (cli/main.py:116-120); `--procs` processes per
+  GPU x `--workers` pages in flight each (yomitoku_amd/parallel.py: the host half of a page is Python, one GIL
+  per process).  Weights are seeded random draws (no
   network) which detect noise, so the DISCRETE hand-overs between stages use the page generator's
   ground truth - the recogniser gets the true text-line quads, the table recogniser the true table
   boxes, the aggregation the true paragraph boxes - while every network and every pre/post stage
@@ -174,6 +175,33 @@ def cpu_analyzer_page(sds, page: Page, charset):
     op.tables(sds["tab"], page.img, page.tables)
 
 
+def _helper_init(local_rank, sds, shares, workers, index):
+    """One helper process of a rank (yomitoku_amd/parallel.py PageProcesses): same GPU, own HIP context and
+    analyzer replicas built from the rank's (shared-memory) checkpoints, own pages resident in HBM."""
+    from yomitoku_amd.parallel import PageParallel
+
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    pages = make_pages(shares[index], device)
+    pool = PageParallel(lambda i: build_analyzer(device, sds), n_workers=workers)
+    pool.map(pages[:workers])  # first-call allocations happen before the parent starts its clock
+    torch.cuda.synchronize()
+
+    def step(_payload):
+        pool.map(pages)
+        torch.cuda.synchronize()
+        return len(pages)
+
+    return step
+
+
+def make_pages(seeds, device):
+    from concurrent.futures import ThreadPoolExecutor as _TPE
+
+    with _TPE(max_workers=8) as ex:  # numpy's generators release the GIL: 64 pages in ~2 s instead of ~11 s
+        return list(ex.map(lambda i: Page(i, device), seeds))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,7 +209,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="analyzer", choices=["analyzer", "detector"])
     ap.add_argument("--pages", type=int, default=64, help="pages per step per GPU (BASELINE.json configs[3]: 64)")
-    ap.add_argument("--workers", type=int, default=8, help="pages in flight per GPU (analyzer workload)")
+    ap.add_argument("--procs", type=int, default=4, help="processes per GPU (analyzer workload): each has its own interpreter/GIL")
+    ap.add_argument("--workers", type=int, default=2, help="pages in flight per process (analyzer workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -207,21 +236,36 @@ def main():
     # ---- synthetic pages of this rank, resident in HBM before the clock starts
     if args.workload == "detector":
         args.pages = min(args.pages, 8)
-    from concurrent.futures import ThreadPoolExecutor as _TPE
-
-    with _TPE(max_workers=8) as _ex:  # numpy's generators release the GIL: 64 pages in ~2 s instead of ~11 s
-        pages = list(_ex.map(lambda i: Page(1000 * rank + i, device), range(args.pages)))
+    seeds = [1000 * rank + i for i in range(args.pages)]
+    n_procs = max(1, args.procs) if args.workload == "analyzer" else 1
+    shares = [seeds[i::n_procs] for i in range(n_procs)]  # pages of this rank, dealt to its processes
+    pages = make_pages(shares[0], device)
     extra = {}
+    helpers = None
     if args.workload == "analyzer":
+        from yomitoku_amd.parallel import PageProcesses
+
+        if n_procs > 1:
+            for sd in sds.values():
+                for t in sd.values():
+                    t.share_memory_()
+            helpers = PageProcesses(_helper_init, (local_rank, sds, shares, args.workers), n_procs=n_procs - 1, first_index=1)
         pool = PageParallel(lambda i: build_analyzer(device, sds), n_workers=args.workers)
 
-        def step():
-            return pool.map(pages)[-1]
+        def step():  # every process of the rank walks its share of the rank's pages; the step ends when all have
+            if helpers:
+                helpers.start([None] * len(helpers))
+            out = pool.map(pages)[-1]
+            torch.cuda.synchronize()
+            if helpers:
+                assert sum(helpers.finish()) + len(pages) == args.pages
+            return out
 
         metric = "pages/sec (DocumentAnalyzer @1600x1200, lite model set)"
         workload = (f"Full DocumentAnalyzer per page (BASELINE.json configs[3]): DBNet dbnetv2_1 + PARSeq parseq-tiny-dynw-v4 "
                     f"(dynamic_width, batch_bucketing) + RT-DETRv2 layout + RT-DETRv2 table structure + host post-processing "
-                    f"and aggregation; {args.pages} synthetic 1600x1200 pages per step per GPU, {args.workers} pages in flight; "
+                    f"and aggregation; {args.pages} synthetic 1600x1200 pages per step per GPU, dealt to {n_procs} process(es) x "
+                    f"{args.workers} pages in flight each; "
                     f"stage hand-overs use ground truth ({np.mean([len(p.quads) for p in pages]):.0f} text lines, "
                     f"{np.mean([len(p.tables) for p in pages]):.1f} tables, {np.mean([len(p.paragraphs) for p in pages]):.0f} "
                     f"paragraphs per page) because seeded random weights detect noise")
@@ -256,6 +300,9 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     assert out is not None
+
+    if helpers:
+        helpers.close()
 
     # ---- roofline leg: per-launch HIP events around the conv kernel.  The event bookkeeping is
     # single-threaded, so this pass walks the pages serially with ONE analyzer and ONE worker thread.
@@ -346,7 +393,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": workload, "pages_per_step_per_gpu": args.pages, "parallelism": f"page-sharded x{world}",
+            "config": {"workload": workload, "pages_per_step_per_gpu": args.pages,
+                       "parallelism": f"page-sharded x{world} GPU(s), {n_procs} process(es) x {args.workers} pages in flight per GPU",
                        "checkpoints": "seeded synthetic (no network)", **extra},
             "roofline": roof,
             "cpu_baseline": cpu,

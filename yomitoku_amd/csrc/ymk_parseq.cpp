@@ -304,6 +304,7 @@ class ParseqModel : public Model {
       for (long spin = 0;; ++spin) {
         const int v = __atomic_load_n(&host_flags_[i], __ATOMIC_ACQUIRE);
         if (v != 0) return v - 1;
+        __builtin_ia32_pause();
         if ((spin & 0xFFFF) == 0xFFFF) {  // the step may have faulted: do not spin forever
           hipError_t e = hipStreamQuery(s);
           if (e != hipSuccess && e != hipErrorNotReady) YMK_HIP(e);
