@@ -308,10 +308,107 @@ def pin_aggregate():
     print(f"[aggregate] wrote {len(cases)} cases; paragraphs in case 0: {len(cases[0]['output']['paragraphs'])}")
 
 
+def _ref_functions(relpath, names, env):
+    """Compile the named top-level functions of a reference file - its own code, lifted by ast so the module's
+    heavy imports (cv2, onnx, configs ...) never run - into `env` (the reference's utils.misc helpers)."""
+    import ast
+
+    from ._refstubs import REF_SRC
+
+    path = os.path.join(REF_SRC, "yomitoku", relpath)
+    tree = ast.parse(open(path, encoding="utf-8").read())
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert {n.name for n in body} == set(names), (relpath, names)
+    ns = dict(env)
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def pin_filters():
+    """Layout / table box filters and the RT-DETR post-processor: the reference's own functions on seeded
+    random detections -> tests/golden/filters.json."""
+    import copy
+    import json
+    import sys
+    import types
+
+    import torch
+
+    misc = ref_import("yomitoku.utils.misc")
+    env = {k: getattr(misc, k) for k in ("is_contained", "calc_intersection", "filter_by_flag")}
+    within, across = _ref_functions("layout_parser.py", ["filter_contained_rectangles_within_category",
+                                                         "filter_contained_rectangles_across_categories"], env)
+    cells_fn, span_fn = _ref_functions("table_structure_recognizer.py", ["extract_cells", "filter_contained_cells_within_spancell"], env)
+    rng = np.random.default_rng(4242)
+
+    def elements(n, nest=0.4):
+        out = []
+        for b in _random_layout(rng, n):
+            out.append({"box": b, "score": float(rng.random()), "role": None})
+            if rng.random() < nest:  # a box nested in / nearly equal to the previous one
+                d = rng.integers(0, 12, size=4)
+                out.append({"box": [int(b[0] + d[0]), int(b[1] + d[1]), int(b[2] - d[2]), int(b[3] - d[3])], "score": float(rng.random()),
+                            "role": None})
+        return [e for e in out if e["box"][2] > e["box"][0] and e["box"][3] > e["box"][1]]
+
+    layout_cases = []
+    for _ in range(60):
+        cat = {"paragraphs": elements(int(rng.integers(0, 14))), "tables": elements(int(rng.integers(0, 4)), 0.2),
+               "figures": elements(int(rng.integers(0, 4)), 0.2)}
+        inp = copy.deepcopy(cat)
+        a = within(copy.deepcopy(cat))
+        b = across(copy.deepcopy(a), "tables", "paragraphs")
+        c = across(copy.deepcopy(b), "figures", "paragraphs")
+        layout_cases.append({"input": inp, "within": a, "after_tables": b, "after_figures": c})
+    table_cases = []
+    for _ in range(60):
+        x1, y1 = int(rng.integers(0, 300)), int(rng.integers(0, 300))
+        w, h = int(rng.integers(200, 900)), int(rng.integers(120, 600))
+        nr, nc = int(rng.integers(1, 8)), int(rng.integers(1, 7))
+        ys = np.sort(rng.integers(y1, y1 + h, size=nr + 1))
+        xs = np.sort(rng.integers(x1, x1 + w, size=nc + 1))
+        rows = [[x1, int(ys[i]) - int(rng.integers(0, 4)), x1 + w, int(ys[i + 1]) + int(rng.integers(0, 4))] for i in range(nr)]
+        cols = [[int(xs[j]) - int(rng.integers(0, 4)), y1, int(xs[j + 1]) + int(rng.integers(0, 4)), y1 + h] for j in range(nc)]
+        spans = []
+        for _s in range(int(rng.integers(0, 3))):
+            i0, j0 = int(rng.integers(0, nr)), int(rng.integers(0, nc))
+            i1, j1 = int(rng.integers(i0, nr)), int(rng.integers(j0, nc))
+            spans.append([int(xs[j0]) - 2, int(ys[i0]) - 2, int(xs[j1 + 1]) + 2, int(ys[i1 + 1]) + 2])
+        cells = cells_fn(rows, cols)
+        merged = span_fn(copy.deepcopy(cells), spans)
+        table_cases.append({"rows": rows, "cols": cols, "spans": spans, "cells": cells, "merged": merged})
+    # RT-DETR post-processor (torchvision.ops.box_convert is the only torchvision call: cxcywh -> xyxy)
+    tv = sys.modules["torchvision"]
+    if not hasattr(tv, "ops"):
+        def box_convert(boxes, in_fmt, out_fmt):
+            assert (in_fmt, out_fmt) == ("cxcywh", "xyxy")
+            cx, cy, w, h = boxes.unbind(-1)
+            return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], dim=-1)
+
+        tv.ops = types.SimpleNamespace(box_convert=box_convert)
+    pp = ref_import("yomitoku.postprocessor.rtdetr_postprocessor")
+    post_cases = []
+    g = torch.Generator().manual_seed(99)
+    for nc, thr in ((6, 0.5), (3, 0.4), (6, 0.3)):
+        post = pp.RTDETRPostProcessor(num_classes=nc, num_top_queries=300)
+        logits = torch.randn(1, 300, nc, generator=g) * 2.0 - 4.0
+        boxes = torch.rand(1, 300, 4, generator=g) * torch.tensor([1.0, 1.0, 0.6, 0.6]) + torch.tensor([0.0, 0.0, 0.02, 0.02])
+        size = (int(torch.randint(300, 1700, (1,), generator=g)), int(torch.randint(300, 1700, (1,), generator=g)))  # (w, h)
+        res = post({"pred_logits": logits.clone(), "pred_boxes": boxes.clone()}, torch.tensor([size]), thr)[0]
+        post_cases.append({"num_classes": nc, "threshold": thr, "size_wh": list(size), "logits": logits[0].tolist(),
+                           "boxes": boxes[0].tolist(), "labels": res["labels"].tolist(), "out_boxes": res["boxes"].tolist(),
+                           "scores": res["scores"].tolist()})
+    with open(os.path.join(GOLDEN, "filters.json"), "w") as f:
+        json.dump({"layout": layout_cases, "table": table_cases, "post": post_cases}, f)
+    print(f"[filters] wrote {len(layout_cases)} layout, {len(table_cases)} table, {len(post_cases)} post-processor cases; "
+          f"kept detections: {[len(c['labels']) for c in post_cases]}")
+
+
 def main(argv):
     what = argv[1] if len(argv) > 1 else "all"
     os.makedirs(GOLDEN, exist_ok=True)
-    todo = {"dbnet": pin_dbnet, "parseq": pin_parseq, "rtdetr": pin_rtdetr, "host": pin_host_logic, "aggregate": pin_aggregate}
+    todo = {"dbnet": pin_dbnet, "parseq": pin_parseq, "rtdetr": pin_rtdetr, "host": pin_host_logic, "aggregate": pin_aggregate,
+            "filters": pin_filters}
     for k, fn in todo.items():
         if what in (k, "all"):
             fn()
