@@ -92,6 +92,15 @@ int ymk_pil_resize_to_chw(const unsigned char* page_dev, int page_w, int x0, int
                           int oh, int ow, float* x_dev, void* stream);
 int ymk_crop_batch(const unsigned char* page_dev, int page_h, int page_w, const void* descs_dev, int n, int max_warp_w,
                    int max_warp_h, unsigned char* scratch_dev, float* out_dev, int batch_w, int out_h, void* stream);
+/* ymk_crop_batch_levels: the same with `source_downscale` (data/dataset.py:26-41,64-79): descriptor.level picks the
+ *   pyramid level a crop is cut from.  level_pages: HOST array of n_levels (<= 4) device pointers, level 0 = the page;
+ *   a NULL entry (level not built because no quad uses it) aliases the page.
+ * ymk_halve_u8c3: one pyramid step, cv2.resize(img, None, fx=0.5, fy=0.5, INTER_AREA) on uint8 [h][w][3];
+ *   dst_h / dst_w = round-half-even(h / 2), (w / 2) as cv2 computes them. */
+int ymk_crop_batch_levels(const unsigned char* const* level_pages, const int* level_h, const int* level_w, int n_levels,
+                          const void* descs_dev, int n, int max_warp_w, int max_warp_h, unsigned char* scratch_dev,
+                          float* out_dev, int batch_w, int out_h, void* stream);
+int ymk_halve_u8c3(const unsigned char* src_dev, int h, int w, unsigned char* dst_dev, int dst_h, int dst_w, void* stream);
 int ymk_crop_desc_size(void);
 
 /* ---- DB post-processing on the host (replaces DBnetPostProcessor.boxes_from_bitmap,

@@ -107,6 +107,32 @@ def resize_area(img: np.ndarray, dsize_wh) -> np.ndarray:
     return out.reshape((dh, dw) + img.shape[2:])
 
 
+def resize_half(img: np.ndarray) -> np.ndarray:
+    """cv2.resize(img, None, fx=0.5, fy=0.5, interpolation=cv2.INTER_AREA) on uint8 HxWx3 (data/dataset.py:76-78).
+    dsize = saturate_cast<int>(size * 0.5) (round half to even); the scale stays exactly 2, so this is
+    ResizeAreaFast: full 2x2 cells round as (s + 2) >> 2, cells cut by the right / bottom edge average the pixels
+    they have (saturate_cast<uchar>((float)sum / count)), cells starting past the edge are 0.
+    OpenCV 4.x imgproc/resize.cpp, restated from the published source; parity unpinned (cv2 is not installed)."""
+    assert img.dtype == np.uint8 and img.ndim == 3
+    sh, sw = img.shape[:2]
+    dh, dw = int(round(sh * 0.5)), int(round(sw * 0.5))
+    out = np.zeros((dh, dw, img.shape[2]), dtype=np.uint8)
+    fh, fw = min(dh, sh // 2), min(dw, sw // 2)  # rows / columns of complete cells
+    s = img[: 2 * fh, : 2 * fw].astype(np.int32).reshape(fh, 2, fw, 2, -1).sum(axis=(1, 3))
+    out[:fh, :fw] = ((s + 2) >> 2).astype(np.uint8)
+    for dy in range(dh):
+        for dx in range(dw):
+            if dy < fh and dx < fw:
+                continue
+            sy0, sx0 = 2 * dy, 2 * dx
+            if sy0 >= sh or sx0 >= sw:
+                continue
+            cell = img[sy0 : min(sy0 + 2, sh), sx0 : min(sx0 + 2, sw)].astype(np.int32).reshape(-1, img.shape[2])
+            val = np.rint(cell.sum(0).astype(np.float32) / np.float32(cell.shape[0]))
+            out[dy, dx] = np.clip(val, 0, 255).astype(np.uint8)
+    return out
+
+
 # ------------------------------------------------------------------------------------------
 # cv2.findContours(RETR_LIST): Suzuki & Abe border following, 8-connected foreground
 _NB = [(0, 1), (1, 1), (1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1)]  # clockwise from east (dy, dx)

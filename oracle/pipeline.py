@@ -61,10 +61,23 @@ def make_batches(widths_canvas, order, dynamic_width, width_budget, max_batch_si
 
 
 def recognize(sd, ocfg, img_bgr, quads, charset, dynamic_width=False, batch_bucketing=False, width_budget=None,
-              max_batch_size=None, batch_size=128, forward=None):
-    """-> (contents, scores, directions) in detection order."""
-    rgb = img_bgr[:, :, ::-1]
-    crops = [preprocess.parseq_crop(rgb, q, ocfg.img_size, dynamic_width) for q in quads]
+              max_batch_size=None, batch_size=128, forward=None, source_downscale=False, orientation_fallback=False,
+              fallback_thresh=0.75):
+    """-> (contents, scores, directions) in detection order (TextRecognizer.__call__, text_recognizer.py:352-399, with
+    ParseqDataset's source_downscale routing, data/dataset.py:64-103, and the 180-degree retry, :319-350)."""
+    levels = {0: img_bgr[:, :, ::-1]}
+    quad_levels = np.zeros(len(quads), dtype=int)
+    if source_downscale and len(quads) > 0:
+        quad_levels = preprocess.calc_source_levels(quads, ocfg.img_size[0])
+        level_img = np.ascontiguousarray(img_bgr)
+        for k in range(1, int(quad_levels.max()) + 1):
+            level_img = cvlike.resize_half(level_img)
+            if (quad_levels >= k).any():
+                levels[k] = level_img[:, :, ::-1]
+    crops = []
+    for q, k in zip(quads, quad_levels):
+        qq = (np.asarray(q, dtype=np.float32) / (2.0 ** int(k))).tolist() if k > 0 else q
+        crops.append(preprocess.parseq_crop(levels.get(int(k), levels[0]), qq, ocfg.img_size, dynamic_width, with_roi=True))
     data = [c for c in crops if c is not None]
     tensors = [c[0] for c in data]
     widths = [c[1] for c in data]
@@ -94,6 +107,23 @@ def recognize(sd, ocfg, img_bgr, quads, charset, dynamic_width=False, batch_buck
     if order is not None:
         inv = np.argsort(order)
         preds, scores, directions = [preds[i] for i in inv], [scores[i] for i in inv], [directions[i] for i in inv]
+    if orientation_fallback:
+        retry = [i for i, s_ in enumerate(scores) if s_ < fallback_thresh]
+        if retry:
+            flipped = [preprocess.canvas_tensor(np.ascontiguousarray(np.rot90(data[i][2], 2)), ocfg.img_size)[0] for i in retry]
+            r_preds, r_scores, r_dirs = [], [], []
+            for s0 in range(0, len(retry), batch_size):
+                p = forward(torch.stack(flipped[s0 : s0 + batch_size], 0)).softmax(-1)
+                ids, sc = tokenizer_decode(p)
+                r_preds += [unicodedata.normalize("NFKC", "".join(itos[i] for i in row)) for row in ids]
+                r_scores += sc
+                for i in retry[s0 : s0 + batch_size]:
+                    point = np.array(quads[i])
+                    w, h = np.linalg.norm(point[0] - point[1]), np.linalg.norm(point[1] - point[2])
+                    r_dirs.append("vertical" if h > w * 2 else "horizontal")
+            for j, i in enumerate(retry):
+                if r_scores[j] > scores[i] and r_scores[j] >= fallback_thresh:
+                    preds[i], scores[i], directions[i] = r_preds[j], r_scores[j], r_dirs[j]
     return preds, scores, directions
 
 

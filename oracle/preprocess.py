@@ -91,9 +91,29 @@ def calc_resize_without_padding(img, target_size):
     return max(1, int(h * s)), max(1, int(w * s))
 
 
-def parseq_crop(img_rgb, quad, img_size=(32, 800), dynamic_width=False, align=8, margin=64):
+def calc_source_levels(quads, target_height, max_level=3):
+    """data/dataset.py:16-41: pyramid level per quad, clip(floor(log2(short side / target height)), 0, max_level)."""
+    if len(quads) == 0:
+        return np.zeros(0, dtype=int)
+    q = np.asarray(quads, dtype=np.float32).reshape(-1, 4, 2)
+    short = np.maximum(1.0, np.minimum(np.linalg.norm(q[:, 0] - q[:, 1], axis=1), np.linalg.norm(q[:, 1] - q[:, 2], axis=1)))
+    return np.clip(np.floor(np.log2(short / float(target_height))).astype(int), 0, max_level)
+
+
+def canvas_tensor(roi, img_size, dynamic_width=False, align=8, margin=64):
+    """resize_with[_dynamic]_padding (data/functions.py:379-439) + ToTensor + Normalize(0.5, 0.5) of a (rotated) ROI."""
+    new_h, new_w = calc_resize_without_padding(roi, img_size)
+    resized = cvlike.resize_area(roi, (new_w, new_h)) if (new_h, new_w) != roi.shape[:2] else roi.copy()
+    canvas_w = min(img_size[1], ((new_w + margin + align - 1) // align) * align) if dynamic_width else img_size[1]
+    canvas = np.zeros((img_size[0], canvas_w, 3), dtype=np.uint8)
+    canvas[:new_h, :new_w, :] = resized
+    t = torch.from_numpy(canvas).permute(2, 0, 1).to(torch.float32).div(255)
+    return (t - 0.5) / 0.5, new_w
+
+
+def parseq_crop(img_rgb, quad, img_size=(32, 800), dynamic_width=False, align=8, margin=64, with_roi=False):
     """ParseqDataset._preprocess_on (data/dataset.py:105-124) + transform (:55-62):
-    -> (tensor 3 x 32 x canvas_w in [-1, 1], content_width) or None."""
+    -> (tensor 3 x 32 x canvas_w in [-1, 1], content_width[, rotated roi]) or None."""
     if validate_quads(img_rgb, quad) is None:
         return None
     roi = extract_roi_with_perspective(img_rgb, quad)
@@ -107,4 +127,4 @@ def parseq_crop(img_rgb, quad, img_size=(32, 800), dynamic_width=False, align=8,
     canvas[:new_h, :new_w, :] = resized
     t = torch.from_numpy(canvas).permute(2, 0, 1).to(torch.float32).div(255)
     t = (t - 0.5) / 0.5
-    return t, new_w
+    return (t, new_w, roi) if with_roi else (t, new_w)

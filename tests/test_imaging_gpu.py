@@ -93,3 +93,78 @@ def test_invalid_quads_are_dropped():
     plans = imaging.plan_crops((100, 200), [[[0, 0], [10, 0], [10, 10]], [[0, 0], [300, 0], [300, 10], [0, 10]],
                                             [[5, 5], [50, 5], [50, 20], [5, 20]]], (32, 800), True)
     assert plans[0] is None and plans[1] is None and plans[2] is not None
+
+
+@pytest.mark.parametrize("h,w", [(1000, 1400), (999, 1399), (501, 303), (4, 6)])
+def test_pyramid_halving_matches_oracle(dev, h, w):
+    """source_downscale pyramid step (data/dataset.py:73-79): fast 2x2 cells, partial cells on odd sizes."""
+    from oracle.cvlike import resize_half
+    from yomitoku_amd import imaging
+
+    img = np.ascontiguousarray(_page(h * 3 + w, max(h, 600), max(w, 600))[:h, :w])
+    levels = imaging.build_pyramid(imaging.page_to_device(img, dev), [2])
+    assert len(levels) == 3 and np.array_equal(levels[1].cpu().numpy(), resize_half(img))
+    want = resize_half(resize_half(img))
+    assert levels[2].shape == want.shape
+    assert np.array_equal(levels[2].cpu().numpy(), want)
+
+
+def _big_quads(rng, h, w):
+    """Text boxes whose short side lands on pyramid levels 0..3 (32 px canvas: 64 / 128 / 256 px thresholds)."""
+    quads = []
+    for short, long_ in ((24, 180), (40, 260), (70, 300), (100, 420), (140, 520), (200, 640), (270, 900), (300, 420)):
+        for _ in range(3):
+            x, y = int(rng.integers(4, w - long_ - 8)), int(rng.integers(4, h - short - 8))
+            d = rng.integers(-3, 4, size=(4, 2))
+            quads.append([[x + int(d[0, 0]), y + int(d[0, 1])], [x + long_ + int(d[1, 0]), y + int(d[1, 1])],
+                          [x + long_ + int(d[2, 0]), y + short + int(d[2, 1])], [x + int(d[3, 0]), y + short + int(d[3, 1])]])
+    quads.append([[30, 40], [130, 40], [130, 700], [30, 700]])  # vertical line: rotated crop from level 1
+    return quads
+
+
+@pytest.mark.parametrize("shape", [(1000, 1400), (999, 1399)])
+def test_source_downscale_crops_match_oracle(dev, shape):
+    from oracle import cvlike
+    from oracle.preprocess import calc_source_levels, parseq_crop
+    from yomitoku_amd import imaging
+
+    h, w = shape
+    img = np.ascontiguousarray(_page(23, 1000, 1400)[:h, :w])
+    quads = _big_quads(np.random.default_rng(9), h, w)
+    page = imaging.page_to_device(img, dev)
+    plans, levels = imaging.plan_crops_pyramid(img.shape[:2], quads, (32, 800), True, source_downscale=True)
+    assert levels.tolist() == calc_source_levels(quads, 32).tolist() and set(levels.tolist()) == {0, 1, 2, 3}
+    pyramid = imaging.build_pyramid(page, levels)
+    ref_levels = {0: img}
+    for k in range(1, 4):
+        ref_levels[k] = cvlike.resize_half(ref_levels[k - 1])
+    assert all(p is not None for p in plans)
+    for start in range(0, len(plans), 6):
+        chunk = plans[start : start + 6]
+        batch = imaging.build_crop_batch(pyramid, chunk, 32, None).cpu()
+        for slot, plan in enumerate(chunk):
+            k = int(levels[plan.index])
+            assert plan.desc.level == k
+            q = quads[plan.index] if k == 0 else (np.asarray(quads[plan.index], dtype=np.float32) / (2.0 ** k)).tolist()
+            ref, cw = parseq_crop(ref_levels[k][:, :, ::-1], q, (32, 800), True)
+            assert cw == plan.content_width and ref.shape[-1] == plan.canvas_width
+            got = batch[slot, :, :, : ref.shape[-1]]
+            assert torch.equal(got, ref), f"crop {plan.index} (level {k}) differs: {(got - ref).abs().max().item()}"
+
+
+def test_flipped_crops_match_oracle(dev):
+    """Orientation-fallback retry input: the (rotated) ROI turned by 180 degrees, fixed 800 px canvas."""
+    from oracle.preprocess import canvas_tensor, parseq_crop
+    from yomitoku_amd import imaging
+
+    rng = np.random.default_rng(6)
+    img = _page(12, 1000, 1400)
+    quads = _quads(rng, 1000, 1400, 14) + [[[30, 40], [70, 40], [70, 400], [30, 400]]]
+    page = imaging.page_to_device(img, dev)
+    plans = imaging.plan_crops(img.shape[:2], quads, (32, 800), True)
+    batch = imaging.build_crop_batch(page, plans, 32, 800, flip=True).cpu()
+    rgb = img[:, :, ::-1]
+    for slot, plan in enumerate(plans):
+        _, _, roi = parseq_crop(rgb, quads[plan.index], (32, 800), True, with_roi=True)
+        ref, _ = canvas_tensor(np.ascontiguousarray(np.rot90(roi, 2)), (32, 800))
+        assert torch.equal(batch[slot], ref), f"flipped crop {plan.index} differs"

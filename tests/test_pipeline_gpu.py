@@ -66,6 +66,42 @@ def test_text_recognizer_lite_config(dev, page):
     assert res.points == quads
 
 
+def test_text_recognizer_source_downscale_and_orientation_fallback(dev, page):
+    """The two optional recogniser paths (`--lite` sets source_downscale; text_recognizer.py:319-350 retries
+    low-score lines turned by 180 degrees): same contents / scores as the oracle chain."""
+    from oracle import pipeline as op
+    from oracle.parseq import PRESETS, make_cfg
+    from yomitoku_amd.text_recognizer import TextRecognizer
+    from yomitoku_amd.utils.synth import parseq_state_dict
+
+    img, quads, _ = page
+    quads = quads[:12] + [[[40, 60], [560, 60], [560, 200], [40, 200]], [[600, 300], [1300, 300], [1300, 600], [600, 600]],
+                          [[100, 650], [420, 650], [420, 730], [100, 730]]]  # short sides 140 / 300 / 80: levels 2 / 3 / 1
+    sd = parseq_state_dict(1235, eos_bias=6.0)
+    ocfg = make_cfg(**PRESETS["parseq-tiny-dynw-v4"])
+    kw = dict(dynamic_width=True, batch_bucketing=True, width_budget=8000, max_batch_size=64, batch_size=10)
+    plain = TextRecognizer(model_name="parseq-tiny-dynw-v4", from_pretrained=False, device="cuda:0", dynamic_width=True,
+                           batch_bucketing=True, source_downscale=True)
+    plain.model.load_state_dict(sd)
+    base, _ = plain(img, quads)
+    contents, scores, directions = op.recognize(sd, ocfg, img, quads, plain.charset, source_downscale=True, **kw)
+    assert base.contents == contents and base.directions == directions
+    assert np.allclose(base.scores, scores, rtol=1e-3, atol=1e-6)
+    thresh = float(np.sort(base.scores)[len(base.scores) // 2]) * 1.0001  # about half of the lines get the retry
+    rec = TextRecognizer(model_name="parseq-tiny-dynw-v4", from_pretrained=False, device="cuda:0", dynamic_width=True,
+                         batch_bucketing=True, source_downscale=True, rec_orientation_fallback=True,
+                         rec_orientation_fallback_thresh=thresh)
+    rec.model.load_state_dict(sd)
+    res, _ = rec(img, quads)
+    contents, scores, directions = op.recognize(sd, ocfg, img, quads, rec.charset, source_downscale=True,
+                                                orientation_fallback=True, fallback_thresh=thresh, **kw)
+    assert res.contents == contents and res.directions == directions
+    assert np.allclose(res.scores, scores, rtol=1e-3, atol=1e-6)
+    assert res.points == quads
+    replaced = sum(a != b for a, b in zip(res.scores, base.scores))
+    print("orientation fallback replaced", replaced, "of", len(quads))
+
+
 def test_layout_and_table_stages(dev, page):
     from oracle import pipeline as op
     from oracle.rtdetr import rtdetr_forward

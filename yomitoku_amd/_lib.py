@@ -40,6 +40,12 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p],
     ),
+    "ymk_crop_batch_levels": (
+        c_int,
+        [c_void_p, POINTER(c_int), POINTER(c_int), c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+         c_void_p],
+    ),
+    "ymk_halve_u8c3": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "ymk_crop_desc_size": (c_int, []),
     "ymk_db_postprocess": (
         c_int,

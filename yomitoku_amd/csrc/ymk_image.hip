@@ -204,13 +204,22 @@ struct CropDesc {
   int fast_x, fast_y; // both non-zero: exact integer factors -> cv2's ResizeAreaFast path
   long long warp_off; // offset (bytes) of this crop's warped pixels in the scratch buffer ([wh][ww][3] RGB)
   int slot;           // row of the batch tensor
+  int flip;           // 1: cv2.rotate(ROTATE_180) of the (rotated) crop before the resize - orientation fallback retry
+  int level;          // pyramid level the crop is cut from (source_downscale, data/dataset.py:26-41,64-79); 0 = the page
+};
+
+constexpr int MAX_LEVELS = 4;  // _calc_source_levels clips to max_level = 3
+struct PageLevels {
+  const unsigned char* p[MAX_LEVELS];
+  int H[MAX_LEVELS], W[MAX_LEVELS];
 };
 
 // cv2.warpPerspective(INTER_LINEAR, BORDER_CONSTANT 0) on uint8: source coordinates quantised to 1/32 px,
 // bilinear weights as 15-bit integers summing to 32768.
-__global__ void k_warp_quads(const unsigned char* __restrict__ page, int H, int W, const CropDesc* __restrict__ descs,
-                             unsigned char* __restrict__ scratch) {
+__global__ void k_warp_quads(PageLevels lv, const CropDesc* __restrict__ descs, unsigned char* __restrict__ scratch) {
   const CropDesc& d = descs[blockIdx.z];
+  const unsigned char* __restrict__ page = lv.p[d.level];
+  const int W = lv.W[d.level];
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
   if (x >= d.ww || y >= d.wh) return;
   const double X0 = d.minv[0] * x + d.minv[1] * y + d.minv[2];
@@ -257,6 +266,10 @@ __global__ void k_crop_resize_norm(const CropDesc* __restrict__ descs, const uns
     const unsigned char* img = scratch + d.warp_off;
     // pixel (yy, xx) of the (possibly rotated) crop; ROTATE_90_COUNTERCLOCKWISE: dst(i, j) = src(j, W - 1 - i)
     auto px = [&](int yy, int xx, int c) -> float {
+      if (d.flip) {  // ROTATE_180: dst(i, j) = src(rh - 1 - i, rw - 1 - j)
+        yy = d.rh - 1 - yy;
+        xx = d.rw - 1 - xx;
+      }
       if (d.rot) return (float)img[((size_t)xx * d.ww + (d.ww - 1 - yy)) * 3 + c];
       return (float)img[((size_t)yy * d.ww + xx) * 3 + c];
     };
@@ -294,10 +307,37 @@ __global__ void k_crop_resize_norm(const CropDesc* __restrict__ descs, const uns
   o[2 * plane] = v[2];
 }
 
-void crop_batch(hipStream_t s, const unsigned char* page, int H, int W, const CropDesc* descs_dev, int n, int max_ww,
-                int max_wh, unsigned char* scratch, float* out, int batch_w, int out_h) {
+// cv2.resize(img, None, fx=0.5, fy=0.5, interpolation=INTER_AREA) on uint8 HxWx3 (data/dataset.py:73-79): the scale is
+// exactly 2, i.e. ResizeAreaFast - full 2x2 cells round as (s + 2) >> 2; a cell cut by the right / bottom edge (odd
+// sizes whose half rounds up) averages the pixels it has, rint(sum / count); a cell starting past the edge is 0.
+__global__ void k_halve_u8c3(const unsigned char* __restrict__ src, int H, int W, unsigned char* __restrict__ dst, int dh, int dw) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= dw) return;
+  const int sx0 = 2 * x, sy0 = 2 * y;
+  unsigned char* o = dst + ((size_t)y * dw + x) * 3;
+  if (sx0 >= W || sy0 >= H) {
+    o[0] = o[1] = o[2] = 0;
+    return;
+  }
+  const int nx = sx0 + 2 <= W ? 2 : 1, ny = sy0 + 2 <= H ? 2 : 1;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    int sum = 0;
+    for (int dy = 0; dy < ny; ++dy)
+      for (int dx = 0; dx < nx; ++dx) sum += src[((size_t)(sy0 + dy) * W + sx0 + dx) * 3 + c];
+    if (nx == 2 && ny == 2) o[c] = (unsigned char)((sum + 2) >> 2);
+    else o[c] = (unsigned char)fminf(fmaxf(rintf((float)sum / (float)(nx * ny)), 0.f), 255.f);
+  }
+}
+void halve_u8c3(hipStream_t s, const unsigned char* src, int H, int W, unsigned char* dst, int dh, int dw) {
+  hipLaunchKernelGGL(k_halve_u8c3, dim3((dw + 255) / 256, dh), dim3(256), 0, s, src, H, W, dst, dh, dw);
+  YMK_HIP(hipGetLastError());
+}
+
+void crop_batch(hipStream_t s, const PageLevels& lv, const CropDesc* descs_dev, int n, int max_ww, int max_wh,
+                unsigned char* scratch, float* out, int batch_w, int out_h) {
   if (n == 0) return;
-  hipLaunchKernelGGL(k_warp_quads, dim3((max_ww + 63) / 64, max_wh, n), dim3(64), 0, s, page, H, W, descs_dev, scratch);
+  hipLaunchKernelGGL(k_warp_quads, dim3((max_ww + 63) / 64, max_wh, n), dim3(64), 0, s, lv, descs_dev, scratch);
   hipLaunchKernelGGL(k_crop_resize_norm, dim3((batch_w + 63) / 64, out_h, n), dim3(64), 0, s, descs_dev, scratch, out,
                      batch_w, out_h);
   YMK_HIP(hipGetLastError());
@@ -338,8 +378,46 @@ int ymk_crop_batch(const unsigned char* page_dev, int page_h, int page_w, const 
                    int max_warp_h, unsigned char* scratch_dev, float* out_dev, int batch_w, int out_h, void* stream) {
   try {
     YMK_CHECK(page_dev && descs_dev && scratch_dev && out_dev, "null argument");
-    ymk::crop_batch((hipStream_t)stream, page_dev, page_h, page_w, (const ymk::CropDesc*)descs_dev, n, max_warp_w,
-                    max_warp_h, scratch_dev, out_dev, batch_w, out_h);
+    ymk::PageLevels lv{};
+    for (int i = 0; i < ymk::MAX_LEVELS; ++i) {  // a descriptor naming a level > 0 reads the page: callers with a pyramid use _levels
+      lv.p[i] = page_dev;
+      lv.H[i] = page_h;
+      lv.W[i] = page_w;
+    }
+    ymk::crop_batch((hipStream_t)stream, lv, (const ymk::CropDesc*)descs_dev, n, max_warp_w, max_warp_h, scratch_dev, out_dev,
+                    batch_w, out_h);
+    return 0;
+  } catch (const std::exception& e) {
+    ymk::set_error(e.what());
+    return 1;
+  }
+}
+int ymk_crop_batch_levels(const unsigned char* const* level_pages_dev, const int* level_h, const int* level_w, int n_levels,
+                          const void* descs_dev, int n, int max_warp_w, int max_warp_h, unsigned char* scratch_dev,
+                          float* out_dev, int batch_w, int out_h, void* stream) {
+  try {
+    YMK_CHECK(level_pages_dev && level_h && level_w && descs_dev && scratch_dev && out_dev, "null argument");
+    YMK_CHECK(n_levels >= 1 && n_levels <= ymk::MAX_LEVELS, "1..4 pyramid levels");
+    ymk::PageLevels lv{};
+    for (int i = 0; i < ymk::MAX_LEVELS; ++i) {
+      const int k = i < n_levels && level_pages_dev[i] ? i : 0;  // unused levels alias the page
+      lv.p[i] = level_pages_dev[k];
+      lv.H[i] = level_h[k];
+      lv.W[i] = level_w[k];
+    }
+    YMK_CHECK(lv.p[0] != nullptr, "level 0 (the page) is required");
+    ymk::crop_batch((hipStream_t)stream, lv, (const ymk::CropDesc*)descs_dev, n, max_warp_w, max_warp_h, scratch_dev, out_dev,
+                    batch_w, out_h);
+    return 0;
+  } catch (const std::exception& e) {
+    ymk::set_error(e.what());
+    return 1;
+  }
+}
+int ymk_halve_u8c3(const unsigned char* src_dev, int h, int w, unsigned char* dst_dev, int dst_h, int dst_w, void* stream) {
+  try {
+    YMK_CHECK(src_dev && dst_dev && h > 0 && w > 0 && dst_h > 0 && dst_w > 0, "bad argument");
+    ymk::halve_u8c3((hipStream_t)stream, src_dev, h, w, dst_dev, dst_h, dst_w);
     return 0;
   } catch (const std::exception& e) {
     ymk::set_error(e.what());

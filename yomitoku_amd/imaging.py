@@ -141,6 +141,8 @@ class CropDesc(ctypes.Structure):
         ("fast_x", ctypes.c_int), ("fast_y", ctypes.c_int),
         ("warp_off", ctypes.c_longlong),
         ("slot", ctypes.c_int),
+        ("flip", ctypes.c_int),
+        ("level", ctypes.c_int),
     ]
 
 
@@ -289,10 +291,73 @@ def _plan_crops_scalar(shape_hw, quads, img_size=(32, 800), dynamic_width=False,
     return plans
 
 
-def build_crop_batch(page_dev: torch.Tensor, plans: Sequence[CropPlan], out_h: int = 32, batch_w: Optional[int] = None):
-    """Run the warp + resize kernels for one mini-batch: fp32 B x 3 x out_h x batch_w on the device."""
+def plan_crops_pyramid(shape_hw, quads, img_size=(32, 800), dynamic_width=False, source_downscale=False):
+    """plan_crops with the reference's source_downscale routing (data/dataset.py:64-103): each quad is planned on its
+    pyramid level, with its corners divided by 2^level in float32 (then truncated like any quad).  Returns
+    (plans, levels): plans[i].desc.level names the level; coordinates reported to the caller stay in page space."""
+    n = len(quads)
+    levels = source_levels(quads, img_size[0]) if source_downscale and n > 0 else np.zeros(n, dtype=int)
+    if not levels.any():
+        return plan_crops(shape_hw, quads, img_size, dynamic_width), levels
+    shapes = [tuple(int(v) for v in shape_hw[:2])]
+    for _ in range(int(levels.max())):
+        shapes.append((half_size(shapes[-1][0]), half_size(shapes[-1][1])))
+    plans: List[Optional[CropPlan]] = [None] * n
+    for k in sorted(set(levels.tolist())):
+        idx = np.flatnonzero(levels == k).tolist()
+        sub_quads = [quads[i] if k == 0 else (np.asarray(quads[i], dtype=np.float32) / (2.0 ** k)).tolist() for i in idx]
+        for i, plan in zip(idx, plan_crops(shapes[k], sub_quads, img_size, dynamic_width)):
+            if plan is not None:
+                plan.index = i
+                plan.desc.level = k
+                plans[i] = plan
+    return plans, levels
+
+
+def source_levels(quads, target_height: int, max_level: int = 3) -> np.ndarray:
+    """_calc_source_levels (data/dataset.py:16-41): a crop whose short side is s can be cut from the 2^k-downscaled
+    page as long as s / 2^k >= target_height; k = clip(floor(log2(s / target_height)), 0, max_level) per quad."""
+    if len(quads) == 0:
+        return np.zeros(0, dtype=int)
+    q = np.asarray(quads, dtype=np.float32).reshape(-1, 4, 2)
+    w = np.linalg.norm(q[:, 0] - q[:, 1], axis=1)
+    h = np.linalg.norm(q[:, 1] - q[:, 2], axis=1)
+    short = np.maximum(1.0, np.minimum(w, h))
+    return np.clip(np.floor(np.log2(short / float(target_height))).astype(int), 0, max_level)
+
+
+def half_size(n: int) -> int:
+    """cv2.resize(..., fx=0.5): dsize = saturate_cast<int>(n * 0.5) = round half to even."""
+    return int(round(n * 0.5))
+
+
+def build_pyramid(page_dev: torch.Tensor, needed_levels) -> List[Optional[torch.Tensor]]:
+    """Levels 0..max(needed) of the page as uint8 H x W x 3 device tensors (2x INTER_AREA halvings, each from the
+    previous level, data/dataset.py:73-79); levels no quad uses are built only as stepping stones and dropped."""
+    lib = _lib.load()
+    needed = {int(v) for v in needed_levels}
+    top = max(needed) if needed else 0
+    levels: List[Optional[torch.Tensor]] = [page_dev]
+    cur = page_dev
+    for k in range(1, top + 1):
+        h, w = cur.shape[:2]
+        nxt = torch.empty((half_size(h), half_size(w), 3), dtype=torch.uint8, device=page_dev.device)
+        with torch.cuda.device(page_dev.device):
+            _lib.check(lib.ymk_halve_u8c3(cur.data_ptr(), h, w, nxt.data_ptr(), nxt.shape[0], nxt.shape[1], _lib.current_stream_ptr()),
+                       "ymk_halve_u8c3")
+        levels.append(nxt if any(v >= k for v in needed) else None)
+        cur = nxt
+    return levels
+
+
+def build_crop_batch(page_dev, plans: Sequence[CropPlan], out_h: int = 32, batch_w: Optional[int] = None, flip: bool = False):
+    """Run the warp + resize kernels for one mini-batch: fp32 B x 3 x out_h x batch_w on the device.
+    page_dev: the resident page, or the list of pyramid levels (`build_pyramid`) when plans carry levels.
+    flip: every crop is turned by 180 degrees before the resize (orientation-fallback retry)."""
     lib = _lib.load()
     assert ctypes.sizeof(CropDesc) == lib.ymk_crop_desc_size(), "CropDesc layout mismatch"
+    levels = list(page_dev) if isinstance(page_dev, (list, tuple)) else [page_dev]
+    page0 = levels[0]
     n = len(plans)
     if batch_w is None:
         batch_w = max(p.canvas_width for p in plans)
@@ -302,19 +367,25 @@ def build_crop_batch(page_dev: torch.Tensor, plans: Sequence[CropPlan], out_h: i
     for slot, p in enumerate(plans):
         ctypes.memmove(ctypes.byref(arr[slot]), ctypes.byref(p.desc), ctypes.sizeof(CropDesc))
         arr[slot].slot = slot
+        arr[slot].flip = 1 if flip else 0
         arr[slot].warp_off = off
+        if p.desc.level >= len(levels) or levels[p.desc.level] is None:
+            raise ValueError(f"crop plan wants pyramid level {p.desc.level}, which was not built")
         off += p.desc.ww * p.desc.wh * 3
         off = (off + 15) & ~15
         max_w, max_h = max(max_w, p.desc.ww), max(max_h, p.desc.wh)
-    dev = page_dev.device
+    dev = page0.device
     descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
     scratch = torch.empty(max(off, 16), dtype=torch.uint8, device=dev)
     out = torch.empty((n, 3, out_h, batch_w), dtype=torch.float32, device=dev)
-    H, W = page_dev.shape[:2]
+    nl = len(levels)
+    ptrs = (ctypes.c_void_p * nl)(*[(t.data_ptr() if t is not None else None) for t in levels])
+    hs = (ctypes.c_int * nl)(*[(t.shape[0] if t is not None else 0) for t in levels])
+    ws = (ctypes.c_int * nl)(*[(t.shape[1] if t is not None else 0) for t in levels])
     with torch.cuda.device(dev):
         _lib.check(
-            lib.ymk_crop_batch(page_dev.data_ptr(), H, W, descs.data_ptr(), n, max_w, max_h, scratch.data_ptr(),
-                               out.data_ptr(), batch_w, out_h, _lib.current_stream_ptr()),
-            "ymk_crop_batch",
+            lib.ymk_crop_batch_levels(ptrs, hs, ws, nl, descs.data_ptr(), n, max_w, max_h, scratch.data_ptr(), out.data_ptr(),
+                                      batch_w, out_h, _lib.current_stream_ptr()),
+            "ymk_crop_batch_levels",
         )
     return out

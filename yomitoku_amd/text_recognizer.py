@@ -80,9 +80,10 @@ class TextRecognizerModelCatalog(BaseModelCatalog):
 class CropSet:
     """What ParseqDataset holds (data/dataset.py:44-129), minus the pixels: the per-quad plans."""
 
-    def __init__(self, cfg, page_dev, quads, dynamic_width=False):
-        self.page = page_dev
-        plans = imaging.plan_crops(page_dev.shape[:2], quads, cfg.data.img_size, dynamic_width)
+    def __init__(self, cfg, page_dev, quads, dynamic_width=False, source_downscale=False):
+        plans, levels = imaging.plan_crops_pyramid(page_dev.shape[:2], quads, cfg.data.img_size, dynamic_width, source_downscale)
+        # the page, or its pyramid when some quads are cut from a 2^k-downscaled copy (dataset.py:64-79)
+        self.page = imaging.build_pyramid(page_dev, levels) if levels.any() else page_dev
         self.plans = [p for p in plans if p is not None]
         self.content_widths = [p.content_width for p in self.plans]
         self.valid_quads = [q for q, p in zip(quads, plans) if p is not None]
@@ -100,8 +101,6 @@ class TextRecognizer(BaseModule):
         super().__init__()
         if infer_onnx:
             raise NotImplementedError("the ONNX backend is out of scope of the MI355X path (infer_onnx=False only)")
-        if source_downscale or rec_orientation_fallback:
-            raise NotImplementedError("source_downscale / rec_orientation_fallback are not implemented yet (SURVEY §8f-4)")
         self.load_model(model_name, path_cfg, from_pretrained=from_pretrained)
         self.charset = load_charset(self._cfg.charset)
         self.tokenizer = ParseqTokenizer(self.charset)
@@ -112,12 +111,12 @@ class TextRecognizer(BaseModule):
         self.model.eval()
         self.visualize = visualize
         self.infer_onnx = False
-        self.rec_orientation_fallback = False
+        self.rec_orientation_fallback = bool(rec_orientation_fallback)
         self.rec_orientation_fallback_thresh = rec_orientation_fallback_thresh
         self.batch_bucketing = batch_bucketing
         self.dynamic_width = dynamic_width
         self.num_parallel_batches = num_parallel_batches  # no effect, as in the reference
-        self.source_downscale = False
+        self.source_downscale = bool(source_downscale)
         self.model.to(self.device)
 
     # ------------------------------------------------------------------ batching (text_recognizer.py:115-203)
@@ -126,7 +125,7 @@ class TextRecognizer(BaseModule):
         if polygons is None:
             h, w = page.shape[:2]
             polygons = [[[0, 0], [w, 0], [w, h], [0, h]]]
-        dataset = CropSet(self._cfg, page, polygons, dynamic_width=self.dynamic_width)
+        dataset = CropSet(self._cfg, page, polygons, dynamic_width=self.dynamic_width, source_downscale=self.source_downscale)
         order = None
         if self.batch_bucketing and len(dataset) == len(polygons) and len(dataset) > 1:
             order = np.argsort(dataset.content_widths).tolist()
@@ -200,6 +199,33 @@ class TextRecognizer(BaseModule):
             offset += len(plans)
         return preds, scores, directions
 
+    # ------------------------------------------------------------------ 180-degree retry (text_recognizer.py:319-350)
+    def _prepare_fallback_batch(self, dataset, indices):
+        """The retried crops turned by 180 degrees on the fixed-width canvas (resize_with_padding), in chunks of
+        cfg.data.batch_size - the flip happens inside the crop kernel, on the same warped pixels."""
+        plans = [dataset.plans[i] for i in indices]
+        size = int(self._cfg.data.batch_size)
+        return [plans[i : i + size] for i in range(0, len(plans), size)]
+
+    def _apply_orientation_fallback(self, dataset, points, preds, scores, directions):
+        retry = [i for i, s in enumerate(scores) if s < self.rec_orientation_fallback_thresh]
+        if not retry:
+            return
+        retry_points = [points[i] for i in retry]
+        h, w = (int(v) for v in self._cfg.data.img_size)
+        r_preds, r_scores, r_dirs = [], [], []
+        offset = 0
+        for plans in self._prepare_fallback_batch(dataset, retry):
+            data = imaging.build_crop_batch(dataset.page, plans, out_h=h, batch_w=w, flip=True)
+            pred, score, direction = self.postprocess(self._run_inference(data), retry_points[offset : offset + len(plans)])
+            r_preds.extend(pred)
+            r_scores.extend(score)
+            r_dirs.extend(direction)
+            offset += len(plans)
+        for j, idx in enumerate(retry):
+            if r_scores[j] > scores[idx] and r_scores[j] >= self.rec_orientation_fallback_thresh:
+                preds[idx], scores[idx], directions[idx] = r_preds[j], r_scores[j], r_dirs[j]
+
     def __call__(self, img, points=None, vis=None):
         batches, points, dataset, order = self.preprocess(img, points)
         if order is not None:
@@ -211,6 +237,8 @@ class TextRecognizer(BaseModule):
             directions = [directions[i] for i in inverse]
         else:
             preds, scores, directions = self._run_batch_inference(dataset, batches, points)
+        if self.rec_orientation_fallback:
+            self._apply_orientation_fallback(dataset, points, preds, scores, directions)
         results = TextRecognizerSchema(contents=preds, scores=scores, points=points, directions=directions)
         if self.visualize:
             raise NotImplementedError("visualisation is out of scope of the MI355X path (visualize=False only)")
