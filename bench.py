@@ -43,7 +43,7 @@ LITE_CONFIGS = {
     "ocr": {
         "text_detector": {"from_pretrained": False},
         "text_recognizer": {"model_name": "parseq-tiny-dynw-v4", "from_pretrained": False, "dynamic_width": True,
-                            "batch_bucketing": True},
+                            "batch_bucketing": True, "source_downscale": True},  # cli/main.py:505-520 (--lite)
     },
     "layout_analyzer": {"layout_parser": {"from_pretrained": False}, "table_structure_recognizer": {"from_pretrained": False}},
 }
@@ -170,16 +170,17 @@ def cpu_analyzer_page(sds, page: Page, charset):
     op.detect(sds["det"], page.img)
     ocfg = make_cfg(**PRESETS["parseq-tiny-dynw-v4"])
     op.recognize(sds["rec"], ocfg, page.img, page.quads, charset, dynamic_width=True, batch_bucketing=True,
-                 width_budget=8000, max_batch_size=64, batch_size=10)
+                 width_budget=8000, max_batch_size=64, batch_size=10, source_downscale=True)
     op.layout(sds["lay"], page.img)
     op.tables(sds["tab"], page.img, page.tables)
 
 
 def _helper_init(local_rank, sds, shares, workers, index):
     """One helper process of a rank (yomitoku_amd/parallel.py PageProcesses): same GPU, own HIP context and
-    analyzer replicas built from the rank's (shared-memory) checkpoints, own pages resident in HBM."""
+    analyzer replicas built from the rank's checkpoints (received as numpy arrays), own pages resident in HBM."""
     from yomitoku_amd.parallel import PageParallel
 
+    sds = {k: {name: torch.from_numpy(a) for name, a in sd.items()} for k, sd in sds.items()}
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     pages = make_pages(shares[index], device)
@@ -246,10 +247,9 @@ def main():
         from yomitoku_amd.parallel import PageProcesses
 
         if n_procs > 1:
-            for sd in sds.values():
-                for t in sd.values():
-                    t.share_memory_()
-            helpers = PageProcesses(_helper_init, (local_rank, sds, shares, args.workers), n_procs=n_procs - 1, first_index=1)
+            # the rank's checkpoints go to its helpers by value, as numpy arrays through the spawn pipe (no /dev/shm)
+            wire = {k: {name: t.numpy() for name, t in sd.items()} for k, sd in sds.items()}
+            helpers = PageProcesses(_helper_init, (local_rank, wire, shares, args.workers), n_procs=n_procs - 1, first_index=1)
         pool = PageParallel(lambda i: build_analyzer(device, sds), n_workers=args.workers)
 
         def step():  # every process of the rank walks its share of the rank's pages; the step ends when all have
@@ -377,7 +377,7 @@ def main():
                 n_cpu += 1
             sample = (f"{n_cpu} of the same synthetic pages through the oracle restatement (PyTorch-CPU fp32) of the `--lite` "
                       "chain: detector + recogniser + layout + table nets with their pre/post-processing, "
-                      "without source_downscale / onnxruntime")
+                      "PyTorch path for the detector too (onnxruntime is not installed)")
         else:
             from oracle.dbnet import dbnet_forward
 

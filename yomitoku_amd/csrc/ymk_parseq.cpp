@@ -8,6 +8,8 @@
 //     is an independent fmaf chain;
 //   - tokens, <eos> bookkeeping and the repetition detector live on the device; the host reads one
 //     int per step (the "every row has an <eos>" flag, models/parseq.py:245-250).
+#include <sched.h>
+
 #include "ymk_common.h"
 #include "ymk_seq.h"
 #include "ymk_decstep.h"
@@ -304,7 +306,8 @@ class ParseqModel : public Model {
       for (long spin = 0;; ++spin) {
         const int v = __atomic_load_n(&host_flags_[i], __ATOMIC_ACQUIRE);
         if (v != 0) return v - 1;
-        __builtin_ia32_pause();
+        if (spin < 4096) __builtin_ia32_pause();  // ~20 us of pure spinning, then give the core away between polls:
+        else sched_yield();                       // 8 ranks x 8 pages in flight must not pin 64 host cores
         if ((spin & 0xFFFF) == 0xFFFF) {  // the step may have faulted: do not spin forever
           hipError_t e = hipStreamQuery(s);
           if (e != hipSuccess && e != hipErrorNotReady) YMK_HIP(e);
