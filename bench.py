@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the MI355X DocumentAnalyzer hot path (contract: task prompt / DESIGN.md §8).
 
-    python bench.py --gpus N --steps K --warmup W [--workload analyzer|detector] [--pages 64] [--procs 4] [--workers 2]
+    python bench.py --gpus N --steps K --warmup W [--workload analyzer|detector|recognizer] [--pages 64] [--procs 4] [--workers 2]
 
 One rank per GPU (torchrun env).  A "step" is one pass of the hot path over one batch of synthetic
 1600x1200 pages that are already resident in HBM (uint8 BGR, as `cv2.imread` would hand them over).
@@ -20,6 +20,8 @@ workload analyzer (default; BASELINE.json configs[3], `--lite` model set): DBNet
   boxes, the aggregation the true paragraph boxes - while every network and every pre/post stage
   still runs at full cost on every page inside the timed region.
 workload detector (configs[1]): DBNet forward alone on a batch of 8 pages.
+workload recognizer (configs[2]): TextRecognizer (`--rec-model parseq` = open-beta geometry, or the lite model) on 2048
+  synthetic text lines per step; metric text-lines/sec.
 """
 from __future__ import annotations
 
@@ -203,12 +205,98 @@ def make_pages(seeds, device):
         return list(ex.map(lambda i: Page(i, device), seeds))
 
 
+REC_PRESETS = {  # --rec-model: (synth.parseq_state_dict kwargs, oracle preset name, batching kwargs of the oracle chain)
+    "parseq": (dict(seed=1236, patch=(8, 8), enc_dim=512, dec_dim=512, num_tokens=7312, eos_bias=6.5), "parseq",
+               dict(width_budget=None, max_batch_size=None, batch_size=128)),
+    "parseq-tiny-dynw-v4": (dict(seed=1235, eos_bias=6.1), "parseq-tiny-dynw-v4",
+                            dict(width_budget=8000, max_batch_size=64, batch_size=10)),
+}
+
+
+def recognizer_workload(args, rank, local_rank, world, device, lib):
+    """BASELINE.json configs[2]: TextRecognizer with dynamic_width + batch_bucketing on 2048 synthetic 32 x W text-line
+    crops per GPU per step (one sheet image + 2048 quads through TextRecognizer.__call__).  Unit: text lines."""
+    from yomitoku_amd import _lib, imaging
+    from yomitoku_amd import distributed as ydist
+    from yomitoku_amd.text_recognizer import TextRecognizer
+    from yomitoku_amd.utils.synth import parseq_state_dict, synthetic_line_sheet
+
+    ckpt_kw, preset, batching = REC_PRESETS[args.rec_model]
+    sd = ydist.broadcast_state_dict(parseq_state_dict(**ckpt_kw) if rank == 0 else None, src=0, device=device)
+    sheet, quads = synthetic_line_sheet(seed=1 + rank, n_lines=args.lines)
+    page = imaging.page_to_device(sheet, device)
+    rec = TextRecognizer(model_name=args.rec_model, from_pretrained=False, device=str(device), dynamic_width=True, batch_bucketing=True)
+    rec.model.load_state_dict(sd)
+
+    def step():
+        return rec(page, quads)[0]
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank != 0:
+        return None
+    roof = cpu = None
+    _lib.check(lib.ymk_prof_begin())
+    step()
+    torch.cuda.synchronize()
+    ms, fl, ln = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+    _lib.check(lib.ymk_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(ln)))
+    if ms.value > 0:
+        ach = fl.value / (ms.value * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "conv_igemm / conv_splitk (every linear layer of the ViT encoder and the decoder)",
+                "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                "traffic": None, "launches_per_line": round(ln.value / args.lines, 2),
+                "gflop_per_line": round(fl.value / args.lines / 1e9, 2), "kernel_ms_per_step": round(ms.value, 2)}
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import pipeline as op
+        from oracle.parseq import PRESETS, make_cfg
+
+        n_cpu = min(args.lines, 96)
+        ocfg = make_cfg(**PRESETS[preset])
+        t1 = time.perf_counter()
+        op.recognize(sd, ocfg, sheet, quads[:n_cpu], rec.charset, dynamic_width=True, batch_bucketing=True, **batching)
+        cpu = {"value": round(n_cpu / (time.perf_counter() - t1), 2), "unit": "lines/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"the first {n_cpu} of the same lines through oracle.pipeline.recognize (PyTorch-CPU fp32 restatement)"}
+    widths = [q[1][0] - q[0][0] for q in quads]
+    return {
+        "metric": f"PARSeq text-lines/sec (TextRecognizer {args.rec_model}, dynamic_width + batch_bucketing)",
+        "value": round(args.lines * args.steps * world / dt, 1), "unit": "lines/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"TextRecognizer {args.rec_model} on {args.lines} synthetic 32 x W text lines per GPU per step "
+                               f"(W log-normal, median {int(np.median(widths))} px, [16, 800]; BASELINE.json configs[2]); one "
+                               f"TextRecognizer call per step, {len(set(out.contents))} distinct strings decoded, "
+                               f"mean length {np.mean([len(c) for c in out.contents]):.1f} characters (seeded random weights)",
+                   "lines_per_step_per_gpu": args.lines, "parallelism": f"line sheets sharded x{world} GPU(s)",
+                   "checkpoints": "seeded synthetic (no network)", "last_batch_ar_steps": int(rec.model.last_ar_steps)},
+        "roofline": roof, "cpu_baseline": cpu,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="analyzer", choices=["analyzer", "detector"])
+    ap.add_argument("--workload", default="analyzer", choices=["analyzer", "detector", "recognizer"])
+    ap.add_argument("--rec-model", default="parseq", choices=sorted(REC_PRESETS), help="recognizer workload: model (configs[2]: parseq)")
+    ap.add_argument("--lines", type=int, default=2048, help="recognizer workload: text lines per step per GPU")
     ap.add_argument("--pages", type=int, default=64, help="pages per step per GPU (BASELINE.json configs[3]: 64)")
     ap.add_argument("--procs", type=int, default=4, help="processes per GPU (analyzer workload): each has its own interpreter/GIL")
     ap.add_argument("--workers", type=int, default=2, help="pages in flight per process (analyzer workload)")
@@ -226,6 +314,14 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     lib = _lib.load()
+
+    if args.workload == "recognizer":
+        line = recognizer_workload(args, rank, local_rank, world, device, lib)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
 
     # ---- weights: drawn once on rank 0, ONE flat RCCL broadcast per checkpoint over xGMI
     sds = make_checkpoints() if rank == 0 else {k: None for k in ("det", "rec", "lay", "tab")}

@@ -291,3 +291,31 @@ def synthetic_line_batch(seed: int, batch: int, width: int, height: int = 32) ->
         img = paper * (1 - ink) + 0.1 * ink
         x[b, :, :, :cw] = (img.expand(3, -1, -1) + 0.02 * torch.randn(3, height, cw, generator=g)).clamp(0, 1) * 2 - 1
     return x
+
+
+def synthetic_line_sheet(seed: int = 1, n_lines: int = 2048, sheet_width: int = 3200, line_height: int = 32):
+    """(sheet, quads): `n_lines` text-line boxes, all `line_height` px tall, widths log-normal (median ~120 px, clipped to
+    [16, 800]: the crop-width distribution the reference quotes, cli/main.py:508), packed row by row on one uint8 BGR
+    sheet - BASELINE.json configs[2] ("2048 synthetic 32xW text-line crops") in a form TextRecognizer.__call__ accepts."""
+    rng = np.random.default_rng(seed + 104729)
+    widths = np.clip(rng.lognormal(math.log(120), 0.8, size=n_lines), 16, 800).astype(int)
+    gap = 6
+    rows, x, y = [], gap, gap
+    for w in widths.tolist():
+        if x + w + gap > sheet_width:
+            x, y = gap, y + line_height + gap
+        rows.append((x, y, w))
+        x += w + gap
+    height = y + line_height + gap
+    img = np.clip(rng.normal(245.0, 3.0, size=(height, sheet_width, 3)), 0, 255).astype(np.uint8)
+    quads = []
+    for x0, y0, w in rows:
+        xx = x0 + 2
+        while xx < x0 + w - 2:  # glyph-like strokes
+            gw = int(rng.integers(8, 25))
+            x1 = min(xx + gw, x0 + w - 2)
+            block = img[y0 + 3 : y0 + line_height - 3, xx:x1]
+            block[rng.random(block.shape[:2]) < 0.55] = int(rng.integers(10, 70))
+            xx = x1 + int(rng.integers(2, 7))
+        quads.append([[x0, y0], [x0 + w, y0], [x0 + w, y0 + line_height], [x0, y0 + line_height]])
+    return img, quads
