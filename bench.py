@@ -225,7 +225,8 @@ def recognizer_workload(args, rank, local_rank, world, device, lib):
     sd = ydist.broadcast_state_dict(parseq_state_dict(**ckpt_kw) if rank == 0 else None, src=0, device=device)
     sheet, quads = synthetic_line_sheet(seed=1 + rank, n_lines=args.lines)
     page = imaging.page_to_device(sheet, device)
-    rec = TextRecognizer(model_name=args.rec_model, from_pretrained=False, device=str(device), dynamic_width=True, batch_bucketing=True)
+    rec = TextRecognizer(model_name=args.rec_model, from_pretrained=False, device=str(device), dynamic_width=True, batch_bucketing=True,
+                         num_parallel_batches=args.rec_lanes)
     rec.model.load_state_dict(sd)
 
     def step():
@@ -252,6 +253,7 @@ def recognizer_workload(args, rank, local_rank, world, device, lib):
     if rank != 0:
         return None
     roof = cpu = None
+    rec.num_parallel_batches = 1  # the per-launch event bookkeeping is single-threaded: serial pass for the roofline leg
     _lib.check(lib.ymk_prof_begin())
     step()
     torch.cuda.synchronize()
@@ -283,7 +285,8 @@ def recognizer_workload(args, rank, local_rank, world, device, lib):
                                f"(W log-normal, median {int(np.median(widths))} px, [16, 800]; BASELINE.json configs[2]); one "
                                f"TextRecognizer call per step, {len(set(out.contents))} distinct strings decoded, "
                                f"mean length {np.mean([len(c) for c in out.contents]):.1f} characters (seeded random weights)",
-                   "lines_per_step_per_gpu": args.lines, "parallelism": f"line sheets sharded x{world} GPU(s)",
+                   "lines_per_step_per_gpu": args.lines,
+                   "parallelism": f"line sheets sharded x{world} GPU(s), {args.rec_lanes} mini-batches in flight",
                    "checkpoints": "seeded synthetic (no network)", "last_batch_ar_steps": int(rec.model.last_ar_steps)},
         "roofline": roof, "cpu_baseline": cpu,
     }
@@ -297,6 +300,7 @@ def main():
     ap.add_argument("--workload", default="analyzer", choices=["analyzer", "detector", "recognizer"])
     ap.add_argument("--rec-model", default="parseq", choices=sorted(REC_PRESETS), help="recognizer workload: model (configs[2]: parseq)")
     ap.add_argument("--lines", type=int, default=2048, help="recognizer workload: text lines per step per GPU")
+    ap.add_argument("--rec-lanes", type=int, default=4, help="recognizer workload: TextRecognizer num_parallel_batches")
     ap.add_argument("--pages", type=int, default=64, help="pages per step per GPU (BASELINE.json configs[3]: 64)")
     ap.add_argument("--procs", type=int, default=4, help="processes per GPU (analyzer workload): each has its own interpreter/GIL")
     ap.add_argument("--workers", type=int, default=2, help="pages in flight per process (analyzer workload)")

@@ -102,6 +102,27 @@ def test_text_recognizer_source_downscale_and_orientation_fallback(dev, page):
     print("orientation fallback replaced", replaced, "of", len(quads))
 
 
+def test_text_recognizer_parallel_batches_equal_serial(dev, page):
+    """num_parallel_batches > 1 runs mini-batches on replica lanes concurrently; the result is the serial one."""
+    from yomitoku_amd.text_recognizer import TextRecognizer
+    from yomitoku_amd.utils.synth import parseq_state_dict
+
+    img, quads, _ = page
+    sd = parseq_state_dict(1235, eos_bias=6.0)
+    outs = []
+    for lanes in (1, 3):
+        rec = TextRecognizer(model_name="parseq-tiny-dynw-v4", from_pretrained=False, device="cuda:0", dynamic_width=True,
+                             batch_bucketing=True, num_parallel_batches=lanes)
+        rec.model.load_state_dict(sd)
+        rec._cfg.data.max_batch_size = 8  # several mini-batches out of ~50 lines
+        res, _ = rec(img, quads)
+        res2, _ = rec(img, quads)  # lanes are reused
+        assert res.contents == res2.contents and res.scores == res2.scores
+        outs.append(res)
+    assert outs[0].contents == outs[1].contents
+    assert outs[0].scores == outs[1].scores and outs[0].directions == outs[1].directions
+
+
 def test_layout_and_table_stages(dev, page):
     from oracle import pipeline as op
     from oracle.rtdetr import rtdetr_forward

@@ -21,6 +21,10 @@
 // Global -> register -> LDS double buffering, one barrier per K tile.
 // blockIdx is remapped so that each XCD (private L2) owns a contiguous range of tiles, n fastest,
 // i.e. the blocks that re-read one A row panel run on the same L2 (guide T1, bijective form).
+//
+// Two kernels share the operand layout and the epilogue: conv_igemm (above) for launches that fill the
+// chip, conv_splitk for grid-starved ones (K split over the waves of a block, see its comment);
+// conv2d() picks per launch from the GEMM shape alone, so a given shape always takes the same path.
 #include "ymk_common.h"
 
 namespace ymk {

@@ -6,8 +6,10 @@
 //   - K/V of the context and of the encoder memory are projected once and cached (the reference
 //     re-projects them every step); rows are bit-identical because each output row of the MFMA GEMM
 //     is an independent fmaf chain;
-//   - tokens, <eos> bookkeeping and the repetition detector live on the device; the host reads one
-//     int per step (the "every row has an <eos>" flag, models/parseq.py:245-250).
+//   - tokens, <eos> bookkeeping and the repetition detector live on the device; the host polls one
+//     mapped word per step, two steps behind the device (the "every row has an <eos>" test,
+//     models/parseq.py:245-250); the steps queued past the stop are no-ops;
+//   - decoder widths <= 256 run a whole AR step as one kernel (ymk_decstep.hip), wider ones as GEMMs.
 #include <sched.h>
 
 #include "ymk_common.h"

@@ -115,7 +115,7 @@ class TextRecognizer(BaseModule):
         self.rec_orientation_fallback_thresh = rec_orientation_fallback_thresh
         self.batch_bucketing = batch_bucketing
         self.dynamic_width = dynamic_width
-        self.num_parallel_batches = num_parallel_batches  # no effect, as in the reference
+        self.num_parallel_batches = int(num_parallel_batches)  # mini-batches in flight (see _run_batch_inference_parallel)
         self.source_downscale = bool(source_downscale)
         self.model.to(self.device)
 
@@ -170,9 +170,10 @@ class TextRecognizer(BaseModule):
         return imaging.build_crop_batch(dataset.page, plans, out_h=int(self._cfg.data.img_size[0]), batch_w=batch_w)
 
     # ------------------------------------------------------------------ inference + decode
-    def _run_inference(self, data: torch.Tensor):
-        logits = self.model(data)
-        return self.model.token_stats(logits)  # == softmax(-1).max(-1), without materialising the softmax
+    def _run_inference(self, data: torch.Tensor, model=None):
+        model = model or self.model
+        logits = model(data)
+        return model.token_stats(logits)  # == softmax(-1).max(-1), without materialising the softmax
 
     def postprocess(self, stats, points):
         ids, probs = stats
@@ -187,6 +188,8 @@ class TextRecognizer(BaseModule):
         return pred, score, directions
 
     def _run_batch_inference(self, dataset, batches, points):
+        if self.num_parallel_batches > 1 and len(batches) > 1:
+            return self._run_batch_inference_parallel(dataset, batches, points)
         preds, scores, directions = [], [], []
         offset = 0
         for plans in batches:
@@ -197,6 +200,59 @@ class TextRecognizer(BaseModule):
             scores.extend(score)
             directions.extend(direction)
             offset += len(plans)
+        return preds, scores, directions
+
+    def _lanes(self, n):
+        """n (model replica, HIP stream) pairs: mini-batches are independent, but a model handle owns one workspace
+        arena, so concurrent batches need their own replica (the lite recogniser is 40 MB; packed once, kept)."""
+        if getattr(self, "_lane_weights", None) is not self.model.state_dict():  # first use, or new weights were loaded
+            self._lane_models, self._lane_streams = [self.model], getattr(self, "_lane_streams", [])
+            self._lane_weights = self.model.state_dict()
+        while len(self._lane_models) < n:
+            twin = type(self.model)(cfg=self._cfg)
+            twin.load_state_dict(self.model.state_dict()).to(self.device)
+            self._lane_models.append(twin)
+        dev = torch.device(self.device)
+        while len(self._lane_streams) < n:
+            self._lane_streams.append(torch.cuda.Stream(device=dev))
+        return list(zip(self._lane_models[:n], self._lane_streams[:n]))
+
+    def _run_batch_inference_parallel(self, dataset, batches, points):
+        """`num_parallel_batches` mini-batches in flight (text_recognizer.py:285-317 runs them on CPU worker threads;
+        there the gate is dead code).  Here each lane is a thread with its own replica and HIP stream:
+        the AR decode of one batch is a chain of small launches that leaves the device mostly idle.  Outputs are
+        those of the serial loop - batches do not interact - in batch order."""
+        import queue
+        from concurrent.futures import ThreadPoolExecutor
+
+        n = min(int(self.num_parallel_batches), len(batches))
+        free = queue.Queue()
+        for lane in self._lanes(n):
+            free.put(lane)
+        offsets = np.cumsum([0] + [len(b) for b in batches]).tolist()
+        dev = torch.device(self.device)
+        issued = torch.cuda.current_stream(dev)  # the page upload / pyramid were issued here
+
+        def work(i):
+            model, stream = free.get()
+            try:
+                stream.wait_stream(issued)
+                with torch.cuda.stream(stream):
+                    data = self._collate(dataset, batches[i])
+                    stats = self._run_inference(data, model)
+                    out = self.postprocess(stats, points[offsets[i] : offsets[i + 1]])  # .cpu() waits for this stream
+                self.model.last_ar_steps = model.last_ar_steps
+                return out
+            finally:
+                free.put((model, stream))
+
+        if not hasattr(self, "_lane_pool") or self._lane_pool._max_workers < n:
+            self._lane_pool = ThreadPoolExecutor(max_workers=n, thread_name_prefix="ymk-rec")
+        preds, scores, directions = [], [], []
+        for pred, score, direction in self._lane_pool.map(work, range(len(batches))):
+            preds.extend(pred)
+            scores.extend(score)
+            directions.extend(direction)
         return preds, scores, directions
 
     # ------------------------------------------------------------------ 180-degree retry (text_recognizer.py:319-350)
