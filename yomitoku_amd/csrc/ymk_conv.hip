@@ -25,6 +25,9 @@
 // Two kernels share the operand layout and the epilogue: conv_igemm (above) for launches that fill the
 // chip, conv_splitk for grid-starved ones (K split over the waves of a block, see its comment);
 // conv2d() picks per launch from the GEMM shape alone, so a given shape always takes the same path.
+#include <deque>
+#include <mutex>
+
 #include "ymk_common.h"
 
 namespace ymk {
@@ -466,8 +469,9 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk(ConvK p) {
 
 // ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream
 struct ProfState {
+  std::mutex mu;  // launches may come from several host threads (page workers, recogniser lanes)
   bool on = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  std::deque<std::pair<hipEvent_t, hipEvent_t>> ev;  // deque: a span's pointer stays valid while others are added
   size_t used = 0;
   double flop = 0.0;
   std::vector<std::string> desc;
@@ -487,11 +491,13 @@ static bool no_splitk() {  // YMK_NO_SPLITK=1: every launch through conv_igemm (
 }
 
 void prof_begin() {
+  std::lock_guard<std::mutex> lock(g_prof.mu);
   g_prof.on = true;
   g_prof.used = 0;
   g_prof.flop = 0.0;
 }
 void prof_end(double* ms, double* flop, int64_t* launches) {
+  std::lock_guard<std::mutex> lock(g_prof.mu);
   double total = 0.0;
   for (size_t i = 0; i < g_prof.used; ++i) {
     YMK_HIP(hipEventSynchronize(g_prof.ev[i].second));
@@ -512,6 +518,7 @@ void prof_end(double* ms, double* flop, int64_t* launches) {
 static std::pair<hipEvent_t, hipEvent_t>* prof_open(hipStream_t s, const ConvK& k, int BM, int BN, int grid, int ksplit) {
   std::pair<hipEvent_t, hipEvent_t>* e = nullptr;
   if (g_prof.on) {
+    std::lock_guard<std::mutex> lock(g_prof.mu);
     if (g_prof.used == g_prof.ev.size()) {
       std::pair<hipEvent_t, hipEvent_t> n;
       YMK_HIP(hipEventCreate(&n.first));
