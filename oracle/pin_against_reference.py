@@ -404,11 +404,107 @@ def pin_filters():
           f"kept detections: {[len(c['labels']) for c in post_cases]}")
 
 
+def _ref_methods(relpath, cls, names, env):
+    """Like _ref_functions for methods of a reference class: returned as plain functions taking `self` first."""
+    import ast
+
+    from ._refstubs import REF_SRC
+
+    path = os.path.join(REF_SRC, "yomitoku", relpath)
+    tree = ast.parse(open(path, encoding="utf-8").read())
+    klass = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls)
+    body = [n for n in klass.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert {n.name for n in body} == set(names), (relpath, cls, names)
+    ns = dict(env)
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def pin_geometry():
+    """Integer geometry and batching rules of the recogniser / detector front ends, answered by the reference's own
+    functions (cv2.resize replaced by a stand-in that only reports the size it was asked for):
+    resize_shortest_edge sizes, calc_resize_without_padding, validate_quads, _calc_source_levels,
+    TextRecognizer._make_mini_batch compositions, ParseqTokenizer.decode -> tests/golden/geometry.json."""
+    import json
+    import types
+
+    import torch
+    import torch.nn.functional as F
+
+    cv2 = types.SimpleNamespace(INTER_AREA=3, resize=lambda img, dsize, interpolation=None: np.zeros((dsize[1], dsize[0], 3), np.uint8))
+    fenv = {"np": np, "cv2": cv2}
+    rse, calc, validate = _ref_functions("data/functions.py", ["resize_shortest_edge", "calc_resize_without_padding", "validate_quads"], fenv)
+    short_sides, levels_fn = _ref_functions("data/dataset.py", ["_quad_short_sides", "_calc_source_levels"], {"np": np})
+    rng = np.random.default_rng(77)
+    sizes = [(1600, 1200), (1200, 1600), (480, 640), (2100, 1500), (91, 38), (700, 2400), (32, 32), (33, 4000)]
+    sizes += [(int(rng.integers(20, 5000)), int(rng.integers(20, 5000))) for _ in range(300)]
+    resize_cases = []
+    for h, w in sizes:
+        out = rse(np.zeros((h, w, 3), np.uint8), 1280, 1600)
+        resize_cases.append({"h": h, "w": w, "out": [int(out.shape[0]), int(out.shape[1])]})
+    pad_cases = []
+    for _ in range(400):
+        h, w = int(rng.integers(1, 700)), int(rng.integers(1, 3000))
+        nh, nw = calc(np.zeros((h, w, 3), np.uint8), (32, 800))
+        pad_cases.append({"h": h, "w": w, "out": [int(nh), int(nw)]})
+    quad_cases = []
+    img = np.zeros((300, 400, 3), np.uint8)
+    for _ in range(300):
+        q = (rng.integers(-20, 430, size=(4, 2)) + rng.random((4, 2)) * (rng.random() < 0.3)).tolist()
+        if rng.random() < 0.05:
+            q = q[:3]
+        quad_cases.append({"quad": q, "valid": validate(img, q) is True})
+    level_cases = []
+    for _ in range(40):
+        n = int(rng.integers(1, 12))
+        quads = []
+        for _q in range(n):
+            x, y = float(rng.integers(0, 500)), float(rng.integers(0, 500))
+            w, h = float(rng.integers(2, 1200)), float(rng.integers(2, 600))
+            quads.append([[x, y], [x + w, y + rng.integers(-3, 4)], [x + w, y + h], [x, y + h]])
+        quads = np.asarray(quads, dtype=np.float64).tolist()
+        level_cases.append({"quads": quads, "levels": [int(v) for v in levels_fn(quads, 32)]})
+    mk, collate = _ref_methods("text_recognizer.py", "TextRecognizer", ["_make_mini_batch", "_collate"], {"torch": torch, "F": F, "np": np})
+    batch_cases = []
+    for k in range(60):
+        n = int(rng.integers(1, 150))
+        widths = (np.clip(rng.lognormal(np.log(120), 0.8, size=n), 16, 800).astype(int) // 8 * 8 + 8).tolist()
+        dynamic = bool(k % 3 != 2)
+        budget = [8000, None, 3000][k % 3] if dynamic else None
+        max_bs = [64, None, 16][(k // 3) % 3]
+        data = types.SimpleNamespace(batch_size=[10, 128, 7][k % 3], width_budget=budget, max_batch_size=max_bs)
+        fake = types.SimpleNamespace(_cfg=types.SimpleNamespace(data=data), dynamic_width=dynamic)
+        fake._collate = lambda mb, fake=fake: collate(fake, mb)
+        wlist = widths if dynamic else [800] * n
+        tensors = [torch.full((1, 1, w), float(i)) for i, w in enumerate(wlist)]  # value = crop index
+        order = np.argsort(wlist, kind="stable").tolist() if (k % 2 == 0 and n > 1) else None
+        out = mk(fake, tensors, order)
+        batch_cases.append({"widths": wlist, "dynamic": dynamic, "batch_size": data.batch_size, "width_budget": budget,
+                            "max_batch_size": max_bs, "order": order,
+                            "batches": [{"members": [int(v) for v in b[:, 0, 0, 0].tolist()], "width": int(b.shape[-1])} for b in out]})
+    tok = ref_import("yomitoku.postprocessor.parseq_tokenizer")
+    charset = [chr(0x3041 + i) for i in range(60)]
+    t = tok.ParseqTokenizer(charset)
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(24, 12, len(t) - 2, generator=g) * 3.0
+    logits[:, :, 0] += torch.linspace(-4, 6, 12)[None, :]  # <eos> grows more likely along the sequence
+    logits[3, :, 0] = -30.0  # a row that never ends
+    probs = logits.softmax(-1)
+    texts, scores = t.decode(probs)
+    tok_case = {"charset": charset, "probs": probs.tolist(), "texts": texts, "scores": scores}
+    with open(os.path.join(GOLDEN, "geometry.json"), "w") as f:
+        json.dump({"resize": resize_cases, "pad": pad_cases, "quads": quad_cases, "levels": level_cases, "batches": batch_cases,
+                   "tokenizer": tok_case}, f)
+    print(f"[geometry] resize {len(resize_cases)}, pad {len(pad_cases)}, quads {len(quad_cases)} "
+          f"({sum(c['valid'] for c in quad_cases)} valid), levels {len(level_cases)}, batching {len(batch_cases)}, "
+          f"tokenizer {len(texts)} rows (lengths {sorted(set(len(x) for x in texts))})")
+
+
 def main(argv):
     what = argv[1] if len(argv) > 1 else "all"
     os.makedirs(GOLDEN, exist_ok=True)
     todo = {"dbnet": pin_dbnet, "parseq": pin_parseq, "rtdetr": pin_rtdetr, "host": pin_host_logic, "aggregate": pin_aggregate,
-            "filters": pin_filters}
+            "filters": pin_filters, "geometry": pin_geometry}
     for k, fn in todo.items():
         if what in (k, "all"):
             fn()
