@@ -80,3 +80,20 @@ def test_matches_oracle_open_beta_no_refine(dev):
     out = net(x.to(dev)).cpu()
     assert out.shape == ref.shape and out.shape[1] == steps
     assert (out - ref).abs().max().item() < LOGIT_TOL
+
+
+def test_matches_oracle_small_geometry(dev):
+    """parseq-small geometry: 16x16 patches, D = 384, 8 heads -> head dim 48 (flash attention pads it to 64 in LDS;
+    the decoder takes the per-op path because 48 / 4 lanes per head is not a power of two)."""
+    from oracle.parseq import parseq_forward
+    from yomitoku_amd.utils.synth import parseq_state_dict, synthetic_line_batch
+
+    kw = dict(patch=(16, 16), enc_dim=384, dec_dim=384, num_tokens=7312, enc_depth=2)
+    sd = parseq_state_dict(78, eos_bias=6.0, **kw)
+    ocfg, net = _net(dev, sd, "parseq", patch=(16, 16), enc_dim=384, enc_heads=8, dec_dim=384, dec_heads=8, enc_depth=2)
+    x = synthetic_line_batch(6, 3, 800)
+    ref, steps = parseq_forward(sd, ocfg, x, return_steps=True)
+    out = net(x.to(dev)).cpu()
+    assert net.last_ar_steps == steps and out.shape == ref.shape
+    assert torch.equal(out.argmax(-1), ref.argmax(-1))
+    assert (out - ref).abs().max().item() < LOGIT_TOL

@@ -38,7 +38,8 @@ def _ref_attn(q, k, v, heads, mask=None, kpm=None):
 
 
 @pytest.mark.parametrize("b,heads,hd,lq,lk", [(2, 6, 32, 184, 184), (1, 8, 64, 100, 100), (3, 8, 96, 40, 40),
-                                              (2, 6, 32, 800, 800), (2, 8, 32, 101, 37), (1, 8, 32, 300, 300)])
+                                              (2, 6, 32, 800, 800), (2, 8, 32, 101, 37), (1, 8, 32, 300, 300),
+                                              (2, 8, 48, 100, 100), (1, 8, 48, 77, 131)])  # 48: parseq-small (padded to 64 in LDS)
 def test_flash_attention(dev, b, heads, hd, lq, lk):
     from yomitoku_amd import hipops
 

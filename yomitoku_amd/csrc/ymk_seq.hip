@@ -112,21 +112,25 @@ struct AttnP {
   float scale;
 };
 
-template <int HD>
+// HD: head dim as laid out in LDS / the accumulators (a multiple of 32); HDR <= HD: the real head dim (a multiple of 8).
+// HDR < HD (48 in 64, parseq-small) leaves LDS columns HDR..HD-1 unwritten: they only feed output rows d >= HDR, which
+// are never stored.
+template <int HD, int HDR = HD>
 __global__ __launch_bounds__(256, 1) void k_flash_attn(AttnP p) {
   constexpr int KT = 64;           // keys per LDS tile
   constexpr int LDH = HD + 4;      // padded row
-  constexpr int NKC = HD / 8;      // k-chunks of 8 in the QK^T product
+  constexpr int NKC = HDR / 8;     // k-chunks of 8 in the QK^T product
   constexpr int NDC = HD / 32;     // 32-wide d chunks of the output
-  constexpr int LPT = (KT * HD / 4) / 256;  // float4 loads per thread per operand
+  constexpr int LPT = (KT * HDR / 4) / 256;  // float4 loads per thread per operand
+  static_assert(HD % 32 == 0 && HDR % 8 == 0 && HDR <= HD && (KT * HDR / 4) % 256 == 0, "head dim");
   __shared__ __attribute__((aligned(16))) float lds[2 * 2 * KT * LDH];
 
   const int t = threadIdx.x, wv = t >> 6, lane = t & 63, li = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q0 = blockIdx.x * 128 + wv * 32;
-  const float* qb = p.q + (size_t)b * p.bsq + h * HD;
-  const float* kb = p.k + (size_t)b * p.bsk + h * HD;
-  const float* vb = p.v + (size_t)b * p.bsv + h * HD;
+  const float* qb = p.q + (size_t)b * p.bsq + h * HDR;
+  const float* kb = p.k + (size_t)b * p.bsk + h * HDR;
+  const float* vb = p.v + (size_t)b * p.bsv + h * HDR;
 
   // this lane's query row, pre-scaled: Q[q][kc*8 + 4*lh + s]
   f32x4 qf[NKC];
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void k_flash_attn(AttnP p) {
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
       const int idx = t + 256 * i;
-      const int row = idx / (HD / 4), c4 = idx - row * (HD / 4);
+      const int row = idx / (HDR / 4), c4 = idx - row * (HDR / 4);
       const int key = min(k0 + row, p.Lk - 1);
       rk[i] = *reinterpret_cast<const f32x4*>(kb + (size_t)key * p.ldk + c4 * 4);
       rv[i] = *reinterpret_cast<const f32x4*>(vb + (size_t)key * p.ldv + c4 * 4);
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void k_flash_attn(AttnP p) {
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
       const int idx = t + 256 * i;
-      const int row = idx / (HD / 4), c4 = idx - row * (HD / 4);
+      const int row = idx / (HDR / 4), c4 = idx - row * (HDR / 4);
       *reinterpret_cast<f32x4*>(Ks + row * LDH + c4 * 4) = rk[i];
       *reinterpret_cast<f32x4*>(Vs + row * LDH + c4 * 4) = rv[i];
     }
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void k_flash_attn(AttnP p) {
   const int qi = q0 + li;
   if (qi < p.Lq) {
     const float inv = 1.f / l_run;
-    float* orow = p.o + (size_t)b * p.bso + (size_t)qi * p.ldo + h * HD;
+    float* orow = p.o + (size_t)b * p.bso + (size_t)qi * p.ldo + h * HDR;
 #pragma unroll
     for (int dc = 0; dc < NDC; ++dc)
 #pragma unroll
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void k_flash_attn(AttnP p) {
         w.y = oacc[dc][4 * g + 1] * inv;
         w.z = oacc[dc][4 * g + 2] * inv;
         w.w = oacc[dc][4 * g + 3] * inv;
-        *reinterpret_cast<f32x4*>(orow + dc * 32 + 8 * g + 4 * lh) = w;
+        if (dc * 32 + 8 * g + 4 * lh < HDR) *reinterpret_cast<f32x4*>(orow + dc * 32 + 8 * g + 4 * lh) = w;
       }
   }
 }
@@ -261,6 +265,7 @@ void flash_attention(hipStream_t s, const float* q, const float* k, const float*
   if (hd == 32) hipLaunchKernelGGL(k_flash_attn<32>, grid, dim3(256), 0, s, p);
   else if (hd == 64) hipLaunchKernelGGL(k_flash_attn<64>, grid, dim3(256), 0, s, p);
   else if (hd == 96) hipLaunchKernelGGL(k_flash_attn<96>, grid, dim3(256), 0, s, p);
+  else if (hd == 48) hipLaunchKernelGGL((k_flash_attn<64, 48>), grid, dim3(256), 0, s, p);
   else throw Error("attention: unsupported head dim " + std::to_string(hd));
   YMK_HIP(hipGetLastError());
 }
