@@ -500,11 +500,56 @@ def pin_geometry():
           f"tokenizer {len(texts)} rows (lengths {sorted(set(len(x) for x in texts))})")
 
 
+def pin_configs():
+    """Default values of every on-path config dataclass of the reference (configs/*.py), as plain containers ->
+    tests/golden/configs.json.  Paths into the reference's resource directory are reduced to their base names."""
+    import dataclasses
+    import importlib.util
+    import json
+
+    from ._refstubs import REF_SRC
+
+    names = {
+        "TextDetectorDBNetConfig": "cfg_text_detector_dbnet", "TextDetectorDBNetV2Config": "cfg_text_detector_dbnet_v2",
+        "TextDetectorDBNetV2_1Config": "cfg_text_detector_dbnet_v2_1", "TextRecognizerPARSeqConfig": "cfg_text_recognizer_parseq",
+        "TextRecognizerPARSeqV2Config": "cfg_text_recognizer_parseq_v2", "TextRecognizerPARSeqSmallConfig": "cfg_text_recognizer_parseq_small",
+        "TextRecognizerPARSeqTinyConfig": "cfg_text_recognizer_parseq_tiny",
+        "TextRecognizerPARSeqLargeV41Config": "cfg_text_recognizer_parseq_large_v4_1",
+        "TextRecognizerPARSeqTinyDynwV4Config": "cfg_text_recognizer_parseq_tiny_dynw_v4",
+        "LayoutParserRTDETRv2Config": "cfg_layout_parser_rtdtrv2", "LayoutParserRTDETRv2V2Config": "cfg_layout_parser_rtdtrv2_v2",
+        "TableStructureRecognizerRTDETRv2Config": "cfg_table_structure_recognizer_rtdtrv2",
+    }
+
+    def clean(v):
+        if isinstance(v, dict):
+            return {k: clean(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return [clean(x) for x in v]
+        if isinstance(v, str) and ("/" in v or "\\" in v) and os.path.splitext(v)[1] in (".txt", ".ttf", ".otf"):
+            return "<resource>/" + os.path.basename(v)
+        return v
+
+    install = ref_import  # registers the namespace packages
+    install("yomitoku.constants") if os.path.exists(os.path.join(REF_SRC, "yomitoku", "constants.py")) else None
+    out = {}
+    for cls, mod in names.items():
+        path = os.path.join(REF_SRC, "yomitoku", "configs", mod + ".py")
+        spec = importlib.util.spec_from_file_location("yomitoku.configs." + mod, path)
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[spec.name] = m
+        spec.loader.exec_module(m)
+        out[cls] = clean(dataclasses.asdict(getattr(m, cls)()))
+    with open(os.path.join(GOLDEN, "configs.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(f"[configs] wrote {len(out)} default configs")
+
+
 def main(argv):
     what = argv[1] if len(argv) > 1 else "all"
     os.makedirs(GOLDEN, exist_ok=True)
     todo = {"dbnet": pin_dbnet, "parseq": pin_parseq, "rtdetr": pin_rtdetr, "host": pin_host_logic, "aggregate": pin_aggregate,
-            "filters": pin_filters, "geometry": pin_geometry}
+            "filters": pin_filters, "geometry": pin_geometry,
+            "configs": pin_configs}
     for k, fn in todo.items():
         if what in (k, "all"):
             fn()

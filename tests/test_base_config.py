@@ -1,0 +1,112 @@
+"""Config / catalog / module base: the behaviours the reference's own tests/test_base.py checks, and
+every default config value against the reference's dataclasses (oracle/pin_against_reference.py configs ->
+tests/golden/configs.json).  No GPU: nothing here builds a network."""
+import json
+import os
+
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "configs.json")
+
+
+def _clean(v):
+    if isinstance(v, dict):
+        return {k: _clean(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_clean(x) for x in v]
+    if isinstance(v, str) and os.sep in v and os.path.splitext(v)[1] in (".txt", ".ttf", ".otf"):
+        return "<resource>/" + os.path.basename(v)
+    return v
+
+
+def test_default_configs_equal_the_reference():
+    from yomitoku_amd import configs
+    from yomitoku_amd.config import structured, to_container
+
+    with open(GOLD) as f:
+        gold = json.load(f)
+    assert len(gold) == 12
+    for name, want in gold.items():
+        got = _clean(to_container(structured(getattr(configs, name))))
+        assert got == want, name
+
+
+def test_resources_named_by_the_configs_exist():
+    from yomitoku_amd import configs
+    from yomitoku_amd.config import structured
+
+    for name in ("TextRecognizerPARSeqConfig", "TextRecognizerPARSeqTinyDynwV4Config", "TextRecognizerPARSeqLargeV41Config"):
+        cfg = structured(getattr(configs, name))
+        assert os.path.isfile(cfg.charset), cfg.charset
+        with open(cfg.charset, encoding="utf-8") as f:
+            assert len(f.read()) + 3 == cfg.num_tokens  # [E] + charset + [B], [P]
+
+
+def test_load_yaml_config(tmp_path):
+    from yomitoku_amd.config import load_config, load_yaml_config
+    from yomitoku_amd.configs import LayoutParserRTDETRv2Config
+
+    with pytest.raises(FileNotFoundError):
+        load_yaml_config(tmp_path / "dummy.yaml")
+    binary = tmp_path / "test.jpg"
+    binary.write_bytes(bytes(range(256)) * 4)
+    with pytest.raises(ValueError):
+        load_yaml_config(binary)
+    override = tmp_path / "layout_parser.yaml"
+    override.write_text("thresh_score: 0.8\n")
+    assert load_yaml_config(override).thresh_score == 0.8
+    cfg = load_config(LayoutParserRTDETRv2Config, str(override))
+    assert cfg.thresh_score == 0.8
+    assert cfg.hf_hub_repo == "KotaroKinoshita/yomitoku-layout-parser-rtdtrv2-open-beta"
+    nested = tmp_path / "nested.yaml"
+    nested.write_text("RTDETRTransformerv2:\n  num_queries: 100\n")
+    cfg = load_config(LayoutParserRTDETRv2Config, str(nested))
+    assert cfg.RTDETRTransformerv2.num_queries == 100 and cfg.RTDETRTransformerv2.num_layers == 6  # siblings keep defaults
+
+
+def test_catalog_and_module_contract(tmp_path):
+    from yomitoku_amd import base
+    from yomitoku_amd.config import load_yaml_config
+    from yomitoku_amd.configs import LayoutParserRTDETRv2Config
+    from yomitoku_amd.nets import RTDETRv2
+
+    class Catalog(base.BaseModelCatalog):
+        def __init__(self):
+            super().__init__()
+            self.register("test", LayoutParserRTDETRv2Config, RTDETRv2)
+
+    catalog = Catalog()
+    assert catalog.list_model() == ["test"]
+    with pytest.raises(ValueError):
+        catalog.get("dummy")
+    with pytest.raises(ValueError):
+        catalog.register("test", None, None)
+
+    class Module(base.BaseModule):
+        model_catalog = Catalog()
+        calls = 0
+
+        def __init__(self):
+            super().__init__()
+
+        def __call__(self):
+            Module.calls += 1
+            return "ran"
+
+    module = Module()
+    module.load_model("test", None, from_pretrained=False)  # no weights exist offline: seeded synthetic draw, host side only
+    assert isinstance(module.model, RTDETRv2)
+    module.save_config(tmp_path / "config.yaml")
+    assert load_yaml_config(tmp_path / "config.yaml").hf_hub_repo == LayoutParserRTDETRv2Config().hf_hub_repo
+    module.log_config()
+    module.catalog()
+    assert module() == "ran" and Module.calls == 1  # __call__ goes through the observer wrapper and still returns
+
+    class Invalid(base.BaseModule):
+        def __init__(self):
+            super().__init__()
+
+    with pytest.raises(NotImplementedError):
+        Invalid()
+    with pytest.raises(Exception):
+        module.device = "cpu"  # the MI355X path has no CPU fallback
