@@ -65,3 +65,15 @@ def test_configs_must_be_dicts():
     for cls in (OCR, LayoutAnalyzer, DocumentAnalyzer):
         with pytest.raises(ValueError):
             cls(configs="not-a-dict")
+
+
+def test_missing_config_file_is_reported_before_anything_is_built():
+    """tests/test_document_analyzer.py::test_invalid_path, tests/test_ocr.py::test_ocr_invalid_path of the reference."""
+    from yomitoku_amd.document_analyzer import OCR, DocumentAnalyzer, LayoutAnalyzer
+
+    with pytest.raises(FileNotFoundError):
+        DocumentAnalyzer(configs={"ocr": {"text_detector": {"path_cfg": "tests/yaml/dummy.yaml"}}})
+    with pytest.raises(FileNotFoundError):
+        OCR(configs={"text_detector": {"path_cfg": "tests/yaml/dummy.yaml"}})
+    with pytest.raises(FileNotFoundError):
+        LayoutAnalyzer(configs={"layout_parser": {"path_cfg": "tests/yaml/dummy.yaml"}})

@@ -201,3 +201,33 @@ def test_document_analyzer_end_to_end(dev, page):
     assert again.model_dump() == results.model_dump()
     orders = sorted([p.order for p in results.paragraphs] + [t.order for t in results.tables] + [f.order for f in results.figures])
     assert orders == list(range(len(orders)))
+
+
+def test_nested_configs_reach_the_modules(dev, tmp_path):
+    """tests/test_document_analyzer.py::test_initialize and tests/test_ocr.py::test_ocr of the reference: per-module YAML
+    overrides given through the nested `configs` dict land in the right module (on the cuda device instead of "cpu")."""
+    import torch
+
+    from yomitoku_amd.document_analyzer import OCR, DocumentAnalyzer
+
+    files = {}
+    for name, text in (("text_detector", "post_process:\n  thresh: 0.4\n"), ("text_recognizer", "refine_iters: 0\n"),
+                       ("layout_parser", "thresh_score: 0.8\n"), ("table_structure_recognizer", "thresh_score: 0.8\n")):
+        files[name] = tmp_path / f"{name}.yaml"
+        files[name].write_text(text)
+    lite = {"from_pretrained": False}
+    configs = {
+        "ocr": {"text_detector": {"path_cfg": str(files["text_detector"]), **lite},
+                "text_recognizer": {"path_cfg": str(files["text_recognizer"]), "model_name": "parseq-tiny-dynw-v4", **lite}},
+        "layout_analyzer": {"layout_parser": {"path_cfg": str(files["layout_parser"]), **lite},
+                            "table_structure_recognizer": {"path_cfg": str(files["table_structure_recognizer"]), **lite}},
+    }
+    an = DocumentAnalyzer(configs=configs, device="cuda:0", visualize=False)
+    for module in (an.text_detector, an.text_recognizer, an.layout.layout_parser, an.layout.table_structure_recognizer):
+        assert torch.device(module.device) == torch.device("cuda:0") and module.visualize is False
+    assert an.text_detector.post_processor.thresh == 0.4
+    assert an.text_recognizer.model.refine_iters == 0
+    assert an.layout.layout_parser.thresh_score == 0.8
+    assert an.layout.table_structure_recognizer.thresh_score == 0.8
+    ocr = OCR(configs=configs["ocr"], device="cuda:0")
+    assert ocr.detector.post_processor.thresh == 0.4 and ocr.recognizer.model.refine_iters == 0
