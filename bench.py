@@ -324,6 +324,7 @@ def main():
         if rank == 0:
             print(json.dumps(line), flush=True)
         if world > 1:
+            torch.distributed.barrier()  # rank 0 is still in its roofline / CPU legs: the others wait here, not in teardown
             torch.distributed.destroy_process_group()
         return
 
@@ -513,6 +514,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if world > 1:
+        torch.distributed.barrier()  # rank 0 is still in its roofline leg: the others wait here, not in teardown
         torch.distributed.destroy_process_group()
 
 
