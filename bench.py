@@ -430,6 +430,8 @@ def main():
         torch.cuda.synchronize()
         ms, fl, ln = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
         _lib.check(lib.ymk_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(ln)))
+        alg_bytes = ctypes.c_double()
+        _lib.check(lib.ymk_prof_bytes(ctypes.byref(alg_bytes)))
         if ms.value > 0:
             achieved = fl.value / (ms.value * 1e-3) / 1e12
             roof = {
@@ -440,11 +442,20 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": None,
+                "algorithmic_bytes_per_launch": int(alg_bytes.value // max(1, ln.value)),
                 "launches_per_page": int(ln.value // units),
                 "avg_launch_us": round(ms.value * 1e3 / max(1, ln.value), 2),
                 "kernel_ms_per_page": round(ms.value / units, 3),
                 "gflop_per_page": round(fl.value / units / 1e9, 1),
             }
+        pmc = os.path.join(ROOT, "profiles", f"r01_{args.workload}_pmc_conv_traffic.json")
+        if roof is not None and os.path.exists(pmc):
+            # HBM bytes per conv launch from the PMC passes of this same workload (rocprofv3 cannot run inside bench.py:
+            # profiles/README.md has the commands); compare with algorithmic_bytes_per_launch
+            with open(pmc) as f:
+                t = json.load(f)
+            roof["traffic"] = t["hbm_bytes_per_launch"]
+            roof["traffic_source"] = os.path.relpath(pmc, ROOT)
         if args.workload == "analyzer" and roof is not None:
             # the north star quotes MFMA utilisation "on DBNet conv": the same measurement over the detector's launches alone
             det = solo.analyzer.text_detector

@@ -57,8 +57,9 @@ int ymk_dbnet_forward(ymk_model* m, const float* x_dev, int n, int h, int w, flo
  * batches of TextRecognizer._collate, text_recognizer.py:146-156); logits_dev: fp32
  * [b][max_label_length+1][num_tokens-2] (always allocate the full 101 rows); *out_len receives the
  * number of valid rows per sample (101 when refine_iters >= 1, else the AR steps executed),
- * *ar_steps the greedy steps executed before every row held an <eos>.  Synchronises the stream
- * once per AR step (the reference's own early-stop test, models/parseq.py:245-250). */
+ * *ar_steps the greedy steps executed before every row held an <eos>.  The call blocks until the AR loop
+ * has stopped (the host polls a mapped flag two steps behind the device - the reference's early-stop test,
+ * models/parseq.py:245-250) and returns with the refinement pass still queued on the stream. */
 int ymk_parseq_dims(ymk_model* m, int* num_steps, int* num_classes);
 int ymk_parseq_forward(ymk_model* m, const float* x_dev, int b, int w, float* logits_dev, int* out_len, int* ar_steps,
                        void* stream);
@@ -114,9 +115,11 @@ int ymk_db_postprocess(const float* prob_host, int h, int w, float thresh, float
 /* ---- measurement aid for bench.py (not on the product path): between begin/end every launch of
  * the implicit-GEMM convolution kernel is bracketed by HIP events on its own stream; end returns
  * the summed kernel time, the algorithmic FLOPs (2*M*Cout*KH*KW*Cin, unpadded) and launch count.
- * Single-threaded use only. */
+ * ymk_prof_bytes: algorithmic HBM bytes of the launches since the last begin (input view + weights + output
+ * [+ residual], each counted once) - what the PMC traffic of the same launches is compared with. */
 int ymk_prof_begin(void);
 int ymk_prof_end(double* conv_ms, double* conv_flop, int64_t* conv_launches);
+int ymk_prof_bytes(double* conv_bytes);
 
 /* ---- single operators (exported for the parity tests; same kernels the models use) -----
  * NHWC fp32 tensors; weight in PyTorch OIHW order on the host. */

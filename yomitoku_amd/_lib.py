@@ -54,6 +54,7 @@ SIGNATURES = {
     ),
     "ymk_prof_begin": (c_int, []),
     "ymk_prof_end": (c_int, [POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
+    "ymk_prof_bytes": (c_int, [POINTER(c_double)]),
     "ymk_op_conv2d": (
         c_int,
         [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,

@@ -14,6 +14,7 @@ void rtdetr_forward(Model* m, const float* x, int B, int H, int W, float* logits
 void row_maxprob(hipStream_t s, const float* logits, int rows, int C, int* ids, float* probs);
 void prof_begin();
 void prof_end(double* ms, double* flop, int64_t* launches);
+double prof_bytes();
 }  // namespace ymk
 
 struct ymk_model {
@@ -150,6 +151,13 @@ int ymk_prof_end(double* conv_ms, double* conv_flop, int64_t* conv_launches) {
   YMK_API_BEGIN
   YMK_CHECK(conv_ms && conv_flop && conv_launches, "null argument");
   ymk::prof_end(conv_ms, conv_flop, conv_launches);
+  YMK_API_END
+}
+
+int ymk_prof_bytes(double* conv_bytes) {
+  YMK_API_BEGIN
+  YMK_CHECK(conv_bytes, "null argument");
+  *conv_bytes = ymk::prof_bytes();
   YMK_API_END
 }
 

@@ -474,6 +474,7 @@ struct ProfState {
   std::deque<std::pair<hipEvent_t, hipEvent_t>> ev;  // deque: a span's pointer stays valid while others are added
   size_t used = 0;
   double flop = 0.0;
+  double bytes = 0.0;  // algorithmic HBM bytes: input view, weights, output and residual, each touched once
   std::vector<std::string> desc;
   std::vector<double> lflop;
 };
@@ -495,6 +496,11 @@ void prof_begin() {
   g_prof.on = true;
   g_prof.used = 0;
   g_prof.flop = 0.0;
+  g_prof.bytes = 0.0;
+}
+double prof_bytes() {
+  std::lock_guard<std::mutex> lock(g_prof.mu);
+  return g_prof.bytes;
 }
 void prof_end(double* ms, double* flop, int64_t* launches) {
   std::lock_guard<std::mutex> lock(g_prof.mu);
@@ -529,6 +535,11 @@ static std::pair<hipEvent_t, hipEvent_t>* prof_open(hipStream_t s, const ConvK& 
     const int creal = k.mode == 0 ? k.C : 3;
     const double fl = 2.0 * (double)k.M * (double)k.Cout * (double)(k.KH * k.KW * creal);
     g_prof.flop += fl;
+    {
+      const double images = (double)k.M / ((double)k.OH * k.OW);
+      const double outs = (double)k.M * k.Cout * (k.epi == EPI_DECONV2X2 ? 1.0 : 1.0);
+      g_prof.bytes += 4.0 * (images * k.H * k.W * creal + (double)k.Cout * k.KH * k.KW * creal + outs * (k.res ? 2.0 : 1.0));
+    }
     char buf[160];
     snprintf(buf, sizeof buf, "M=%7d Cin=%4d Cout=%4d k=%dx%d s=%d d=%d tile=%dx%d ksplit=%d grid=%d", k.M, k.C, k.Cout, k.KH,
              k.KW, k.stride, k.dil, BM, BN, ksplit, grid);
