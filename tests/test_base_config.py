@@ -110,3 +110,44 @@ def test_catalog_and_module_contract(tmp_path):
         Invalid()
     with pytest.raises(Exception):
         module.device = "cpu"  # the MI355X path has no CPU fallback
+
+
+def test_pretrained_weights_resolution(tmp_path, monkeypatch):
+    """from_pretrained: a local directory, then the Hugging Face hub cache (offline), then a loud error."""
+    import torch
+    from safetensors.torch import save_file
+
+    from yomitoku_amd.nets import load_safetensors_dir
+
+    local = tmp_path / "weights"
+    local.mkdir()
+    save_file({"a.weight": torch.arange(6, dtype=torch.float32).reshape(2, 3)}, str(local / "model.safetensors"))
+    sd = load_safetensors_dir(str(local))
+    assert list(sd) == ["a.weight"] and sd["a.weight"].shape == (2, 3)
+    # hub cache layout: models--<org>--<name>/{refs/main, snapshots/<rev>/model.safetensors}
+    hub = tmp_path / "hf" / "hub" / "models--SomeOrg--some-model"
+    (hub / "refs").mkdir(parents=True)
+    (hub / "refs" / "main").write_text("abc123")
+    snap = hub / "snapshots" / "abc123"
+    snap.mkdir(parents=True)
+    save_file({"b.bias": torch.ones(4)}, str(snap / "model.safetensors"))
+    monkeypatch.setenv("HF_HOME", str(tmp_path / "hf"))
+    monkeypatch.setenv("HF_HUB_CACHE", str(tmp_path / "hf" / "hub"))
+    monkeypatch.setenv("HF_HUB_OFFLINE", "1")
+    import importlib
+
+    import huggingface_hub.constants as hc
+
+    importlib.reload(hc)
+    try:
+        import huggingface_hub.file_download as fd
+
+        importlib.reload(fd)
+        sd = load_safetensors_dir("SomeOrg/some-model")
+        assert list(sd) == ["b.bias"]
+        with pytest.raises(FileNotFoundError, match="pretrained weights not found"):  # offline mode: no network attempt
+            load_safetensors_dir("SomeOrg/missing-model")
+    finally:
+        monkeypatch.undo()
+        importlib.reload(hc)
+        importlib.reload(fd)

@@ -24,17 +24,30 @@ def _require_cuda(t: torch.Tensor, what: str):
 
 
 def load_safetensors_dir(repo_or_dir: str) -> "OrderedDict[str, torch.Tensor]":
-    """Offline counterpart of PyTorchModelHubMixin.from_pretrained (base.py:84): `repo_or_dir`
-    must be a local directory holding model.safetensors (what `yomitoku_download_model` writes)."""
-    path = os.path.join(repo_or_dir, "model.safetensors")
-    if not os.path.isfile(path):
-        raise FileNotFoundError(
-            f"{path} not found: pretrained weights must be available locally (no network); "
-            "pass from_pretrained=False for seeded synthetic weights"
-        )
+    """Counterpart of PyTorchModelHubMixin.from_pretrained (base.py:84): `repo_or_dir` is a local directory holding
+    model.safetensors, or a Hugging Face repo id resolved through the hub cache first (what a previous
+    `yomitoku_download_model` / reference run left in ~/.cache/huggingface) and the network last."""
     from safetensors.torch import load_file
 
-    return OrderedDict(load_file(path))
+    path = os.path.join(repo_or_dir, "model.safetensors")
+    if os.path.isfile(path):
+        return OrderedDict(load_file(path))
+    tried = [path]
+    if not os.path.isabs(repo_or_dir) and repo_or_dir.count("/") == 1:
+        try:
+            from huggingface_hub import hf_hub_download
+        except ImportError:  # pragma: no cover - huggingface_hub ships with the image
+            hf_hub_download = None
+        if hf_hub_download is not None:
+            for offline in (True, False):
+                try:
+                    return OrderedDict(load_file(hf_hub_download(repo_or_dir, "model.safetensors", local_files_only=offline)))
+                except Exception as exc:  # noqa: BLE001 - cache miss / no network: report both below
+                    tried.append(f"hub {'cache' if offline else 'download'} of {repo_or_dir}: {type(exc).__name__}")
+    raise FileNotFoundError(
+        "pretrained weights not found (" + "; ".join(tried) + "): place model.safetensors in a local directory and point "
+        "`hf_hub_repo` at it, or pass from_pretrained=False for seeded synthetic weights"
+    )
 
 
 class HipNet:
