@@ -77,3 +77,17 @@ def test_missing_config_file_is_reported_before_anything_is_built():
         OCR(configs={"text_detector": {"path_cfg": "tests/yaml/dummy.yaml"}})
     with pytest.raises(FileNotFoundError):
         LayoutAnalyzer(configs={"layout_parser": {"path_cfg": "tests/yaml/dummy.yaml"}})
+
+
+def test_import_paths_of_the_reference_resolve():
+    """from yomitoku import X / from yomitoku.ocr import OCR / from yomitoku.layout_analyzer import LayoutAnalyzer."""
+    import yomitoku_amd
+    from yomitoku_amd import document_analyzer
+    from yomitoku_amd.layout_analyzer import LayoutAnalyzer
+    from yomitoku_amd.ocr import OCR
+
+    assert OCR is document_analyzer.OCR and LayoutAnalyzer is document_analyzer.LayoutAnalyzer
+    for name in ("OCR", "LayoutParser", "TableStructureRecognizer", "TextDetector", "TextRecognizer", "LayoutAnalyzer",
+                 "DocumentAnalyzer"):
+        assert getattr(yomitoku_amd, name).__name__ == name
+    assert isinstance(yomitoku_amd.__version__, str)

@@ -8,6 +8,8 @@ Importing the package does not load the HIP library; the first module constructi
 (`yomitoku_amd._lib.load()` raises if libymk_hip.so has not been built - there is no CPU fallback).
 """
 
+__version__ = "0.1.0"
+
 __all__ = ["DocumentAnalyzer", "OCR", "LayoutAnalyzer", "TextDetector", "TextRecognizer", "LayoutParser",
            "TableStructureRecognizer"]
 
