@@ -88,3 +88,42 @@ def test_max_candidates_keeps_the_newest_borders():
     q, _ = run_cpp(pred, pred.shape, 2, 0.3, 0.4, 3, 3.5)
     rq, _ = db_postprocess(pred, pred.shape, 2, 0.3, 0.4, 3, 3.5)
     assert q == rq and len(q) <= 3
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_cpp_matches_oracle_on_noise_fields(seed):
+    """Organic shapes: thresholded smooth noise gives blobs with concavities, holes, one-pixel bridges and diagonal
+    (8-connected) joints - the cases that separate a correct border follower from an almost correct one."""
+    from oracle.cvlike import db_postprocess
+
+    rng = np.random.default_rng(1000 + seed)
+    h, w = int(rng.integers(40, 110)), int(rng.integers(48, 140))
+    field = _blur(_blur(rng.random((h, w)).astype(np.float32), 7), 5)
+    field = (field - field.min()) / (field.max() - field.min() + 1e-9)
+    pred = np.clip(field * 1.15 - 0.1 + (rng.random((h, w)) > 0.997) * 0.7, 0, 1).astype(np.float32)
+    params = (1, float(rng.uniform(0.35, 0.6)), float(rng.uniform(0.3, 0.6)), 1500, float(rng.uniform(1.2, 4.0)))
+    size = (int(h * rng.uniform(1.0, 3.0)), int(w * rng.uniform(1.0, 3.0)))
+    ref_q, ref_s = db_postprocess(pred, size, *params)
+    q, s = run_cpp(pred, size, *params)
+    assert q == ref_q
+    assert np.allclose(s, ref_s, rtol=0, atol=1e-9)
+
+
+def test_candidate_cap_and_degenerate_shapes():
+    from oracle.cvlike import db_postprocess
+
+    pred = np.zeros((120, 200), dtype=np.float32)
+    for i, (y, x) in enumerate((yy, xx) for yy in range(4, 110, 12) for xx in range(4, 190, 16)):
+        pred[y : y + 6, x : x + 10] = 0.9  # 108 separate blobs
+    for cap in (1500, 40, 1):
+        q, s = run_cpp(pred, (240, 400), 2, 0.3, 0.4, cap, 2.0)
+        rq, rs = db_postprocess(pred, (240, 400), 2, 0.3, 0.4, cap, 2.0)
+        assert q == rq and np.allclose(s, rs)
+        assert len(q) <= cap
+    thin = np.zeros((30, 60), dtype=np.float32)
+    thin[10, 5:50] = 0.9   # one pixel high
+    thin[15:28, 55] = 0.9  # one pixel wide
+    thin[3, 3] = 0.9       # a single pixel
+    q, s = run_cpp(thin, (30, 60), 1, 0.3, 0.1, 1500, 2.0)
+    rq, rs = db_postprocess(thin, (30, 60), 1, 0.3, 0.1, 1500, 2.0)
+    assert q == rq and np.allclose(s, rs)
