@@ -518,7 +518,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "pages_per_step_per_gpu": args.pages,
-                       "parallelism": f"page-sharded x{world} GPU(s), {n_procs} process(es) x {args.workers} pages in flight per GPU",
+                       "parallelism": (f"page-sharded x{world} GPU(s), {n_procs} process(es) x {args.workers} pages in flight per GPU"
+                                       if args.workload == "analyzer" else f"page-sharded x{world} GPU(s), one batch of {args.pages} per forward"),
                        "checkpoints": "seeded synthetic (no network)", **extra},
             "roofline": roof,
             "cpu_baseline": cpu,
