@@ -41,6 +41,24 @@ import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 
+# YMK_BENCH_DRY=1: CPU rehearsal of the ORCHESTRATION only (ranks over gloo, helper processes, step barriers, the
+# max-over-ranks clock, teardown) with stub page workers from tests/bench_dry_stubs.py - what tests/test_bench_dry.py
+# runs at world size 2, since multi-GPU boxes are the driver's.  It does no GPU work and its line says "dry_run".
+DRY = os.environ.get("YMK_BENCH_DRY") == "1"
+
+
+def rank_device(local_rank):
+    if DRY:
+        return torch.device("cpu")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    return device
+
+
+def device_sync():
+    if not DRY:
+        torch.cuda.synchronize()
+
 LITE_CONFIGS = {
     "ocr": {
         "text_detector": {"from_pretrained": False},
@@ -183,16 +201,15 @@ def _helper_init(local_rank, sds, shares, workers, index):
     from yomitoku_amd.parallel import PageParallel
 
     sds = {k: {name: torch.from_numpy(a) for name, a in sd.items()} for k, sd in sds.items()}
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+    device = rank_device(local_rank)
     pages = make_pages(shares[index], device)
     pool = PageParallel(lambda i: build_analyzer(device, sds), n_workers=workers)
     pool.map(pages[:workers])  # first-call allocations happen before the parent starts its clock
-    torch.cuda.synchronize()
+    device_sync()
 
     def step(_payload):
         pool.map(pages)
-        torch.cuda.synchronize()
+        device_sync()
         return len(pages)
 
     return step
@@ -312,11 +329,10 @@ def main():
     from yomitoku_amd import imaging
     from yomitoku_amd.parallel import PageParallel
 
-    rank, local_rank, world = ydist.init()
+    rank, local_rank, world = ydist.init("gloo" if DRY else None)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+    assert DRY or torch.cuda.is_available(), "bench.py needs a HIP device"
+    device = rank_device(local_rank)
     lib = _lib.load()
 
     if args.workload == "recognizer":
@@ -357,7 +373,7 @@ def main():
             if helpers:
                 helpers.start([None] * len(helpers))
             out = pool.map(pages)[-1]
-            torch.cuda.synchronize()
+            device_sync()
             if helpers:
                 assert sum(helpers.finish()) + len(pages) == args.pages
             return out
@@ -384,17 +400,17 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    device_sync()
     if world > 1:
         torch.distributed.barrier()
-    torch.cuda.synchronize()
+    device_sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
-    torch.cuda.synchronize()
+    device_sync()
     if world > 1:
         torch.distributed.barrier()
-    torch.cuda.synchronize()
+    device_sync()
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -408,7 +424,7 @@ def main():
     # ---- roofline leg: per-launch HIP events around the conv kernel.  The event bookkeeping is
     # single-threaded, so this pass walks the pages serially with ONE analyzer and ONE worker thread.
     roof = None
-    if rank == 0:
+    if rank == 0 and not DRY:
         if args.workload == "analyzer":
             from concurrent.futures import ThreadPoolExecutor
 
@@ -468,7 +484,7 @@ def main():
             roof["dbnet_conv"] = {"achieved": round(d_ach, 2), "frac": round(d_ach / FP32_MFMA_PEAK_TFLOPS, 4),
                                   "launches_per_page": int(ln.value // 4), "kernel_ms_per_page": round(ms.value / 4, 3),
                                   "gflop_per_page": round(fl.value / 4 / 1e9, 1)}
-        if args.workload == "analyzer":
+        if args.workload == "analyzer" and not DRY:
             st = solo.analyzer.stats
             extra["measured_units_per_page"] = {
                 "ar_steps_last_batch": int(solo.analyzer.text_recognizer.model.last_ar_steps),
@@ -479,7 +495,7 @@ def main():
 
     # ---- CPU baseline leg (rank 0, N=1): oracle chain on the host cores, bounded sample
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not DRY:
         t1 = time.perf_counter()
         n_cpu = 0
         if args.workload == "analyzer":
@@ -524,11 +540,19 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        if DRY:
+            line["dry_run"] = True
+            line["metric"] = "DRY RUN - orchestration rehearsal with stub page workers, not a measurement"
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()  # rank 0 is still in its roofline leg: the others wait here, not in teardown
         torch.distributed.destroy_process_group()
 
+
+if DRY:  # stub page workers / pages / checkpoints for the CPU rehearsal (also in the spawned helper processes)
+    from tests import bench_dry_stubs
+
+    bench_dry_stubs.install(globals())
 
 if __name__ == "__main__":
     main()
