@@ -91,3 +91,37 @@ def test_import_paths_of_the_reference_resolve():
                  "DocumentAnalyzer"):
         assert getattr(yomitoku_amd, name).__name__ == name
     assert isinstance(yomitoku_amd.__version__, str)
+
+
+def test_aggregate_accounts_for_every_word_on_a_full_size_page():
+    """Property at BASELINE page scale (1600x1200, ~80 lines, ruled tables): after aggregation every recognised word
+    is in exactly one place - a table cell, a paragraph, or on its own - and paragraph ranks are a permutation."""
+    from yomitoku_amd import document_analyzer as da
+    from yomitoku_amd import schemas as sch
+    from yomitoku_amd.utils.synth import synthetic_page_with_truth
+
+    for seed in (0, 5, 9):
+        img, quads, tables, paragraphs = synthetic_page_with_truth(seed)
+        words = [sch.WordPrediction(points=[[int(a), int(b)] for a, b in q], content=f"w{i}", direction="horizontal",
+                                    rec_score=0.9, det_score=0.9) for i, q in enumerate(quads)]
+        tabs = []
+        for x1, y1, x2, y2 in tables:
+            cells = [sch.TableCellSchema(col=c + 1, row=r + 1, col_span=1, row_span=1, contents=None,
+                                         box=[x1 + (x2 - x1) * c // 3, y1 + (y2 - y1) * r // 4, x1 + (x2 - x1) * (c + 1) // 3,
+                                              y1 + (y2 - y1) * (r + 1) // 4]) for r in range(4) for c in range(3)]
+            tabs.append(sch.TableStructureRecognizerSchema(box=[x1, y1, x2, y2], n_row=4, n_col=3, rows=[], cols=[], spans=[],
+                                                           cells=cells, order=0))
+        lay = sch.LayoutAnalyzerSchema(paragraphs=[sch.Element(id=None, box=list(b), score=1.0, role=None, contents=None)
+                                                   for b in paragraphs], tables=tabs, figures=[])
+        an = da.DocumentAnalyzer.__new__(da.DocumentAnalyzer)
+        an.reading_order, an.ignore_meta, an.ignore_ruby, an.ruby_threshold, an.img = "auto", False, False, 2.0, img
+        out = an.aggregate(sch.OCRSchema(words=words), lay)
+        placed = []
+        for t in out["tables"]:
+            for c in t.cells:
+                placed += [w for w in c.contents.split("\n") if w]
+        for p in out["paragraphs"]:
+            placed += p.contents.split("\n")
+        assert sorted(placed) == sorted(w.content for w in words)  # each word exactly once
+        ranks = sorted([p.order for p in out["paragraphs"]] + [t.order for t in out["tables"]])
+        assert ranks == list(range(len(ranks)))

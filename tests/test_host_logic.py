@@ -92,3 +92,26 @@ def test_quad_to_xyxy_and_filter():
 
     assert quad_to_xyxy([[5, 9], [40, 7], [41, 30], [4, 31]]) == (4, 7, 41, 31)
     assert filter_by_flag(["a", "b", "c"], [True, False, True]) == ["a", "c"]
+
+
+def test_reading_order_is_a_permutation_at_page_scale():
+    """Size-independent property at sizes far beyond the golden cases: every element gets a distinct rank 0..n-1,
+    whatever the layout, and ranking is a pure function of the boxes (second call, same answer)."""
+    import random
+
+    from yomitoku_amd.reading_order import prediction_reading_order
+
+    rng = random.Random(11)
+    for n in (2, 7, 64, 300):
+        for direction in ("top2bottom", "right2left", "left2right"):
+            boxes = []
+            for _ in range(n):
+                x, y = rng.randint(0, 1500), rng.randint(0, 2000)
+                boxes.append([x, y, x + rng.randint(2, 500), y + rng.randint(2, 90)])
+            els = [SimpleNamespace(box=list(b), order=0) for b in boxes]
+            prediction_reading_order(els, direction)
+            first = [e.order for e in els]
+            assert sorted(first) == list(range(n))
+            again = [SimpleNamespace(box=list(b), order=0) for b in boxes]
+            prediction_reading_order(again, direction)
+            assert [e.order for e in again] == first
