@@ -62,3 +62,23 @@ def test_golden_fixture(dev, nets):
     net = DBNet().load_state_dict(dbnet_state_dict(int(z["seed"]))).to(dev)
     out = net(torch.from_numpy(z["x"]).to(dev))["binary"].cpu().numpy()
     assert np.abs(out - z["prob"]).max() < PROB_TOL
+
+
+def test_full_size_page_matches_oracle(dev, nets):
+    """BASELINE.json's page size: a synthetic 1600x1200 page -> detector tensor 1x3x1600x1184 -> probability map,
+    the whole way through the product pre-processing, against the oracle chain (a few seconds of CPU)."""
+    from oracle.dbnet import dbnet_forward
+    from oracle.preprocess import detector_preprocess
+    from yomitoku_amd import imaging
+    from yomitoku_amd.utils.synth import synthetic_page
+
+    sd, net = nets
+    img = synthetic_page(21, 1600, 1200)
+    x = imaging.detector_tensor(imaging.page_to_device(img, dev), 1280, 1600)
+    assert tuple(x.shape) == (1, 3, 1600, 1184)
+    out = net(x)["binary"]
+    assert torch.equal(net(x)["binary"], out)  # same shape, same kernels: bit-identical
+    ref = dbnet_forward(sd, detector_preprocess(img))["binary"]
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < PROB_TOL, f"max |dP| = {err}"
+    assert 0.0 <= out.min().item() and out.max().item() <= 1.0
