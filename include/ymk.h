@@ -63,6 +63,15 @@ int ymk_dbnet_forward(ymk_model* m, const float* x_dev, int n, int h, int w, flo
 int ymk_parseq_dims(ymk_model* m, int* num_steps, int* num_classes);
 int ymk_parseq_forward(ymk_model* m, const float* x_dev, int b, int w, float* logits_dev, int* out_len, int* ar_steps,
                        void* stream);
+/* The same forward over n_groups mini-batches in ONE call (TextRecognizer's per-page mini-batches, of one page or of
+ * several: text_recognizer.py:158-203 runs them one after the other).  Group g is its own tensor x_dev[g]
+ * ([b[g]][3][32][w[g]], padded to ITS widest crop exactly as _collate does - padding columns are ordinary ViT tokens, so
+ * the groups are never re-padded to a common width); x_dev, b, w, out_len, ar_steps are HOST arrays of n_groups
+ * entries.  Every layer runs once over the token rows of all groups laid end to end, attention reads per-sample
+ * (row offset, length) tables, and one greedy loop serves all rows; logits_dev: [sum b][max_label_length+1][C] in
+ * group order.  out_len[g] / ar_steps[g] are what group g's own ymk_parseq_forward call would have returned. */
+int ymk_parseq_forward_groups(ymk_model* m, const float* const* x_dev, const int* b, const int* w, int n_groups,
+                              float* logits_dev, int* out_len, int* ar_steps, void* stream);
 /* what ParseqTokenizer.decode needs from softmax(logits) (parseq_tokenizer.py:79-87) without
  * materialising it: per row the arg-max class id and max probability. rows = b * out_len. */
 int ymk_parseq_token_stats(const float* logits_dev, int rows, int num_classes, int* ids_dev, float* probs_dev,

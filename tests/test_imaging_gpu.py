@@ -87,6 +87,30 @@ def test_recogniser_crops_match_oracle(dev, dynamic):
             assert (batch[slot, :, :, ref.shape[-1]:] == -1).all()
 
 
+def test_recogniser_crops_large_downscale(dev):
+    """Crops scaled down by more than the 24-tap table of the detector path (a ~900 px tall line, a 2000 px tall
+    vertical one, and the whole page as TextRecognizer(img, points=None) hands it over): uint8-exact vs the oracle."""
+    from oracle.preprocess import parseq_crop
+    from yomitoku_amd import imaging
+
+    img = _page(12, 2100, 1500)
+    h, w = img.shape[:2]
+    quads = [[[10, 20], [1480, 20], [1480, 925], [10, 925]],      # 905 px tall -> scale 28.3 on both axes
+             [[40, 30], [740, 30], [740, 2090], [40, 2090]],      # vertical: rotated, 2060 -> 800 wide, 700 -> 32 tall
+             [[0, 0], [w, 0], [w, h], [0, h]]]                    # the whole page
+    page = imaging.page_to_device(img, dev)
+    rgb = img[:, :, ::-1]
+    for dynamic in (False, True):
+        plans = imaging.plan_crops(img.shape[:2], quads, (32, 800), dynamic)
+        assert all(p is not None for p in plans)
+        batch = imaging.build_crop_batch(page, plans, 32, None if dynamic else 800).cpu()
+        for slot, plan in enumerate(plans):
+            ref, cw = parseq_crop(rgb, quads[plan.index], (32, 800), dynamic)
+            assert cw == plan.content_width
+            got = batch[slot, :, :, : ref.shape[-1]]
+            assert torch.equal(got, ref), f"crop {plan.index} differs: {(got - ref).abs().max().item()}"
+
+
 def test_invalid_quads_are_dropped():
     from yomitoku_amd import imaging
 

@@ -97,3 +97,82 @@ def test_matches_oracle_small_geometry(dev):
     assert net.last_ar_steps == steps and out.shape == ref.shape
     assert torch.equal(out.argmax(-1), ref.argmax(-1))
     assert (out - ref).abs().max().item() < LOGIT_TOL
+
+
+def _groups(seed, shapes):
+    from yomitoku_amd.utils.synth import synthetic_line_batch
+
+    return [synthetic_line_batch(seed + i, b, w) for i, (b, w) in enumerate(shapes)]
+
+
+@pytest.mark.parametrize("shapes", [[(5, 160), (2, 800), (9, 72), (1, 96)], [(3, 64), (3, 64)], [(4, 240)]])
+def test_grouped_forward_matches_oracle_and_single_calls(dev, shapes):
+    """ymk_parseq_forward_groups: several mini-batches, each with its own padded width, through one forward with one
+    greedy loop.  Per group: logits vs the oracle run on that group alone (1e-3, same arg-max), the step count the
+    group's own loop would have stopped at, and agreement with the single-group entry point."""
+    from oracle.parseq import parseq_forward
+    from yomitoku_amd.utils.synth import parseq_state_dict
+
+    sd = parseq_state_dict(1235, eos_bias=5.5)
+    ocfg, net = _net(dev, sd)
+    xs = _groups(11, shapes)
+    logits, out_lens, steps = net.forward_groups([x.to(dev) for x in xs])
+    lg = logits.cpu()
+    assert lg.shape[0] == sum(b for b, _ in shapes)
+    row = 0
+    for x, n, st in zip(xs, out_lens, steps):
+        ref, ref_steps = parseq_forward(sd, ocfg, x, return_steps=True)
+        got = lg[row : row + x.shape[0], :n]
+        assert st == ref_steps and got.shape == ref.shape
+        assert torch.equal(got.argmax(-1), ref.argmax(-1))
+        assert (got - ref).abs().max().item() < LOGIT_TOL
+        one = net(x.to(dev)).cpu()
+        assert net.last_ar_steps == st
+        assert torch.equal(one.argmax(-1), got.argmax(-1))
+        assert (one - got).abs().max().item() < 1e-4  # kernel shape choice follows M: last bits only
+        row += x.shape[0]
+    again, _, _ = net.forward_groups([x.to(dev) for x in xs])
+    assert torch.equal(again.cpu(), lg), "grouped forward must be bit-identical on repeat"
+
+
+def test_grouped_forward_open_beta_no_refine(dev):
+    """Per-op decoder path (D = 512) with ragged encoder memory, refine_iters = 0: each group returns the AR logits of
+    the steps ITS loop would have run, although the shared loop runs until the slowest group is done."""
+    from oracle.parseq import parseq_forward
+    from yomitoku_amd.utils.synth import parseq_state_dict
+
+    kw = dict(patch=(8, 8), enc_dim=512, dec_dim=512, num_tokens=7312, enc_depth=3)
+    sd = parseq_state_dict(77, eos_bias=6.0, **kw)
+    ocfg, net = _net(dev, sd, "parseq", enc_depth=3, refine_iters=0)
+    xs = _groups(21, [(4, 224), (2, 96), (3, 400)])
+    logits, out_lens, steps = net.forward_groups([x.to(dev) for x in xs])
+    lg = logits.cpu()
+    row = 0
+    for x, n, st in zip(xs, out_lens, steps):
+        ref, ref_steps = parseq_forward(sd, ocfg, x, return_steps=True)
+        got = lg[row : row + x.shape[0], :n]
+        assert st == ref_steps and n == ref_steps and got.shape == ref.shape
+        assert (got - ref).abs().max().item() < LOGIT_TOL
+        row += x.shape[0]
+    print("open-beta grouped steps", steps)
+
+
+def test_grouped_forward_open_beta_refine(dev):
+    """Per-op decoder path with refinement (flash cross-attention over ragged memory, Lq = 101)."""
+    from oracle.parseq import parseq_forward
+    from yomitoku_amd.utils.synth import parseq_state_dict
+
+    kw = dict(patch=(8, 8), enc_dim=512, dec_dim=512, num_tokens=7312, enc_depth=2)
+    sd = parseq_state_dict(79, eos_bias=6.0, **kw)
+    ocfg, net = _net(dev, sd, "parseq", enc_depth=2)
+    xs = _groups(31, [(3, 160), (2, 640)])
+    logits, out_lens, steps = net.forward_groups([x.to(dev) for x in xs])
+    lg = logits.cpu()
+    row = 0
+    for x, n, st in zip(xs, out_lens, steps):
+        ref, ref_steps = parseq_forward(sd, ocfg, x, return_steps=True)
+        got = lg[row : row + x.shape[0], :n]
+        assert st == ref_steps and got.shape == ref.shape
+        assert torch.equal(got.argmax(-1), ref.argmax(-1))
+        assert (got - ref).abs().max().item() < LOGIT_TOL
+        row += x.shape[0]

@@ -102,25 +102,27 @@ def test_text_recognizer_source_downscale_and_orientation_fallback(dev, page):
     print("orientation fallback replaced", replaced, "of", len(quads))
 
 
-def test_text_recognizer_parallel_batches_equal_serial(dev, page):
-    """num_parallel_batches > 1 runs mini-batches on replica lanes concurrently; the result is the serial one."""
+def test_text_recognizer_pages_equal_single_calls(dev, page):
+    """recognize_pages: the mini-batches of several pages share PARSeq forwards; every page's strings, directions and
+    scores are those of its own __call__ (mini-batches never mix pages), also when a forward is split by the line cap."""
     from yomitoku_amd.text_recognizer import TextRecognizer
-    from yomitoku_amd.utils.synth import parseq_state_dict
+    from yomitoku_amd.utils.synth import parseq_state_dict, synthetic_page_with_truth
 
     img, quads, _ = page
+    img2, quads2, _, _ = synthetic_page_with_truth(7)
     sd = parseq_state_dict(1235, eos_bias=6.0)
-    outs = []
-    for lanes in (1, 3):
-        rec = TextRecognizer(model_name="parseq-tiny-dynw-v4", from_pretrained=False, device="cuda:0", dynamic_width=True,
-                             batch_bucketing=True, num_parallel_batches=lanes)
-        rec.model.load_state_dict(sd)
-        rec._cfg.data.max_batch_size = 8  # several mini-batches out of ~50 lines
-        res, _ = rec(img, quads)
-        res2, _ = rec(img, quads)  # lanes are reused
-        assert res.contents == res2.contents and res.scores == res2.scores
-        outs.append(res)
-    assert outs[0].contents == outs[1].contents
-    assert outs[0].scores == outs[1].scores and outs[0].directions == outs[1].directions
+    rec = TextRecognizer(model_name="parseq-tiny-dynw-v4", from_pretrained=False, device="cuda:0", dynamic_width=True,
+                         batch_bucketing=True, num_parallel_batches=3)
+    rec.model.load_state_dict(sd)
+    rec._cfg.data.max_batch_size = 8  # several mini-batches per page
+    singles = [rec(i, q)[0] for i, q in ((img, quads), (img2, quads2), (img, quads[:1]))]
+    for cap in (1024, 20):
+        rec.MAX_LINES_PER_FORWARD = cap
+        multi = rec.recognize_pages([img, img2, img], [quads, quads2, quads[:1]])
+        for a, b in zip(singles, multi):
+            assert a.contents == b.contents and a.directions == b.directions and a.points == b.points
+            assert np.allclose(a.scores, b.scores, rtol=1e-4, atol=1e-7)
+    assert rec.recognize_pages([], []) == []
 
 
 def test_layout_and_table_stages(dev, page):

@@ -28,6 +28,8 @@ SIGNATURES = {
     "ymk_dbnet_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ymk_parseq_dims": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     "ymk_parseq_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, POINTER(c_int), POINTER(c_int), c_void_p]),
+    "ymk_parseq_forward_groups": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int), POINTER(c_int), c_int, c_void_p, POINTER(c_int),
+                                          POINTER(c_int), c_void_p]),
     "ymk_parseq_token_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ymk_rtdetr_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ymk_det_preprocess": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -7,6 +7,8 @@ namespace ymk {
 const std::string& last_error();
 void dbnet_forward(Model* m, const float* x, int n, int h, int w, float* prob, hipStream_t s);
 void parseq_forward(Model* m, const float* x, int B, int W, float* logits, int* out_len, int* ar_steps, hipStream_t s);
+void parseq_forward_groups(Model* m, const float* const* x, const int* b, const int* w, int ng, float* logits, int* out_len,
+                           int* ar_steps, hipStream_t s);
 void parseq_dims(Model* m, int* num_steps, int* num_classes);
 Model* create_parseq();
 Model* create_rtdetr();
@@ -121,6 +123,15 @@ int ymk_parseq_forward(ymk_model* m, const float* x_dev, int b, int w, float* lo
   YMK_CHECK(m && x_dev && logits_dev && out_len && ar_steps, "null argument");
   YMK_HIP(hipSetDevice(m->device));
   ymk::parseq_forward(m->impl, x_dev, b, w, logits_dev, out_len, ar_steps, (hipStream_t)stream);
+  YMK_API_END
+}
+
+int ymk_parseq_forward_groups(ymk_model* m, const float* const* x_dev, const int* b, const int* w, int n_groups,
+                              float* logits_dev, int* out_len, int* ar_steps, void* stream) {
+  YMK_API_BEGIN
+  YMK_CHECK(m && x_dev && b && w && logits_dev && out_len && ar_steps, "null argument");
+  YMK_HIP(hipSetDevice(m->device));
+  ymk::parseq_forward_groups(m->impl, x_dev, b, w, n_groups, logits_dev, out_len, ar_steps, (hipStream_t)stream);
   YMK_API_END
 }
 

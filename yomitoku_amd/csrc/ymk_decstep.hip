@@ -174,7 +174,9 @@ __device__ void attend(float4 qv, const float* __restrict__ base, size_t stride,
 
 __global__ __launch_bounds__(NT) void k_parseq_dec_step(DecStepW W, const int* __restrict__ tok, int ld_tok, int step,
                                                         float* __restrict__ skv, int NS, const float* __restrict__ memkv,
-                                                        int L, float* __restrict__ out, const int* __restrict__ prev_not_done) {
+                                                        int L, const int* __restrict__ mem_off,
+                                                        const int* __restrict__ mem_len, float* __restrict__ out,
+                                                        const int* __restrict__ prev_not_done) {
   if (prev_not_done && *prev_not_done == 0) return;  // speculative step after the batch finished
   __shared__ __attribute__((aligned(16))) float xa[DMAX], xb[DMAX], q[DMAX], kvcur[2 * DMAX], hid[FMAX], sc[HMAX * LMAX],
       part[4 * NT];
@@ -213,7 +215,9 @@ __global__ __launch_bounds__(NT) void k_parseq_dec_step(DecStepW W, const int* _
     matvec<ACT_NONE>(W.Wq_t, W.bq, xa, D, D, nullptr, xb, part);
     float4 qv = *reinterpret_cast<const float4*>(xb + ln * 4);
     qv.x *= scale; qv.y *= scale; qv.z *= scale; qv.w *= scale;
-    attend(qv, memkv + (size_t)b * L * 2 * D, (size_t)2 * D, L, D, H, sc, red, part, xa);
+    // encoder memory of this sample: row mem_off[b], mem_len[b] rows (ragged mini-batches), else b * L, L rows
+    const size_t mrow = mem_off ? (size_t)mem_off[b] : (size_t)b * L;
+    attend(qv, memkv + mrow * 2 * D, (size_t)2 * D, mem_len ? mem_len[b] : L, D, H, sc, red, part, xa);
     matvec<ACT_NONE>(W.Wo2_t, W.bo2, xa, D, D, q, q, part);  // each thread reads q[o] before it writes q[o]
   }
   // ---- feed forward
@@ -226,10 +230,11 @@ __global__ __launch_bounds__(NT) void k_parseq_dec_step(DecStepW W, const int* _
 }
 
 void parseq_dec_step(hipStream_t s, const DecStepW& W, const int* tok, int ld_tok, int step, float* skv, int NS,
-                     const float* memkv, int L, float* out, const int* prev_not_done, int B) {
+                     const float* memkv, int L, const int* mem_off, const int* mem_len, float* out, const int* prev_not_done,
+                     int B) {
   YMK_CHECK(parseq_dec_step_supported(W.D, W.H, W.F, L, NS), "fused decoder step: unsupported geometry");
-  hipLaunchKernelGGL(k_parseq_dec_step, dim3(B), dim3(NT), 0, s, W, tok, ld_tok, step, skv, NS, memkv, L, out,
-                     prev_not_done);
+  hipLaunchKernelGGL(k_parseq_dec_step, dim3(B), dim3(NT), 0, s, W, tok, ld_tok, step, skv, NS, memkv, L, mem_off, mem_len,
+                     out, prev_not_done);
   YMK_HIP(hipGetLastError());
 }
 

@@ -45,6 +45,43 @@ __device__ __forceinline__ void area_taps(int d, double scale, int ssize, Taps& 
     t.wt[t.n++] = (float)(fmin(fmin(fsx2 - sx2, 1.0), cell) / cell);
   }
 }
+// The same taps without the MAXT cap, for the recogniser crops (a tall text line or a whole page handed to
+// TextRecognizer is scaled down by far more than 22): tap i of n = left partial cell, the full cells, right partial
+// cell, in computeResizeAreaTab's order, so sums accumulate exactly as with the array form.
+struct AreaSpan {
+  int sx1, sx2, n;
+  int has_l, has_r;
+  float wl, wf, wr;
+  __device__ __forceinline__ void tap(int i, int& idx, float& wt) const {
+    if (i < has_l) {
+      idx = sx1 - 1;
+      wt = wl;
+    } else if (i - has_l < sx2 - sx1) {
+      idx = sx1 + (i - has_l);
+      wt = wf;
+    } else {
+      idx = sx2;
+      wt = wr;
+    }
+  }
+};
+__device__ __forceinline__ AreaSpan area_span(int d, double scale, int ssize) {
+  const double fsx1 = d * scale, fsx2 = fsx1 + scale;
+  const double cell = fmin(scale, ssize - fsx1);
+  AreaSpan a;
+  int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+  sx2 = min(sx2, ssize - 1);
+  sx1 = min(sx1, sx2);
+  a.sx1 = sx1;
+  a.sx2 = sx2;
+  a.has_l = sx1 - fsx1 > 1e-3 ? 1 : 0;
+  a.has_r = fsx2 - sx2 > 1e-3 ? 1 : 0;
+  a.wl = (float)((sx1 - fsx1) / cell);
+  a.wf = (float)(1.0 / cell);
+  a.wr = (float)(fmin(fmin(fsx2 - sx2, 1.0), cell) / cell);
+  a.n = a.has_l + (sx2 - sx1) + a.has_r;
+  return a;
+}
 // INTER_AREA used for enlarging = bilinear taps with the area coefficient rule
 __device__ __forceinline__ void linear_area_tap(int d, double scale, int ssize, int& s0, float& f) {
   const double inv = 1.0 / scale;
@@ -285,15 +322,19 @@ __global__ void k_crop_resize_norm(const CropDesc* __restrict__ descs, const uns
         else v[c] = fminf(fmaxf(rintf((float)sacc * (1.f / (float)(d.fast_x * d.fast_y))), 0.f), 255.f);
       }
     } else {
-      Taps tx, ty;
-      area_taps(x, (double)d.rw / d.nw, d.rw, tx);
-      area_taps(y, (double)d.rh / d.nh, d.rh, ty);
+      const AreaSpan tx = area_span(x, (double)d.rw / d.nw, d.rw);
+      const AreaSpan ty = area_span(y, (double)d.rh / d.nh, d.rh);
       float sum[3] = {0.f, 0.f, 0.f};
       for (int r = 0; r < ty.n; ++r) {
+        int yi, xi;
+        float wy, wx;
+        ty.tap(r, yi, wy);
         float buf[3] = {0.f, 0.f, 0.f};
-        for (int c2 = 0; c2 < tx.n; ++c2)
-          for (int c = 0; c < 3; ++c) buf[c] = buf[c] + px(ty.idx[r], tx.idx[c2], c) * tx.wt[c2];
-        for (int c = 0; c < 3; ++c) sum[c] = r == 0 ? ty.wt[r] * buf[c] : sum[c] + ty.wt[r] * buf[c];
+        for (int c2 = 0; c2 < tx.n; ++c2) {
+          tx.tap(c2, xi, wx);
+          for (int c = 0; c < 3; ++c) buf[c] = buf[c] + px(yi, xi, c) * wx;
+        }
+        for (int c = 0; c < 3; ++c) sum[c] = r == 0 ? wy * buf[c] : sum[c] + wy * buf[c];
       }
       for (int c = 0; c < 3; ++c) v[c] = fminf(fmaxf(rintf(sum[c]), 0.f), 255.f);  // saturate_cast<uchar>
     }

@@ -20,6 +20,11 @@ namespace ymk {
 
 void tile_rows(hipStream_t s, const float* src, int rows, int D, float* dst, int B);
 
+struct PGroup {
+  const float* x;
+  int B, W;
+};
+
 namespace {
 
 struct EncBlock {
@@ -165,32 +170,42 @@ class ParseqModel : public Model {
   ~ParseqModel() override {
     if (qmask_) (void)hipFree(qmask_);
     if (host_flags_) (void)hipHostFree(host_flags_);
+    if (stage_) (void)hipHostFree(stage_);
   }
 
   int num_classes() const { return C_; }
   int num_steps() const { return nsteps_; }
 
-  // x: device fp32 [B][3][img_h][W]; logits: device [B][nsteps][C]; returns rows valid per sample
-  void forward(const float* x, int B, int W, float* logits, int* out_len, int* ar_steps, hipStream_t s) {
+  // A forward over `ng` mini-batches at once ("groups": each keeps its own padded width, so the padding columns every
+  // crop sees are those of its own mini-batch).  Rows of a GEMM are independent, attention is per
+  // sample, so the groups share every launch: token rows are laid end to end, attention kernels read per-sample
+  // (offset, length) tables, and ONE greedy loop runs until every row of every group holds an <eos>.
+  // groups[g].x: device fp32 [B_g][3][img_h][W_g]; logits: device [sum B_g][nsteps][C];
+  // out_len[g] / ar_steps[g]: rows valid per sample / greedy steps of group g as its own loop would have run them.
+  void forward_groups(const PGroup* groups, int ng, float* logits, int* out_len, int* ar_steps, hipStream_t s) {
     YMK_CHECK(finalized, "model not finalized");
-    YMK_CHECK(B > 0 && W >= pw_ && W % pw_ == 0 && W <= img_w_, "parseq input width must be a multiple of the patch width, <= img_w");
-    const uint64_t key = ((uint64_t)B << 32) | (uint64_t)W;
+    YMK_CHECK(ng > 0, "parseq: no mini-batch");
+    uint64_t key = 1469598103934665603ull;
+    for (int g = 0; g < ng; ++g) {
+      YMK_CHECK(groups[g].x != nullptr && groups[g].B > 0 && groups[g].W >= pw_ && groups[g].W % pw_ == 0 && groups[g].W <= img_w_,
+                "parseq input width must be a multiple of the patch width, <= img_w");
+      key = (key ^ (((uint64_t)groups[g].B << 32) | (uint64_t)groups[g].W)) * 1099511628211ull;
+    }
     if (key != shape_key_) {
       arena.dry_run = true;
       arena.reset();
-      int a = 0, b2 = 0;
-      run(x, B, W, logits, &a, &b2, s);
+      run(groups, ng, logits, out_len, ar_steps, s);
       arena.dry_run = false;
       const size_t need = arena.used();
       arena.reset();
       if (need > arena.capacity()) {
         YMK_HIP(hipStreamSynchronize(s));
-        arena.reserve(need);
+        arena.reserve(need + need / 4);  // ragged workloads change shape every call: leave head room, grow rarely
       }
       shape_key_ = key;
     }
     arena.reset();
-    run(x, B, W, logits, out_len, ar_steps, s);
+    run(groups, ng, logits, out_len, ar_steps, s);
   }
 
  private:
@@ -201,18 +216,18 @@ class ParseqModel : public Model {
   // query-stream tail shared by the AR step and the refinement pass:
   //   q (in/out, [M][Dd]) already holds query + self-attention; adds cross attention and the FFN,
   //   then decoder.norm + head -> out rows (ld_out floats apart)
-  void stream_tail(hipStream_t s, float* q, int M, int B, int Lq, const float* memkv, int L, float* t, float* t2, float* h,
-                   float* out, int ld_out) {
+  void stream_tail(hipStream_t s, float* q, int M, int B, int Lq, const float* memkv, int L, const SeqTab* mem, float* t,
+                   float* t2, float* h, float* out, int ld_out) {
     const int D = Dd_, hd = D / dh_;
     const float scale = 1.f / std::sqrt((float)hd);
     ln(s, q, n1g_, n1b_, 1e-5f, t, M, D);
     gemm(s, t, M, D, D, ca_q_, ACT_NONE, nullptr, 0, t2, D);
     if (Lq >= 32)
       flash_attention(s, t2, memkv, memkv + D, t, B, dh_, Lq, L, hd, D, 2 * D, 2 * D, D, (long)Lq * D, (long)L * 2 * D,
-                      (long)L * 2 * D, (long)Lq * D, scale);
+                      (long)L * 2 * D, (long)Lq * D, scale, mem);
     else
       small_attention(s, t2, memkv, memkv + D, t, B, dh_, Lq, L, hd, D, 2 * D, 2 * D, D, (long)Lq * D, (long)L * 2 * D,
-                      (long)L * 2 * D, (long)Lq * D, scale, nullptr, 0, nullptr, 0);
+                      (long)L * 2 * D, (long)Lq * D, scale, nullptr, 0, nullptr, 0, mem);
     gemm(s, t, M, D, D, ca_o_, ACT_NONE, q, D, q, D);
     ln(s, q, n2g_, n2b_, 1e-5f, t, M, D);
     gemm(s, t, M, D, D, lin1_, ACT_GELU, nullptr, 0, h, lin1_.cout);
@@ -221,19 +236,31 @@ class ParseqModel : public Model {
     gemm(s, t, M, D, D, head_, ACT_NONE, nullptr, 0, out, ld_out);
   }
 
-  void run(const float* x, int B, int W, float* logits, int* out_len, int* ar_steps, hipStream_t s) {
+  void run(const PGroup* groups, int ng, float* logits, int* out_len, int* ar_steps, hipStream_t s) {
     const bool dry = arena.dry_run;
-    const int D = D_, gw = W / pw_, L = gh_ * gw, M = B * L, hd = D / eh_;
+    const int D = D_, hd = D / eh_;
     const int NS = nsteps_, C = C_;
+    // ---------------- geometry: token rows of the groups end to end, one (offset, length) pair per sample
+    int B = 0, M = 0, Lmax = 0;
+    size_t x4_max = 0;
+    for (int g = 0; g < ng; ++g) {
+      const int L = gh_ * (groups[g].W / pw_);
+      B += groups[g].B;
+      M += groups[g].B * L;
+      Lmax = std::max(Lmax, L);
+      x4_max = std::max(x4_max, (size_t)groups[g].B * img_h_ * groups[g].W * 4);
+    }
+    const bool ragged = ng > 1;
     // ---------------- encoder
-    Tensor x4 = arena.tensor(B, img_h_, W, 4);
-    Tensor tk = arena.tensor(B, gh_, gw, D);
+    float* x4buf = arena.alloc_f(x4_max);
+    float* xs = arena.alloc_f((size_t)M * D);  // [M][D] token stream, updated in place
     float* y = arena.alloc_f((size_t)M * D);
     float* qkv = arena.alloc_f((size_t)M * 3 * D);
     float* att = arena.alloc_f((size_t)M * D);
     float* hbuf = arena.alloc_f((size_t)M * blocks_[0].fc1.cout);
     float* mem = arena.alloc_f((size_t)M * D);
     float* memkv = arena.alloc_f((size_t)M * 2 * D);
+    int* tab = (int*)arena.alloc_bytes((size_t)2 * B * sizeof(int));  // [B] first token row | [B] token rows
     // ---------------- decoder buffers
     const int MR = B * NS;
     float* qsa = arena.alloc_f((size_t)NS * D);        // W_q(norm_q(pos_queries)) - shared by the batch
@@ -253,21 +280,55 @@ class ParseqModel : public Model {
     unsigned char* kpm = (unsigned char*)arena.alloc_bytes((size_t)MR);
     if (dry) return;
 
-    nchw3_to_nhwc4(s, x, B, img_h_, W, x4);
-    {
-      ConvArgs a;
-      a.stride = ph_;
-      a.stride_w = pw_;
-      conv2d(s, x4, patch_, a, tk);
+    SeqTab enc_tab, mem_tab;
+    if (ragged) {
+      // the tables travel through a pinned staging buffer owned by the model: a forward returns only after its
+      // greedy loop has been observed to finish, so the previous call's copy has long left the buffer
+      if ((size_t)8 * B > stage_cap_) {
+        if (stage_) YMK_HIP(hipHostFree(stage_));
+        stage_ = nullptr;
+        stage_cap_ = 0;
+        YMK_HIP(hipHostMalloc((void**)&stage_, (size_t)16 * B * sizeof(int), hipHostMallocDefault));
+        stage_cap_ = (size_t)16 * B;
+      }
+      int row = 0, b = 0;
+      for (int g = 0; g < ng; ++g) {
+        const int L = gh_ * (groups[g].W / pw_);
+        for (int i = 0; i < groups[g].B; ++i, ++b) {
+          stage_[b] = row;
+          stage_[B + b] = L;
+          row += L;
+        }
+      }
+      YMK_HIP(hipMemcpyAsync(tab, stage_, (size_t)2 * B * sizeof(int), hipMemcpyHostToDevice, s));
+      enc_tab.qoff = enc_tab.koff = mem_tab.koff = tab;
+      enc_tab.qlen = enc_tab.klen = mem_tab.klen = tab + B;
     }
-    float* xs = tk.p;  // [M][D] token stream, updated in place
-    add_pos_embed(s, xs, pos_embed_, B, gh_, gw, full_gw_, D);
+    const SeqTab* enc_t = ragged ? &enc_tab : nullptr;
+    const SeqTab* mem_t = ragged ? &mem_tab : nullptr;
+    const int L = Lmax;  // uniform length when not ragged
+
+    {
+      size_t row = 0;
+      for (int g = 0; g < ng; ++g) {
+        const int Bg = groups[g].B, W = groups[g].W, gw = W / pw_;
+        Tensor x4{x4buf, Bg, img_h_, W, 4, 4};
+        Tensor tk{xs + row * D, Bg, gh_, gw, D, D};
+        nchw3_to_nhwc4(s, groups[g].x, Bg, img_h_, W, x4);
+        ConvArgs a;
+        a.stride = ph_;
+        a.stride_w = pw_;
+        conv2d(s, x4, patch_, a, tk);
+        add_pos_embed(s, tk.p, pos_embed_, Bg, gh_, gw, full_gw_, D);
+        row += (size_t)Bg * gh_ * gw;
+      }
+    }
     const float scale = 1.f / std::sqrt((float)hd);
     for (const EncBlock& b : blocks_) {
       ln(s, xs, b.ln1g, b.ln1b, 1e-6f, y, M, D);
       gemm(s, y, M, D, D, b.qkv, ACT_NONE, nullptr, 0, qkv, 3 * D);
       flash_attention(s, qkv, qkv + D, qkv + 2 * D, att, B, eh_, L, L, hd, 3 * D, 3 * D, 3 * D, D, (long)L * 3 * D,
-                      (long)L * 3 * D, (long)L * 3 * D, (long)L * D, scale);
+                      (long)L * 3 * D, (long)L * 3 * D, (long)L * D, scale, enc_t);
       gemm(s, att, M, D, D, b.proj, ACT_NONE, xs, D, xs, D);
       ln(s, xs, b.ln2g, b.ln2b, 1e-6f, y, M, D);
       gemm(s, y, M, D, D, b.fc1, ACT_GELU, nullptr, 0, hbuf, b.fc1.cout);
@@ -279,17 +340,7 @@ class ParseqModel : public Model {
     gemm(s, mem, M, D, D, ca_kv_, ACT_NONE, nullptr, 0, memkv, 2 * D);
     ln(s, posq_, nqg_, nqb_, 1e-5f, t1, NS, D);
     gemm(s, t1, NS, D, D, sa_q_, ACT_NONE, nullptr, 0, qsa, D);
-    fill_i32(s, tok, pad_, (size_t)MR);
-    {
-      // tok[:, 0] = bos; state = {0, 0, -1, 0}
-      std::vector<int> st((size_t)B * 4, 0);
-      for (int b = 0; b < B; ++b) st[b * 4 + 2] = -1;
-      YMK_HIP(hipMemcpyAsync(state, st.data(), st.size() * sizeof(int), hipMemcpyHostToDevice, s));
-      std::vector<int> col((size_t)B, bos_);
-      YMK_HIP(hipMemcpy2DAsync(tok, (size_t)NS * sizeof(int), col.data(), sizeof(int), sizeof(int), B,
-                               hipMemcpyHostToDevice, s));
-      YMK_HIP(hipStreamSynchronize(s));  // host vectors go out of scope
-    }
+    init_decode(s, tok, NS, state, bos_, pad_, B);  // tok[:, 0] = bos, rest pad; state = {0, 0, -1, 0}
     const int dhd = D / dh_;
     const float dscale = 1.f / std::sqrt((float)dhd);
     // Early stop without stalling the queue: step i counts the rows still lacking an <eos> into
@@ -326,7 +377,7 @@ class ParseqModel : public Model {
         // the whole query stream of step i in one launch, then the vocabulary head as a GEMM
         DecStepW w = fw_;
         w.qsa = qsa;
-        parseq_dec_step(s, w, tok, NS, i, skv, NS, memkv, L, t1, prev, B);
+        parseq_dec_step(s, w, tok, NS, i, skv, NS, memkv, L, mem_tab.koff, mem_tab.klen, t1, prev, B);
         gemm(s, t1, B, D, D, head_, ACT_NONE, nullptr, 0, arlog + (size_t)i * C, NS * C);
       } else {
         // content row i (token tok[:, i]) -> norm_c -> K|V cache row i
@@ -336,7 +387,7 @@ class ParseqModel : public Model {
         small_attention(s, qsa + (size_t)i * D, skv, skv + D, t1, B, dh_, 1, i + 1, dhd, D, 2 * D, 2 * D, D, 0,
                         (long)NS * 2 * D, (long)NS * 2 * D, D, dscale, nullptr, 0, nullptr, 0);
         gemm(s, t1, B, D, D, sa_o_, ACT_NONE, posq_ + (size_t)i * D, 0, qcur, D);
-        stream_tail(s, qcur, B, B, 1, memkv, L, t1, t2, hdec, arlog + (size_t)i * C, NS * C);
+        stream_tail(s, qcur, B, B, 1, memkv, L, mem_t, t1, t2, hdec, arlog + (size_t)i * C, NS * C);
       }
       greedy_step(s, arlog + (size_t)i * C, (long)NS * C, C, i, NS, tok, raw, NS, state, eos_, rep_on_, rep_pmax_, rep_p1_,
                   rep_min_, not_done + i, i > 0 ? not_done + i - 1 : nullptr, arrived + i,
@@ -353,7 +404,23 @@ class ParseqModel : public Model {
           break;
         }
     }
-    *ar_steps = steps;
+    // per-group step counts: a group's own loop would have stopped once each of ITS rows held an <eos>
+    // (state[b][3] = steps after which row b did; 0 = never).  One copy, issued before the refinement is queued.
+    if (ng > 1) {
+      YMK_HIP(hipMemcpyAsync(stage_ + 4 * B, state, (size_t)B * 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+      YMK_HIP(hipStreamSynchronize(s));  // the stream is idle here: the loop above has seen the last real step finish
+      int b = 0;
+      for (int g = 0; g < ng; ++g) {
+        int sg = 0;
+        for (int i = 0; i < groups[g].B; ++i, ++b) {
+          const int e = stage_[4 * B + 4 * b + 3];
+          sg = std::max(sg, e > 0 ? e : NS);
+        }
+        ar_steps[g] = std::min(sg, steps);
+      }
+    } else {
+      ar_steps[0] = steps;
+    }
 
     if (refine_ > 0) {
       tile_rows(s, posq_, NS, D, posq_t, B);
@@ -371,14 +438,14 @@ class ParseqModel : public Model {
         small_attention(s, qsa, skv, skv + D, t1, B, dh_, NS, S_in, dhd, D, 2 * D, 2 * D, D, 0, (long)NS * 2 * D,
                         (long)NS * 2 * D, (long)NS * D, dscale, qmask_, NS, kpm, NS);
         gemm(s, t1, MR, D, D, sa_o_, ACT_NONE, posq_t, D, qcur, D);
-        stream_tail(s, qcur, MR, B, NS, memkv, L, t1, t2, hdec, logits, C);
+        stream_tail(s, qcur, MR, B, NS, memkv, L, mem_t, t1, t2, hdec, logits, C);
       }
       if (rep_on_) rep_cut(s, logits, (long)NS * C, C, NS, state, eos_, B);
-      *out_len = NS;
+      for (int g = 0; g < ng; ++g) out_len[g] = NS;
     } else {
       YMK_HIP(hipMemcpyAsync(logits, arlog, (size_t)MR * C * sizeof(float), hipMemcpyDeviceToDevice, s));
-      if (rep_on_) rep_cut(s, logits, (long)NS * C, C, steps, state, eos_, B);
-      *out_len = steps;
+      if (rep_on_) rep_cut(s, logits, (long)NS * C, C, steps, state, eos_, B);  // a cut lies before its row's <eos>
+      for (int g = 0; g < ng; ++g) out_len[g] = ar_steps[g];
     }
   }
 
@@ -396,6 +463,8 @@ class ParseqModel : public Model {
   unsigned char* qmask_ = nullptr;
   int* host_flags_ = nullptr;      // mapped pinned: (rows still open) + 1 per AR step
   int* host_flags_dev_ = nullptr;  // the same words as the device addresses them
+  int* stage_ = nullptr;           // pinned: ragged tables out (2B ints at 0), per-row decode state back (4B ints at 4B)
+  size_t stage_cap_ = 0;
   uint64_t shape_key_ = 0;
 };
 
@@ -406,7 +475,17 @@ Model* create_parseq() { return new ParseqModel(); }
 void parseq_forward(Model* m, const float* x, int B, int W, float* logits, int* out_len, int* ar_steps, hipStream_t s) {
   auto* p = dynamic_cast<ParseqModel*>(m);
   YMK_CHECK(p != nullptr, "model is not a parseq");
-  p->forward(x, B, W, logits, out_len, ar_steps, s);
+  const PGroup g{x, B, W};
+  p->forward_groups(&g, 1, logits, out_len, ar_steps, s);
+}
+void parseq_forward_groups(Model* m, const float* const* x, const int* b, const int* w, int ng, float* logits, int* out_len,
+                           int* ar_steps, hipStream_t s) {
+  auto* p = dynamic_cast<ParseqModel*>(m);
+  YMK_CHECK(p != nullptr, "model is not a parseq");
+  YMK_CHECK(ng > 0 && ng <= 4096, "parseq: 1..4096 mini-batches per call");
+  std::vector<PGroup> g((size_t)ng);
+  for (int i = 0; i < ng; ++i) g[i] = PGroup{x[i], b[i], w[i]};
+  p->forward_groups(g.data(), ng, logits, out_len, ar_steps, s);
 }
 void parseq_dims(Model* m, int* num_steps, int* num_classes) {
   auto* p = dynamic_cast<ParseqModel*>(m);

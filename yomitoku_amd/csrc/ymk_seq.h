@@ -8,13 +8,24 @@ void layernorm(hipStream_t s, const float* x, int ldx, int in_rows_mod, const fl
                float* y, int ldy, int M, int D);
 void add_pos_embed(hipStream_t s, float* x, const float* pos, int B, int gh, int gw, int full_gw, int D);
 
+// Ragged batches: device tables of per-sample row offsets and lengths.  A non-null (koff, klen) pair replaces the key /
+// value batch stride and Lk; a non-null (qoff, qlen) pair the query / output batch stride and Lq (then Lq / Lk passed
+// to the launcher are the maxima over the batch: they size the grid).
+struct SeqTab {
+  const int *qoff = nullptr, *qlen = nullptr, *koff = nullptr, *klen = nullptr;
+};
+
 // O[b, q, h*hd:(h+1)*hd] = softmax(scale * Q K^T) V   (no mask; keys 0..Lk-1)
 void flash_attention(hipStream_t s, const float* q, const float* k, const float* v, float* o, int B, int H, int Lq, int Lk,
-                     int hd, int ldq, int ldk, int ldv, int ldo, long bsq, long bsk, long bsv, long bso, float scale);
+                     int hd, int ldq, int ldk, int ldv, int ldo, long bsq, long bsk, long bsv, long bso, float scale,
+                     const SeqTab* tab = nullptr);
 // same contract plus boolean masks (non-zero = blocked), for few queries / short key lists
 void small_attention(hipStream_t s, const float* q, const float* k, const float* v, float* o, int B, int H, int Lq, int Lk,
                      int hd, int ldq, int ldk, int ldv, int ldo, long bsq, long bsk, long bsv, long bso, float scale,
-                     const unsigned char* mask_qk, int ld_mask, const unsigned char* kpm, int ld_kpm);
+                     const unsigned char* mask_qk, int ld_mask, const unsigned char* kpm, int ld_kpm,
+                     const SeqTab* tab = nullptr);
+// decode state at the start of a forward: tok[b][:] = pad, tok[b][0] = bos, state[b] = {0, 0, -1, 0}
+void init_decode(hipStream_t s, int* tok, int ld_tok, int* state, int bos_id, int pad_id, int B);
 
 void ctx_embed_ln(hipStream_t s, const int* tok, int ld_tok, int pos0, int npos, const float* emb, const float* posq,
                   const float* g, const float* be, float eps, float* out, int out_rows, int D, int B);

@@ -110,6 +110,10 @@ struct AttnP {
   long bsq, bsk, bsv, bso;         // batch strides (floats)
   int Lq, Lk, H;
   float scale;
+  // ragged batches (grouped PARSeq forward): per-sample row offsets / lengths replace the batch strides and Lq / Lk.
+  // koff/klen: keys and values of sample b start at row koff[b] and number klen[b]; qoff/qlen: the same for the
+  // queries and the output rows.  Null = the uniform strided form.
+  const int *qoff, *qlen, *koff, *klen;
 };
 
 // HD: head dim as laid out in LDS / the accumulators (a multiple of 32); HDR <= HD: the real head dim (a multiple of 8).
@@ -131,11 +135,26 @@ __global__ __launch_bounds__(256, 1) void k_flash_attn(AttnP p) {
   const float* qb = p.q + (size_t)b * p.bsq + h * HDR;
   const float* kb = p.k + (size_t)b * p.bsk + h * HDR;
   const float* vb = p.v + (size_t)b * p.bsv + h * HDR;
+  float* ob = p.o + (size_t)b * p.bso + h * HDR;
+  int Lq = p.Lq, Lk = p.Lk;
+  if (p.koff) {
+    const size_t r = (size_t)p.koff[b];
+    kb = p.k + r * p.ldk + h * HDR;
+    vb = p.v + r * p.ldv + h * HDR;
+    Lk = p.klen[b];
+  }
+  if (p.qoff) {
+    const size_t r = (size_t)p.qoff[b];
+    qb = p.q + r * p.ldq + h * HDR;
+    ob = p.o + r * p.ldo + h * HDR;
+    Lq = p.qlen[b];
+  }
+  if ((int)blockIdx.x * 128 >= Lq) return;  // block-uniform: the grid is sized for the longest sample
 
   // this lane's query row, pre-scaled: Q[q][kc*8 + 4*lh + s]
   f32x4 qf[NKC];
   {
-    const int qi = min(q0 + li, p.Lq - 1);
+    const int qi = min(q0 + li, Lq - 1);
     const float* qr = qb + (size_t)qi * p.ldq;
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
@@ -157,7 +176,7 @@ __global__ __launch_bounds__(256, 1) void k_flash_attn(AttnP p) {
     for (int i = 0; i < LPT; ++i) {
       const int idx = t + 256 * i;
       const int row = idx / (HDR / 4), c4 = idx - row * (HDR / 4);
-      const int key = min(k0 + row, p.Lk - 1);
+      const int key = min(k0 + row, Lk - 1);
       rk[i] = *reinterpret_cast<const f32x4*>(kb + (size_t)key * p.ldk + c4 * 4);
       rv[i] = *reinterpret_cast<const f32x4*>(vb + (size_t)key * p.ldv + c4 * 4);
     }
@@ -174,7 +193,7 @@ __global__ __launch_bounds__(256, 1) void k_flash_attn(AttnP p) {
     }
   };
 
-  const int ntiles = (p.Lk + KT - 1) / KT;
+  const int ntiles = (Lk + KT - 1) / KT;
   load_kv(0);
   store_kv(0);
   __syncthreads();
@@ -186,7 +205,7 @@ __global__ __launch_bounds__(256, 1) void k_flash_attn(AttnP p) {
 #pragma unroll
     for (int sub = 0; sub < KT / 32; ++sub) {
       const int kbase = tt * KT + sub * 32;
-      if (kbase >= p.Lk) break;  // wave-uniform
+      if (kbase >= Lk) break;  // wave-uniform
       // ---- S^T[key][q] for 32 keys x 32 queries
       f32x16 sacc;
 #pragma unroll
@@ -205,7 +224,7 @@ __global__ __launch_bounds__(256, 1) void k_flash_attn(AttnP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (key >= p.Lk) sacc[r] = -INFINITY;
+        if (key >= Lk) sacc[r] = -INFINITY;
         mt = fmaxf(mt, sacc[r]);
       }
       mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
@@ -238,9 +257,9 @@ __global__ __launch_bounds__(256, 1) void k_flash_attn(AttnP p) {
   }
   // ---- normalise and store: lane holds d = dc*32 + (r&3) + 8*(r>>2) + 4*lh of query q0 + li
   const int qi = q0 + li;
-  if (qi < p.Lq) {
+  if (qi < Lq) {
     const float inv = 1.f / l_run;
-    float* orow = p.o + (size_t)b * p.bso + (size_t)qi * p.ldo + h * HDR;
+    float* orow = ob + (size_t)qi * p.ldo;
 #pragma unroll
     for (int dc = 0; dc < NDC; ++dc)
 #pragma unroll
@@ -256,11 +275,19 @@ __global__ __launch_bounds__(256, 1) void k_flash_attn(AttnP p) {
 }
 
 void flash_attention(hipStream_t s, const float* q, const float* k, const float* v, float* o, int B, int H, int Lq, int Lk,
-                     int hd, int ldq, int ldk, int ldv, int ldo, long bsq, long bsk, long bsv, long bso, float scale) {
+                     int hd, int ldq, int ldk, int ldv, int ldo, long bsq, long bsk, long bsv, long bso, float scale,
+                     const SeqTab* tab) {
   if (B == 0 || Lq == 0) return;
   YMK_CHECK(Lk > 0, "attention: no keys");
   YMK_CHECK(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0, "attention: strides must be multiples of 4");
-  AttnP p{q, k, v, o, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, Lq, Lk, H, scale};
+  AttnP p{q, k, v, o, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, Lq, Lk, H, scale, nullptr, nullptr, nullptr, nullptr};
+  if (tab) {
+    p.qoff = tab->qoff;
+    p.qlen = tab->qlen;
+    p.koff = tab->koff;
+    p.klen = tab->klen;
+    YMK_CHECK((p.qoff == nullptr) == (p.qlen == nullptr) && (p.koff == nullptr) == (p.klen == nullptr), "attention: offset and length tables come in pairs");
+  }
   dim3 grid((Lq + 127) / 128, H, B);
   if (hd == 32) hipLaunchKernelGGL(k_flash_attn<32>, grid, dim3(256), 0, s, p);
   else if (hd == 64) hipLaunchKernelGGL(k_flash_attn<64>, grid, dim3(256), 0, s, p);
@@ -284,6 +311,7 @@ struct SmallAttnP {
   int ld_mask;
   const unsigned char* kpm;
   int ld_kpm;
+  const int *koff, *klen;  // ragged keys/values: sample b reads klen[b] rows from row koff[b] (null = strided, Lk)
 };
 __global__ __launch_bounds__(64) void k_small_attn(SmallAttnP p) {
   __shared__ float prob[1024];
@@ -295,8 +323,14 @@ __global__ __launch_bounds__(64) void k_small_attn(SmallAttnP p) {
   __syncthreads();
   const float* kb = p.k + (size_t)b * p.bsk + h * p.hd;
   const float* vb = p.v + (size_t)b * p.bsv + h * p.hd;
+  int Lk = p.Lk;
+  if (p.koff) {
+    kb = p.k + (size_t)p.koff[b] * p.ldk + h * p.hd;
+    vb = p.v + (size_t)p.koff[b] * p.ldv + h * p.hd;
+    Lk = p.klen[b];
+  }
   float mx = -INFINITY;
-  for (int k = lane; k < p.Lk; k += 64) {
+  for (int k = lane; k < Lk; k += 64) {
     bool blocked = false;
     if (p.mask_qk) blocked = p.mask_qk[(size_t)qi * p.ld_mask + k] != 0;
     if (p.kpm) blocked = blocked || p.kpm[(size_t)b * p.ld_kpm + k] != 0;
@@ -315,7 +349,7 @@ __global__ __launch_bounds__(64) void k_small_attn(SmallAttnP p) {
   }
   mx = wave_max(mx);
   float sum = 0.f;
-  for (int k = lane; k < p.Lk; k += 64) {
+  for (int k = lane; k < Lk; k += 64) {
     const float e = __expf(prob[k] - mx);
     prob[k] = e;
     sum += e;
@@ -326,16 +360,18 @@ __global__ __launch_bounds__(64) void k_small_attn(SmallAttnP p) {
   float* orow = p.o + (size_t)b * p.bso + (size_t)qi * p.ldo + h * p.hd;
   for (int d = lane; d < p.hd; d += 64) {
     float a = 0.f;
-    for (int k = 0; k < p.Lk; ++k) a += prob[k] * vb[(size_t)k * p.ldv + d];
+    for (int k = 0; k < Lk; ++k) a += prob[k] * vb[(size_t)k * p.ldv + d];
     orow[d] = a * inv;
   }
 }
 void small_attention(hipStream_t s, const float* q, const float* k, const float* v, float* o, int B, int H, int Lq, int Lk,
                      int hd, int ldq, int ldk, int ldv, int ldo, long bsq, long bsk, long bsv, long bso, float scale,
-                     const unsigned char* mask_qk, int ld_mask, const unsigned char* kpm, int ld_kpm) {
+                     const unsigned char* mask_qk, int ld_mask, const unsigned char* kpm, int ld_kpm, const SeqTab* tab) {
   if (B == 0 || Lq == 0) return;
   YMK_CHECK(Lk > 0 && Lk <= 1024 && hd <= 128 && hd % 4 == 0, "small attention: Lk <= 1024, hd <= 128");
-  SmallAttnP p{q, k, v, o, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, Lq, Lk, H, hd, scale, mask_qk, ld_mask, kpm, ld_kpm};
+  SmallAttnP p{q, k, v, o, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, Lq, Lk, H, hd, scale, mask_qk, ld_mask, kpm, ld_kpm,
+               tab ? tab->koff : nullptr, tab ? tab->klen : nullptr};
+  YMK_CHECK(!tab || (!tab->qoff && !mask_qk && !kpm), "small attention: ragged keys only, without masks");
   hipLaunchKernelGGL(k_small_attn, dim3(Lq, H, B), dim3(64), 0, s, p);
   YMK_HIP(hipGetLastError());
 }
@@ -464,7 +500,10 @@ __global__ __launch_bounds__(256) void k_greedy_step(const float* __restrict__ l
       }
     }
     trow[j] = next;
-    if (next == eos_id) st[0] = 1;
+    if (next == eos_id && !st[0]) {
+      st[0] = 1;
+      st[3] = step + 1;  // AR steps after which this row holds an <eos> (a mini-batch stops at the max over its rows)
+    }
   }
   if (!st[0]) atomicAdd(not_done, 1);
   if (host_flag) {
@@ -619,6 +658,23 @@ void tile_rows(hipStream_t s, const float* src, int rows, int D, float* dst, int
   size_t g = (total + 255) / 256;
   if (g > 2048) g = 2048;
   hipLaunchKernelGGL(k_tile_rows, dim3((int)g), dim3(256), 0, s, (const float4*)src, (float4*)dst, per, total);
+  YMK_HIP(hipGetLastError());
+}
+
+__global__ void k_init_decode(int* __restrict__ tok, int ld_tok, int* __restrict__ state, int bos_id, int pad_id, int B) {
+  const size_t n = (size_t)B * ld_tok;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    tok[i] = (i % ld_tok) == 0 ? bos_id : pad_id;
+    if (i < (size_t)B * 4) state[i] = (i & 3) == 2 ? -1 : 0;
+  }
+}
+void init_decode(hipStream_t s, int* tok, int ld_tok, int* state, int bos_id, int pad_id, int B) {
+  YMK_CHECK(ld_tok >= 4, "init_decode: ld_tok >= 4");
+  const size_t n = (size_t)B * ld_tok;
+  if (n == 0) return;
+  size_t g = (n + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(k_init_decode, dim3((int)g), dim3(256), 0, s, tok, ld_tok, state, bos_id, pad_id, B);
   YMK_HIP(hipGetLastError());
 }
 

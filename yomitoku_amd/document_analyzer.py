@@ -408,6 +408,49 @@ class DocumentAnalyzer:
         outputs = self.aggregate(results_ocr, results_layout)
         return DocumentAnalyzerSchema(**outputs), ocr, layout
 
+    # ---- several pages per call: device batches across pages (the per-page path above leaves an MI355X mostly idle:
+    # batch-1 RT-DETR / PARSeq launches are grid-starved and every page pays its own greedy-decode loop)
+    def _ocr_pages(self, pages):
+        """det -> rec chain of a wave of pages: DBNet forwards over same-size pages, one grouped PARSeq forward."""
+        dets = self.text_detector.detect_pages(pages)
+        recs = self.text_recognizer.recognize_pages(pages, [d.points for d in dets])
+        return dets, recs
+
+    def _layout_pages(self, pages):
+        """layout -> table chain of a wave: one RT-DETRv2 forward over the pages, one over all their table crops."""
+        lays = self.layout.layout_parser.parse_pages(pages)
+        tables = self.layout.table_structure_recognizer.recognize_pages(pages, [[t.box for t in l.tables] for l in lays])
+        return [LayoutAnalyzerSchema(paragraphs=l.paragraphs, tables=t, figures=l.figures) for l, t in zip(lays, tables)]
+
+    def analyze_pages(self, imgs, wave: int = 8):
+        """`__call__` over a list of pages, `wave` pages at a time on the device.  Every page's result is what
+        `__call__(img)` returns for it (pages never interact: batches are per-image independent, recogniser
+        mini-batches are formed per page); what changes is how the launches are shared.  The two chains of a wave
+        run concurrently on their own HIP streams, as in `run`.  Returns [(DocumentAnalyzerSchema, None, None), ...]."""
+        if self.visualize:
+            raise NotImplementedError("visualisation is out of scope of the MI355X path (visualize=False only)")
+        dev = self.text_detector.device
+        out = []
+        for start in range(0, len(imgs), max(1, int(wave))):
+            chunk = imgs[start : start + max(1, int(wave))]
+            pages = [img if isinstance(img, torch.Tensor) else imaging.page_to_device(img, dev) for img in chunk]
+            if self.split_text_across_cells:
+                f_det = self._pool.submit(self._on_stream, "ocr", self.text_detector.detect_pages, pages)
+                f_lay = self._pool.submit(self._on_stream, "layout", self._layout_pages, pages)
+                dets, lays = f_det.result(), f_lay.result()
+                dets = [_split_text_across_cells(d, l) for d, l in zip(dets, lays)]
+                recs = self._on_stream("ocr", self.text_recognizer.recognize_pages, pages, [d.points for d in dets])
+            else:
+                f_ocr = self._pool.submit(self._on_stream, "ocr", self._ocr_pages, pages)
+                f_lay = self._pool.submit(self._on_stream, "layout", self._layout_pages, pages)
+                dets, recs = f_ocr.result()
+                lays = f_lay.result()
+            for img, det, rec, lay in zip(chunk, dets, recs, lays):
+                self.img = img
+                results_ocr = OCRSchema(words=ocr_aggregate(det, rec))
+                out.append((DocumentAnalyzerSchema(**self.aggregate(results_ocr, lay)), None, None))
+        return out
+
     def __call__(self, img):
         self.img = img
         dev = self.text_detector.device

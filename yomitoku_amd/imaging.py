@@ -39,11 +39,14 @@ def page_to_device(img: np.ndarray, device) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(img)).to(device, non_blocking=True)
 
 
-def detector_tensor(page_dev: torch.Tensor, shortest: int, limit: int) -> torch.Tensor:
-    """TextDetector.preprocess on the device: fp32 1 x 3 x H' x W'."""
+def detector_tensor(page_dev: torch.Tensor, shortest: int, limit: int, out: torch.Tensor = None) -> torch.Tensor:
+    """TextDetector.preprocess on the device: fp32 1 x 3 x H' x W' (or into `out`, a 3 x H' x W' slice of a batch)."""
     h, w = page_dev.shape[:2]
     oh, ow = resize_shortest_edge_dims(h, w, shortest, limit)
-    out = torch.empty((1, 3, oh, ow), dtype=torch.float32, device=page_dev.device)
+    if out is None:
+        out = torch.empty((1, 3, oh, ow), dtype=torch.float32, device=page_dev.device)
+    elif tuple(out.shape[-3:]) != (3, oh, ow) or not out.is_contiguous():
+        raise ValueError(f"detector_tensor: out must be a contiguous 3 x {oh} x {ow} tensor")
     lib = _lib.load()
     with torch.cuda.device(page_dev.device):
         _lib.check(

@@ -163,6 +163,28 @@ class LayoutParser(BaseModule):
         category_elements = filter_contained_rectangles_within_category(category_elements)
         return filter_contained_rectangles_across_categories(category_elements, "tables", "paragraphs")
 
+    MAX_PAGES_PER_FORWARD = 16
+
+    def parse_pages(self, imgs):
+        """`__call__` for several pages through shared RT-DETRv2 forwards (images of a batch are independent,
+        tests/test_rtdetr_gpu.py::test_batch_of_pages_matches_oracle).  One LayoutParserSchema per page."""
+        pages = [img if isinstance(img, torch.Tensor) else imaging.page_to_device(img, self.device) for img in imgs]
+        oh, ow = (int(v) for v in self._cfg.data.img_size)
+        results = []
+        for start in range(0, len(pages), self.MAX_PAGES_PER_FORWARD):
+            chunk = pages[start : start + self.MAX_PAGES_PER_FORWARD]
+            x = torch.empty((len(chunk), 3, oh, ow), dtype=torch.float32, device=chunk[0].device)
+            for k, page in enumerate(chunk):
+                imaging.rtdetr_tensor(page, None, (oh, ow), out=x[k])
+            preds = self.model(x)
+            logits = preds["pred_logits"].cpu().numpy()
+            boxes = preds["pred_boxes"].cpu().numpy()
+            for k, page in enumerate(chunk):
+                h, w = (int(v) for v in page.shape[:2])
+                one = self.postprocessor({"pred_logits": logits[k : k + 1], "pred_boxes": boxes[k : k + 1]}, (w, h), self.thresh_score)
+                results.append(LayoutParserSchema(**self.filtering_elements(one[0])))
+        return results
+
     def __call__(self, img):
         ori_h, ori_w = img.shape[:2]
         preds = self.model(self.preprocess(img))

@@ -220,6 +220,37 @@ class PARSeq(HipNet):
         self.last_ar_steps = ar.value
         return logits[:, : out_len.value]
 
+    def forward_groups(self, batches):
+        """Several mini-batches in ONE forward (ymk_parseq_forward_groups): `batches` is a list of fp32 B_g x 3 x 32 x W_g
+        device tensors, each padded to its own width.  Returns (logits [sum B_g] x S_max x C, out_lens, ar_steps) with
+        per-group row counts / greedy step counts; group g's rows are logits[off_g : off_g + B_g, : out_lens[g]]."""
+        import ctypes
+
+        if not batches:
+            raise ValueError("forward_groups wants at least one mini-batch")
+        for t in batches:
+            _require_cuda(t, "PARSeq")
+        if self._h is None:
+            self.to(batches[0].device)
+        xs = [t.to(torch.float32).contiguous() for t in batches]
+        n = len(xs)
+        lib = _lib.load()
+        ns, nc = ctypes.c_int(), ctypes.c_int()
+        _lib.check(lib.ymk_parseq_dims(self._h, ctypes.byref(ns), ctypes.byref(nc)), "ymk_parseq_dims")
+        total = sum(int(t.shape[0]) for t in xs)
+        logits = torch.empty((total, ns.value, nc.value), dtype=torch.float32, device=xs[0].device)
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in xs])
+        bs = (ctypes.c_int * n)(*[int(t.shape[0]) for t in xs])
+        ws = (ctypes.c_int * n)(*[int(t.shape[3]) for t in xs])
+        out_len, ar = (ctypes.c_int * n)(), (ctypes.c_int * n)()
+        with torch.cuda.device(xs[0].device):
+            _lib.check(
+                lib.ymk_parseq_forward_groups(self._h, ptrs, bs, ws, n, logits.data_ptr(), out_len, ar, _lib.current_stream_ptr()),
+                "ymk_parseq_forward_groups",
+            )
+        self.last_ar_steps = max(ar)
+        return logits, list(out_len), list(ar)
+
     @staticmethod
     def token_stats(logits: torch.Tensor):
         """(ids int32 B x S, probs fp32 B x S): per position arg-max class and max softmax probability."""

@@ -113,6 +113,29 @@ class TableStructureRecognizer(BaseModule):
         spans = sorted(elements["span"], key=lambda e: e["box"][1])
         return cells, rows, cols, spans
 
+    def recognize_pages(self, imgs, boxes_list):
+        """`__call__` for several pages: the table crops of ALL pages fill shared forwards of MAX_TABLES_PER_FORWARD
+        crops.  Returns per page the list `__call__` returns (tables without rows or columns dropped)."""
+        pages = [img if isinstance(img, torch.Tensor) else imaging.page_to_device(img, self.device) for img in imgs]
+        oh, ow = self._cfg.data.img_size
+        flat = [(p, box) for p, boxes in enumerate(boxes_list) for box in boxes]
+        outputs = [[] for _ in pages]
+        for start in range(0, len(flat), self.MAX_TABLES_PER_FORWARD):
+            chunk = flat[start : start + self.MAX_TABLES_PER_FORWARD]
+            batch = torch.empty((len(chunk), 3, oh, ow), dtype=torch.float32, device=pages[chunk[0][0]].device)
+            metas = []
+            for k, (p, box) in enumerate(chunk):
+                _, size, offset = imaging.rtdetr_tensor(pages[p], box, (oh, ow), out=batch[k])
+                metas.append({"size": size, "offset": offset})
+            preds = self.model(batch)
+            logits = preds["pred_logits"].cpu().numpy()
+            bxs = preds["pred_boxes"].cpu().numpy()
+            for k, ((p, _), data) in enumerate(zip(chunk, metas)):
+                table = self.postprocess({"pred_logits": logits[k : k + 1], "pred_boxes": bxs[k : k + 1]}, data)
+                if table.n_row > 0 and table.n_col > 0:
+                    outputs[p].append(table)
+        return outputs
+
     def __call__(self, img, table_boxes, vis=None):
         outputs = []
         for start in range(0, len(table_boxes), self.MAX_TABLES_PER_FORWARD):

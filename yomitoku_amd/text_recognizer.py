@@ -115,7 +115,9 @@ class TextRecognizer(BaseModule):
         self.rec_orientation_fallback_thresh = rec_orientation_fallback_thresh
         self.batch_bucketing = batch_bucketing
         self.dynamic_width = dynamic_width
-        self.num_parallel_batches = int(num_parallel_batches)  # mini-batches in flight (see _run_batch_inference_parallel)
+        # text_recognizer.py:285-317 gates CPU worker threads on this (dead code there); here every
+        # mini-batch of a call already shares one grouped forward, so the value is accepted and has no effect
+        self.num_parallel_batches = int(num_parallel_batches)
         self.source_downscale = bool(source_downscale)
         self.model.to(self.device)
 
@@ -170,6 +172,8 @@ class TextRecognizer(BaseModule):
         return imaging.build_crop_batch(dataset.page, plans, out_h=int(self._cfg.data.img_size[0]), batch_w=batch_w)
 
     # ------------------------------------------------------------------ inference + decode
+    MAX_LINES_PER_FORWARD = 1024  # bounds the logits workspace of one grouped forward (101 x num_tokens floats per line)
+
     def _run_inference(self, data: torch.Tensor, model=None):
         model = model or self.model
         logits = model(data)
@@ -177,7 +181,9 @@ class TextRecognizer(BaseModule):
 
     def postprocess(self, stats, points):
         ids, probs = stats
-        pred, score = self.tokenizer.decode_stats(ids.cpu().numpy(), probs.cpu().numpy())
+        if isinstance(ids, torch.Tensor):
+            ids, probs = ids.cpu().numpy(), probs.cpu().numpy()
+        pred, score = self.tokenizer.decode_stats(ids, probs)
         pred = [unicodedata.normalize("NFKC", x) for x in pred]
         directions = []
         for point in points:
@@ -187,72 +193,44 @@ class TextRecognizer(BaseModule):
             directions.append("vertical" if h > w * 2 else "horizontal")
         return pred, score, directions
 
+    def _infer_groups(self, jobs, flip=False, fixed_width=False):
+        """jobs: (dataset, plans) mini-batches - of one page or of many - through ONE PARSeq forward per
+        MAX_LINES_PER_FORWARD lines (nets.PARSeq.forward_groups): every mini-batch keeps its own padded width and
+        its own early-stop step count, the launches are shared.  Returns per job (ids, probs) as numpy B x S."""
+        out = [None] * len(jobs)
+        start = 0
+        while start < len(jobs):
+            stop, lines = start, 0
+            while stop < len(jobs) and (stop == start or lines + len(jobs[stop][1]) <= self.MAX_LINES_PER_FORWARD):
+                lines += len(jobs[stop][1])
+                stop += 1
+            tensors = []
+            for dataset, plans in jobs[start:stop]:
+                if fixed_width:
+                    h, w = (int(v) for v in self._cfg.data.img_size)
+                    tensors.append(imaging.build_crop_batch(dataset.page, plans, out_h=h, batch_w=w, flip=flip))
+                else:
+                    tensors.append(self._collate(dataset, plans))
+            logits, out_lens, _ = self.model.forward_groups(tensors)
+            ids, probs = self.model.token_stats(logits)
+            ids, probs = ids.cpu().numpy(), probs.cpu().numpy()
+            row = 0
+            for k, (t, n) in enumerate(zip(tensors, out_lens)):
+                b = int(t.shape[0])
+                out[start + k] = (ids[row : row + b, :n], probs[row : row + b, :n])
+                row += b
+            start = stop
+        return out
+
     def _run_batch_inference(self, dataset, batches, points):
-        if self.num_parallel_batches > 1 and len(batches) > 1:
-            return self._run_batch_inference_parallel(dataset, batches, points)
         preds, scores, directions = [], [], []
         offset = 0
-        for plans in batches:
-            batch_points = points[offset : offset + len(plans)]
-            data = self._collate(dataset, plans)
-            pred, score, direction = self.postprocess(self._run_inference(data), batch_points)
+        for plans, stats in zip(batches, self._infer_groups([(dataset, plans) for plans in batches])):
+            pred, score, direction = self.postprocess(stats, points[offset : offset + len(plans)])
             preds.extend(pred)
             scores.extend(score)
             directions.extend(direction)
             offset += len(plans)
-        return preds, scores, directions
-
-    def _lanes(self, n):
-        """n (model replica, HIP stream) pairs: mini-batches are independent, but a model handle owns one workspace
-        arena, so concurrent batches need their own replica (the lite recogniser is 40 MB; packed once, kept)."""
-        if getattr(self, "_lane_weights", None) is not self.model.state_dict():  # first use, or new weights were loaded
-            self._lane_models, self._lane_streams = [self.model], getattr(self, "_lane_streams", [])
-            self._lane_weights = self.model.state_dict()
-        while len(self._lane_models) < n:
-            twin = type(self.model)(cfg=self._cfg)
-            twin.load_state_dict(self.model.state_dict()).to(self.device)
-            self._lane_models.append(twin)
-        dev = torch.device(self.device)
-        while len(self._lane_streams) < n:
-            self._lane_streams.append(torch.cuda.Stream(device=dev))
-        return list(zip(self._lane_models[:n], self._lane_streams[:n]))
-
-    def _run_batch_inference_parallel(self, dataset, batches, points):
-        """`num_parallel_batches` mini-batches in flight (text_recognizer.py:285-317 runs them on CPU worker threads;
-        there the gate is dead code).  Here each lane is a thread with its own replica and HIP stream:
-        the AR decode of one batch is a chain of small launches that leaves the device mostly idle.  Outputs are
-        those of the serial loop - batches do not interact - in batch order."""
-        import queue
-        from concurrent.futures import ThreadPoolExecutor
-
-        n = min(int(self.num_parallel_batches), len(batches))
-        free = queue.Queue()
-        for lane in self._lanes(n):
-            free.put(lane)
-        offsets = np.cumsum([0] + [len(b) for b in batches]).tolist()
-        dev = torch.device(self.device)
-        issued = torch.cuda.current_stream(dev)  # the page upload / pyramid were issued here
-
-        def work(i):
-            model, stream = free.get()
-            try:
-                stream.wait_stream(issued)
-                with torch.cuda.stream(stream):
-                    data = self._collate(dataset, batches[i])
-                    stats = self._run_inference(data, model)
-                    out = self.postprocess(stats, points[offsets[i] : offsets[i + 1]])  # .cpu() waits for this stream
-                self.model.last_ar_steps = model.last_ar_steps
-                return out
-            finally:
-                free.put((model, stream))
-
-        if not hasattr(self, "_lane_pool") or self._lane_pool._max_workers < n:
-            self._lane_pool = ThreadPoolExecutor(max_workers=n, thread_name_prefix="ymk-rec")
-        preds, scores, directions = [], [], []
-        for pred, score, direction in self._lane_pool.map(work, range(len(batches))):
-            preds.extend(pred)
-            scores.extend(score)
-            directions.extend(direction)
         return preds, scores, directions
 
     # ------------------------------------------------------------------ 180-degree retry (text_recognizer.py:319-350)
@@ -268,12 +246,11 @@ class TextRecognizer(BaseModule):
         if not retry:
             return
         retry_points = [points[i] for i in retry]
-        h, w = (int(v) for v in self._cfg.data.img_size)
         r_preds, r_scores, r_dirs = [], [], []
         offset = 0
-        for plans in self._prepare_fallback_batch(dataset, retry):
-            data = imaging.build_crop_batch(dataset.page, plans, out_h=h, batch_w=w, flip=True)
-            pred, score, direction = self.postprocess(self._run_inference(data), retry_points[offset : offset + len(plans)])
+        batches = self._prepare_fallback_batch(dataset, retry)
+        for plans, stats in zip(batches, self._infer_groups([(dataset, plans) for plans in batches], flip=True, fixed_width=True)):
+            pred, score, direction = self.postprocess(stats, retry_points[offset : offset + len(plans)])
             r_preds.extend(pred)
             r_scores.extend(score)
             r_dirs.extend(direction)
@@ -281,6 +258,38 @@ class TextRecognizer(BaseModule):
         for j, idx in enumerate(retry):
             if r_scores[j] > scores[idx] and r_scores[j] >= self.rec_orientation_fallback_thresh:
                 preds[idx], scores[idx], directions[idx] = r_preds[j], r_scores[j], r_dirs[j]
+
+    def recognize_pages(self, imgs, points_list):
+        """`__call__` for several pages at once: the mini-batches of every page are formed per page exactly as in
+        `__call__` (bucketing, width budget, padding), then ALL of them go through shared PARSeq forwards
+        (`_infer_groups`).  Returns one TextRecognizerSchema per page; a page's result does not depend on its
+        neighbours (mini-batches never mix pages)."""
+        preps = [self.preprocess(img, pts) for img, pts in zip(imgs, points_list)]
+        jobs, spans = [], []
+        for batches, _, dataset, _ in preps:
+            spans.append((len(jobs), len(jobs) + len(batches)))
+            jobs.extend((dataset, plans) for plans in batches)
+        stats = self._infer_groups(jobs) if jobs else []
+        results = []
+        for (batches, points, dataset, order), (lo, hi) in zip(preps, spans):
+            walk = [points[i] for i in order] if order is not None else points
+            preds, scores, directions = [], [], []
+            offset = 0
+            for plans, st in zip(batches, stats[lo:hi]):
+                pred, score, direction = self.postprocess(st, walk[offset : offset + len(plans)])
+                preds.extend(pred)
+                scores.extend(score)
+                directions.extend(direction)
+                offset += len(plans)
+            if order is not None:
+                inverse = np.argsort(order)
+                preds = [preds[i] for i in inverse]
+                scores = [scores[i] for i in inverse]
+                directions = [directions[i] for i in inverse]
+            if self.rec_orientation_fallback:
+                self._apply_orientation_fallback(dataset, points, preds, scores, directions)
+            results.append(TextRecognizerSchema(contents=preds, scores=scores, points=points, directions=directions))
+        return results
 
     def __call__(self, img, points=None, vis=None):
         batches, points, dataset, order = self.preprocess(img, points)
