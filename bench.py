@@ -1,24 +1,29 @@
 #!/usr/bin/env python
 """Benchmark of the MI355X DocumentAnalyzer hot path (contract: task prompt / DESIGN.md §8).
 
-    python bench.py --gpus N --steps K --warmup W [--workload analyzer|detector|recognizer] [--pages 64] [--procs 4] [--workers 2]
+    python bench.py --gpus N --steps K --warmup W [--workload analyzer|detector|recognizer] [--model-set lite|default]
+                    [--pages 64] [--wave 8] [--workers 2] [--procs 1]
 
-One rank per GPU (torchrun env).  A "step" is one pass of the hot path over one batch of synthetic
-1600x1200 pages that are already resident in HBM (uint8 BGR, as `cv2.imread` would hand them over).
-Rank 0 prints ONE JSON line: BASELINE.json's metric (pages/s, whole job), the roofline of the
-dominant kernel (live HIP-event timing of every implicit-GEMM convolution launch on its own stream)
-and, at N=1, the CPU baseline (oracle restatement of the reference's PyTorch-CPU path, bounded sample).
+One rank per GPU.  Under torchrun the rank comes from the environment; `python bench.py --gpus N` without one
+spawns its own N ranks (same protocol: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  A "step" is one pass of the hot
+path over one batch of synthetic 1600x1200 pages that are already resident in HBM (uint8 BGR, as `cv2.imread` would
+hand them over).  Rank 0 prints ONE JSON line: BASELINE.json's metric (pages/s, whole job), the roofline of the
+dominant kernel (live HIP-event timing of every implicit-GEMM convolution launch on its own stream, in a serial pass
+of the same program) and, at N=1, the CPU baseline (oracle restatement of the reference's PyTorch-CPU path).
 
-workload analyzer (default; BASELINE.json configs[3], `--lite` model set): DBNet text detector,
-  PARSeq tiny-dynw recogniser (dynamic_width + batch_bucketing), RT-DETRv2 layout parser, RT-DETRv2
-  table-structure recogniser, host post-processing and aggregation.  Every page goes through
-  `DocumentAnalyzer.__call__` on its own, as in the reference (cli/main.py:116-120); `--procs` processes per
-  GPU x `--workers` pages in flight each (yomitoku_amd/parallel.py: the host half of a page is Python, one GIL
-  per process).  Weights are seeded random draws (no
-  network) which detect noise, so the DISCRETE hand-overs between stages use the page generator's
-  ground truth - the recogniser gets the true text-line quads, the table recogniser the true table
-  boxes, the aggregation the true paragraph boxes - while every network and every pre/post stage
-  still runs at full cost on every page inside the timed region.
+workload analyzer (default; BASELINE.json configs[3]): DBNet text detector, PARSeq recogniser, RT-DETRv2 layout
+  parser, RT-DETRv2 table-structure recogniser, host post-processing and aggregation, through
+  `DocumentAnalyzer.analyze_pages`: `--wave` pages share device batches (DBNet / RT-DETR forwards over the wave, one
+  grouped PARSeq forward with one greedy loop), `--workers` waves in flight per process (each on its own replica and
+  HIP streams), `--procs` processes per GPU.  Per-page results equal `DocumentAnalyzer.__call__` page by page
+  (tests/test_pipeline_gpu.py).  `--model-set lite` = the reference's `--lite` switches (cli/main.py:505-520:
+  parseq-tiny-dynw-v4, dynamic_width, batch_bucketing, source_downscale); `--model-set default` = the constructor
+  defaults (dbnetv2_1 + parseq-large-v4_1 at its fixed 800 px canvas).
+  Weights are seeded random draws (no network) which detect noise, so the DISCRETE hand-overs between stages use the
+  page generator's ground truth - the recogniser gets the true text-line quads, the table recogniser the true table
+  boxes, the aggregation the true paragraph boxes - and the DB box extraction runs on a probability map RENDERED from
+  the true quads (so that ~80 boxes per page are traced, scored and unclipped inside the clock), while every network
+  and every pre/post stage still runs at full cost on every page inside the timed region.
 workload detector (configs[1]): DBNet forward alone on a batch of 8 pages.
 workload recognizer (configs[2]): TextRecognizer (`--rec-model parseq` = open-beta geometry, or the lite model) on 2048
   synthetic text lines per step; metric text-lines/sec.
@@ -29,6 +34,7 @@ import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -43,7 +49,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64
 
 # YMK_BENCH_DRY=1: CPU rehearsal of the ORCHESTRATION only (ranks over gloo, helper processes, step barriers, the
 # max-over-ranks clock, teardown) with stub page workers from tests/bench_dry_stubs.py - what tests/test_bench_dry.py
-# runs at world size 2, since multi-GPU boxes are the driver's.  It does no GPU work and its line says "dry_run".
+# runs at world size 2 and 8, since multi-GPU boxes are the driver's.  It does no GPU work and its line says "dry_run".
 DRY = os.environ.get("YMK_BENCH_DRY") == "1"
 
 
@@ -59,6 +65,7 @@ def device_sync():
     if not DRY:
         torch.cuda.synchronize()
 
+
 LITE_CONFIGS = {
     "ocr": {
         "text_detector": {"from_pretrained": False},
@@ -67,22 +74,33 @@ LITE_CONFIGS = {
     },
     "layout_analyzer": {"layout_parser": {"from_pretrained": False}, "table_structure_recognizer": {"from_pretrained": False}},
 }
+DEFAULT_CONFIGS = {  # the constructor defaults of the reference modules (text_detector.py:37, text_recognizer.py:51)
+    "ocr": {"text_detector": {"from_pretrained": False}, "text_recognizer": {"from_pretrained": False}},
+    "layout_analyzer": {"layout_parser": {"from_pretrained": False}, "table_structure_recognizer": {"from_pretrained": False}},
+}
+MODEL_SETS = {"lite": LITE_CONFIGS, "default": DEFAULT_CONFIGS}
 # Biases of the seeded heads, chosen so that the random nets emit realistic unit COUNTS: sparse blobs
 # above the DB threshold, text of ~10-30 tokens per line batch, a handful of layout / row / column boxes.
 CKPT = dict(det=dict(seed=1234), rec=dict(seed=1235, eos_bias=6.1), lay=dict(seed=1240, num_classes=6, score_gain=3.0),
             tab=dict(seed=1241, num_classes=3, score_gain=3.0))
-
+REC_CKPT_OF_SET = {  # synth.parseq_state_dict kwargs per model set, oracle preset, oracle batching kwargs
+    "lite": (dict(seed=1235, eos_bias=6.1), "parseq-tiny-dynw-v4",
+             dict(dynamic_width=True, batch_bucketing=True, width_budget=8000, max_batch_size=64, batch_size=10, source_downscale=True)),
+    "default": (dict(seed=1237, patch=(8, 8), enc_dim=768, dec_dim=768, num_tokens=7121, eos_bias=6.5), "parseq-large-v4_1",
+                dict(dynamic_width=False, batch_bucketing=False, width_budget=None, max_batch_size=None, batch_size=128)),
+}
 
 if os.environ.get("YMK_BENCH_CKPT"):  # e.g. '{"rec": {"eos_bias": 5.5}}' - for unit-count sweeps
     for _k, _v in json.loads(os.environ["YMK_BENCH_CKPT"]).items():
         CKPT[_k].update(_v)
 
 
-def make_checkpoints():
+def make_checkpoints(model_set="lite"):
     from yomitoku_amd.utils.synth import dbnet_state_dict, parseq_state_dict
     from yomitoku_amd.utils.synth_rtdetr import rtdetr_state_dict
 
-    return {"det": dbnet_state_dict(**CKPT["det"]), "rec": parseq_state_dict(**CKPT["rec"]),
+    rec_kw = dict(CKPT["rec"]) if model_set == "lite" else dict(REC_CKPT_OF_SET[model_set][0])
+    return {"det": dbnet_state_dict(**CKPT["det"]), "rec": parseq_state_dict(**rec_kw),
             "lay": rtdetr_state_dict(**CKPT["lay"]), "tab": rtdetr_state_dict(**CKPT["tab"])}
 
 
@@ -123,6 +141,25 @@ def calibrate_heads(sds, device, page):
     return sds
 
 
+def render_truth_map(quads, page_hw, map_hw):
+    """Probability map a trained DBNet would emit for the page's true text lines: each quad shrunk by ~1/6 of its height
+    (the DB training target), filled with 0.93, edges softened by a 5 x 5 box blur.  Pre-rendered per page before the
+    clock; inside the clock it is what ymk_db_postprocess traces, scores and unclips."""
+    from scipy.ndimage import uniform_filter
+
+    (ph, pw), (mh, mw) = page_hw, map_hw
+    m = np.zeros((mh, mw), dtype=np.float32)
+    sy, sx = mh / ph, mw / pw
+    for q in quads:
+        xs, ys = [p[0] for p in q], [p[1] for p in q]
+        x0, x1, y0, y1 = min(xs) * sx, max(xs) * sx, min(ys) * sy, max(ys) * sy
+        d = max(1.0, (y1 - y0) / 6.0)
+        a, b, c, e = int(round(y0 + d)), int(round(y1 - d)), int(round(x0 + d)), int(round(x1 - d))
+        if b > a and e > c:
+            m[a:b, c:e] = 0.93
+    return np.ascontiguousarray(uniform_filter(m, size=5, mode="constant"))
+
+
 class Page:
     def __init__(self, seed, device):
         from yomitoku_amd import imaging
@@ -130,9 +167,12 @@ class Page:
 
         self.img, self.quads, self.tables, self.paragraphs = synthetic_page_with_truth(seed)
         self.dev = imaging.page_to_device(self.img, device)
+        h, w = self.img.shape[:2]
+        self.truth_map = render_truth_map(self.quads, (h, w), imaging.resize_shortest_edge_dims(h, w, 1280, 1600))
 
 
-def build_analyzer(device, sds):
+def build_analyzer(device, sds, model_set="lite"):
+    """One analyzer replica as a callable: run(wave of Page objects) -> list of DocumentAnalyzerSchema."""
     import logging
 
     from yomitoku_amd import document_analyzer as da
@@ -141,61 +181,75 @@ def build_analyzer(device, sds):
     logging.getLogger("yomitoku_amd.base").setLevel(logging.WARNING)
 
     class TruthDrivenAnalyzer(da.DocumentAnalyzer):
-        """DocumentAnalyzer whose stage hand-overs use the page's ground truth (see module doc)."""
+        """DocumentAnalyzer whose stage hand-overs use the pages' ground truth (see module doc)."""
 
-        truth = None
+        truth = None  # {device pointer of the page: Page}
         stats = None
+        serial_chains = False  # roofline pass: the two chains one after the other (clean per-kernel durations)
 
-        def _detect_and_recognize(self, page):
-            det_noise, _ = self.text_detector(page)  # full detector stage; its noise boxes are not propagated
-            det = TextDetectorSchema(points=self.truth.quads, scores=[1.0] * len(self.truth.quads))
-            rec, ocr = self.text_recognizer(page, det.points, None)
+        def _on_stream(self, name, fn, *args):
+            if self.serial_chains:
+                return fn(*args)
+            return super()._on_stream(name, fn, *args)
+
+        def _ocr_pages(self, pages):
+            truth = [self.truth[p.data_ptr()] for p in pages]
+            det = self.text_detector
+            maps = det.forward_pages(pages)  # pre-processing, DBNet forwards, maps back to the host: full cost
+            sizes = [tuple(int(v) for v in p.shape[:2]) for p in pages]
+            assert all(m.shape == t.truth_map.shape for m, t in zip(maps, truth))
+            boxes = det.extract_boxes([t.truth_map for t in truth], sizes)  # C++ box extraction on the rendered maps
+            dets = [TextDetectorSchema(points=t.quads, scores=[1.0] * len(t.quads)) for t in truth]
+            recs = self.text_recognizer.recognize_pages(pages, [d.points for d in dets])
             if self.stats is not None:
-                self.stats["det_boxes"].append(len(det_noise.points))
-            return det, rec, ocr
+                self.stats["det_boxes"].extend(len(b.points) for b in boxes)
+            return dets, recs
 
-    class TruthLayout:
-        def __init__(self, inner, owner):
-            self.inner, self.owner = inner, owner
+        def _layout_pages(self, pages):
+            truth = [self.truth[p.data_ptr()] for p in pages]
+            noise = self.layout.layout_parser.parse_pages(pages)  # full layout stage, result not propagated
+            tables = self.layout.table_structure_recognizer.recognize_pages(pages, [t.tables for t in truth])
+            out = []
+            for t, tb in zip(truth, tables):
+                paragraphs = [Element(id=None, box=b, score=1.0, role=None, contents=None) for b in t.paragraphs]
+                out.append(LayoutAnalyzerSchema(paragraphs=paragraphs, tables=tb, figures=[]))
+            if self.stats is not None:
+                self.stats["layout_boxes"].extend(len(n.paragraphs) + len(n.tables) + len(n.figures) for n in noise)
+                self.stats["cells"].extend(sum(len(x.cells) for x in tb) for tb in tables)
+            return out
 
-        def __call__(self, page):
-            noise, _ = self.inner.layout_parser(page)  # full layout stage, result not propagated
-            tables, _ = self.inner.table_structure_recognizer(page, self.owner.truth.tables)
-            paragraphs = [Element(id=None, box=b, score=1.0, role=None, contents=None) for b in self.owner.truth.paragraphs]
-            if self.owner.stats is not None:
-                self.owner.stats["layout_boxes"].append(len(noise.paragraphs) + len(noise.tables) + len(noise.figures))
-                self.owner.stats["cells"].append(sum(len(t.cells) for t in tables))
-            return LayoutAnalyzerSchema(paragraphs=paragraphs, tables=tables, figures=[]), None
-
-    an = TruthDrivenAnalyzer(configs=LITE_CONFIGS, device=str(device))
+    an = TruthDrivenAnalyzer(configs=MODEL_SETS[model_set], device=str(device))
     an.text_detector.model.load_state_dict(sds["det"])
     an.text_recognizer.model.load_state_dict(sds["rec"])
     an.layout.layout_parser.model.load_state_dict(sds["lay"])
     an.layout.table_structure_recognizer.model.load_state_dict(sds["tab"])
-    an.layout = TruthLayout(an.layout, an)
 
-    def run(page: Page):
-        an.truth = page
-        return an(page.dev)[0]
+    def run(wave):
+        an.truth = {p.dev.data_ptr(): p for p in wave}
+        return [r[0] for r in an.analyze_pages([p.dev for p in wave], wave=len(wave))]
 
     run.analyzer = an
     return run
 
 
-def cpu_analyzer_page(sds, page: Page, charset):
-    """The same page through the oracle chain on the host cores (what `--lite -d cpu` computes)."""
+def cpu_analyzer_page(sds, page: Page, charset, model_set="lite"):
+    """The same page through the oracle chain on the host cores (what `-d cpu` computes with this model set)."""
     from oracle import pipeline as op
     from oracle.parseq import PRESETS, make_cfg
 
+    _, preset, batching = REC_CKPT_OF_SET[model_set]
     op.detect(sds["det"], page.img)
-    ocfg = make_cfg(**PRESETS["parseq-tiny-dynw-v4"])
-    op.recognize(sds["rec"], ocfg, page.img, page.quads, charset, dynamic_width=True, batch_bucketing=True,
-                 width_budget=8000, max_batch_size=64, batch_size=10, source_downscale=True)
+    ocfg = make_cfg(**PRESETS[preset])
+    op.recognize(sds["rec"], ocfg, page.img, page.quads, charset, **batching)
     op.layout(sds["lay"], page.img)
     op.tables(sds["tab"], page.img, page.tables)
 
 
-def _helper_init(local_rank, sds, shares, workers, index):
+def make_waves(pages, wave):
+    return [pages[i : i + wave] for i in range(0, len(pages), wave)]
+
+
+def _helper_init(local_rank, sds, shares, workers, wave, model_set, index):
     """One helper process of a rank (yomitoku_amd/parallel.py PageProcesses): same GPU, own HIP context and
     analyzer replicas built from the rank's checkpoints (received as numpy arrays), own pages resident in HBM."""
     from yomitoku_amd.parallel import PageParallel
@@ -203,12 +257,13 @@ def _helper_init(local_rank, sds, shares, workers, index):
     sds = {k: {name: torch.from_numpy(a) for name, a in sd.items()} for k, sd in sds.items()}
     device = rank_device(local_rank)
     pages = make_pages(shares[index], device)
-    pool = PageParallel(lambda i: build_analyzer(device, sds), n_workers=workers)
-    pool.map(pages[:workers])  # first-call allocations happen before the parent starts its clock
+    waves = make_waves(pages, wave)
+    pool = PageParallel(lambda i: build_analyzer(device, sds, model_set), n_workers=workers)
+    pool.map(waves[:workers])  # first-call allocations happen before the parent starts its clock
     device_sync()
 
     def step(_payload):
-        pool.map(pages)
+        pool.map(waves)
         device_sync()
         return len(pages)
 
@@ -230,10 +285,48 @@ REC_PRESETS = {  # --rec-model: (synth.parseq_state_dict kwargs, oracle preset n
 }
 
 
+def conv_roofline(lib, run_once, units, unit_name, kernel_desc):
+    """HIP events around every implicit-GEMM launch of one serial pass (`run_once`) -> the roofline dict."""
+    from yomitoku_amd import _lib
+
+    _lib.check(lib.ymk_prof_begin())
+    run_once()
+    torch.cuda.synchronize()
+    ms, fl, ln = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+    _lib.check(lib.ymk_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(ln)))
+    alg = ctypes.c_double()
+    _lib.check(lib.ymk_prof_bytes(ctypes.byref(alg)))
+    if ms.value <= 0:
+        return None
+    ach = fl.value / (ms.value * 1e-3) / 1e12
+    return {
+        "bound": "mfma", "kernel": kernel_desc, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        "algorithmic_bytes_per_launch": int(alg.value // max(1, ln.value)),
+        f"launches_per_{unit_name}": round(ln.value / units, 2), "avg_launch_us": round(ms.value * 1e3 / max(1, ln.value), 2),
+        f"kernel_ms_per_{unit_name}": round(ms.value / units, 4), f"gflop_per_{unit_name}": round(fl.value / units / 1e9, 2),
+    }
+
+
+def cpu_timed(fn, n_warm, n_timed, budget_s):
+    """n_warm untimed + up to n_timed timed repetitions of fn(i) (stops early past budget_s, never below 1 timed)."""
+    for i in range(n_warm):
+        fn(i)
+    times = []
+    t_all = time.perf_counter()
+    for i in range(n_timed):
+        t = time.perf_counter()
+        fn(n_warm + i)
+        times.append(time.perf_counter() - t)
+        if time.perf_counter() - t_all > budget_s:
+            break
+    return times
+
+
 def recognizer_workload(args, rank, local_rank, world, device, lib):
     """BASELINE.json configs[2]: TextRecognizer with dynamic_width + batch_bucketing on 2048 synthetic 32 x W text-line
     crops per GPU per step (one sheet image + 2048 quads through TextRecognizer.__call__).  Unit: text lines."""
-    from yomitoku_amd import _lib, imaging
+    from yomitoku_amd import imaging
     from yomitoku_amd import distributed as ydist
     from yomitoku_amd.text_recognizer import TextRecognizer
     from yomitoku_amd.utils.synth import parseq_state_dict, synthetic_line_sheet
@@ -242,8 +335,7 @@ def recognizer_workload(args, rank, local_rank, world, device, lib):
     sd = ydist.broadcast_state_dict(parseq_state_dict(**ckpt_kw) if rank == 0 else None, src=0, device=device)
     sheet, quads = synthetic_line_sheet(seed=1 + rank, n_lines=args.lines)
     page = imaging.page_to_device(sheet, device)
-    rec = TextRecognizer(model_name=args.rec_model, from_pretrained=False, device=str(device), dynamic_width=True, batch_bucketing=True,
-                         num_parallel_batches=args.rec_lanes)
+    rec = TextRecognizer(model_name=args.rec_model, from_pretrained=False, device=str(device), dynamic_width=True, batch_bucketing=True)
     rec.model.load_state_dict(sd)
 
     def step():
@@ -269,29 +361,20 @@ def recognizer_workload(args, rank, local_rank, world, device, lib):
         dt = float(tt.item())
     if rank != 0:
         return None
-    roof = cpu = None
-    rec.num_parallel_batches = 1  # the per-launch event bookkeeping is single-threaded: serial pass for the roofline leg
-    _lib.check(lib.ymk_prof_begin())
-    step()
-    torch.cuda.synchronize()
-    ms, fl, ln = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-    _lib.check(lib.ymk_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(ln)))
-    if ms.value > 0:
-        ach = fl.value / (ms.value * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "conv_igemm / conv_splitk (every linear layer of the ViT encoder and the decoder)",
-                "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": None, "launches_per_line": round(ln.value / args.lines, 2),
-                "gflop_per_line": round(fl.value / args.lines / 1e9, 2), "kernel_ms_per_step": round(ms.value, 2)}
+    cpu = None
+    roof = conv_roofline(lib, step, args.lines, "line", "conv_igemm / conv_splitk (every linear layer of the ViT encoder and the decoder)")
     if world == 1 and not args.no_cpu_baseline:
         from oracle import pipeline as op
         from oracle.parseq import PRESETS, make_cfg
 
         n_cpu = min(args.lines, 96)
         ocfg = make_cfg(**PRESETS[preset])
-        t1 = time.perf_counter()
-        op.recognize(sd, ocfg, sheet, quads[:n_cpu], rec.charset, dynamic_width=True, batch_bucketing=True, **batching)
-        cpu = {"value": round(n_cpu / (time.perf_counter() - t1), 2), "unit": "lines/s", "cores": torch.get_num_threads(), "kind": "port",
-               "sample": f"the first {n_cpu} of the same lines through oracle.pipeline.recognize (PyTorch-CPU fp32 restatement)"}
+        times = cpu_timed(lambda i: op.recognize(sd, ocfg, sheet, quads[:n_cpu], rec.charset, dynamic_width=True, batch_bucketing=True,
+                                                 **batching), 1, 3, 40.0)
+        cpu = {"value": round(n_cpu / float(np.median(times)), 2), "unit": "lines/s", "cores": torch.get_num_threads(), "kind": "port",
+               "runs": [round(n_cpu / t, 2) for t in times],
+               "sample": f"the first {n_cpu} of the same lines through oracle.pipeline.recognize (PyTorch-CPU fp32 restatement), "
+                         f"1 warm-up + {len(times)} timed passes, median"}
     widths = [q[1][0] - q[0][0] for q in quads]
     return {
         "metric": f"PARSeq text-lines/sec (TextRecognizer {args.rec_model}, dynamic_width + batch_bucketing)",
@@ -303,10 +386,35 @@ def recognizer_workload(args, rank, local_rank, world, device, lib):
                                f"TextRecognizer call per step, {len(set(out.contents))} distinct strings decoded, "
                                f"mean length {np.mean([len(c) for c in out.contents]):.1f} characters (seeded random weights)",
                    "lines_per_step_per_gpu": args.lines,
-                   "parallelism": f"line sheets sharded x{world} GPU(s), {args.rec_lanes} mini-batches in flight",
-                   "checkpoints": "seeded synthetic (no network)", "last_batch_ar_steps": int(rec.model.last_ar_steps)},
+                   "parallelism": f"line sheets sharded x{world} GPU(s); the mini-batches of a call share grouped forwards of "
+                                  f"<= {rec.MAX_LINES_PER_FORWARD} lines",
+                   "checkpoints": "seeded synthetic (no network)", "last_forward_ar_steps": int(rec.model.last_ar_steps)},
         "roofline": roof, "cpu_baseline": cpu,
     }
+
+
+def self_spawn(argv, n):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks ourselves (same env protocol), pass rank 0's line
+    through, fail if any rank fails."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), YMK_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = rc or p.wait()
+    if rc:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def main():
@@ -315,14 +423,21 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="analyzer", choices=["analyzer", "detector", "recognizer"])
+    ap.add_argument("--model-set", default="lite", choices=sorted(MODEL_SETS), help="analyzer workload: lite (cli --lite) or default models")
     ap.add_argument("--rec-model", default="parseq", choices=sorted(REC_PRESETS), help="recognizer workload: model (configs[2]: parseq)")
     ap.add_argument("--lines", type=int, default=2048, help="recognizer workload: text lines per step per GPU")
-    ap.add_argument("--rec-lanes", type=int, default=4, help="recognizer workload: TextRecognizer num_parallel_batches")
     ap.add_argument("--pages", type=int, default=64, help="pages per step per GPU (BASELINE.json configs[3]: 64)")
-    ap.add_argument("--procs", type=int, default=4, help="processes per GPU (analyzer workload): each has its own interpreter/GIL")
-    ap.add_argument("--workers", type=int, default=2, help="pages in flight per process (analyzer workload)")
+    ap.add_argument("--total-pages", type=int, default=0, help="strong scaling (configs[4]: 512): pages per step over ALL GPUs")
+    ap.add_argument("--wave", type=int, default=8, help="pages per device batch (analyzer workload)")
+    ap.add_argument("--workers", type=int, default=2, help="waves in flight per process (analyzer workload)")
+    ap.add_argument("--procs", type=int, default=1, help="processes per GPU (analyzer workload): each has its own interpreter/GIL")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="skip the timed region: only the serial roofline pass (the command profiles/ runs under rocprofv3)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(sys.argv[1:], args.gpus))
 
     from yomitoku_amd import _lib
     from yomitoku_amd import distributed as ydist
@@ -333,7 +448,15 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert DRY or torch.cuda.is_available(), "bench.py needs a HIP device"
     device = rank_device(local_rank)
-    lib = _lib.load()
+    lib = None if DRY else _lib.load()
+    # Launch-latency-bound host threads: a worker returning from a 50 us library call must not wait 5 ms (CPython's
+    # default switch interval) behind another worker's Python loop.  An application-level choice, made here.
+    sys.setswitchinterval(float(os.environ.get("YMK_SWITCH_INTERVAL", 2e-4)))
+    if not DRY and hasattr(os, "sched_setaffinity") and world > 1:
+        # one slice of the host cores per rank, so 8 ranks' worker threads do not migrate over each other
+        cores = sorted(os.sched_getaffinity(0))
+        per = max(1, len(cores) // world)
+        os.sched_setaffinity(0, set(cores[local_rank * per : (local_rank + 1) * per]))
 
     if args.workload == "recognizer":
         line = recognizer_workload(args, rank, local_rank, world, device, lib)
@@ -345,7 +468,7 @@ def main():
         return
 
     # ---- weights: drawn once on rank 0, ONE flat RCCL broadcast per checkpoint over xGMI
-    sds = make_checkpoints() if rank == 0 else {k: None for k in ("det", "rec", "lay", "tab")}
+    sds = make_checkpoints(args.model_set) if rank == 0 else {k: None for k in ("det", "rec", "lay", "tab")}
     if rank == 0 and args.workload == "analyzer":
         sds = calibrate_heads(sds, device, Page(0, device))
     for k in ("det", "rec", "lay", "tab"):
@@ -354,7 +477,13 @@ def main():
     # ---- synthetic pages of this rank, resident in HBM before the clock starts
     if args.workload == "detector":
         args.pages = min(args.pages, 8)
-    seeds = [1000 * rank + i for i in range(args.pages)]
+    scaling = "weak"
+    if args.total_pages:  # strong scaling: the job's pages dealt round-robin to the ranks (yomitoku_amd.distributed)
+        seeds = [1000 + i for i in ydist.shard_indices(args.total_pages, rank, world)]
+        scaling = "strong"
+    else:
+        seeds = [1000 * rank + i for i in range(args.pages)]
+    pages_job = args.total_pages if args.total_pages else args.pages * world
     n_procs = max(1, args.procs) if args.workload == "analyzer" else 1
     shares = [seeds[i::n_procs] for i in range(n_procs)]  # pages of this rank, dealt to its processes
     pages = make_pages(shares[0], device)
@@ -366,26 +495,30 @@ def main():
         if n_procs > 1:
             # the rank's checkpoints go to its helpers by value, as numpy arrays through the spawn pipe (no /dev/shm)
             wire = {k: {name: t.numpy() for name, t in sd.items()} for k, sd in sds.items()}
-            helpers = PageProcesses(_helper_init, (local_rank, wire, shares, args.workers), n_procs=n_procs - 1, first_index=1)
-        pool = PageParallel(lambda i: build_analyzer(device, sds), n_workers=args.workers)
+            helpers = PageProcesses(_helper_init, (local_rank, wire, shares, args.workers, args.wave, args.model_set),
+                                    n_procs=n_procs - 1, first_index=1)
+        pool = PageParallel(lambda i: build_analyzer(device, sds, args.model_set), n_workers=args.workers)
+        waves = make_waves(pages, args.wave)
 
         def step():  # every process of the rank walks its share of the rank's pages; the step ends when all have
             if helpers:
                 helpers.start([None] * len(helpers))
-            out = pool.map(pages)[-1]
+            out = pool.map(waves)[-1]
             device_sync()
             if helpers:
-                assert sum(helpers.finish()) + len(pages) == args.pages
+                assert sum(helpers.finish()) + len(pages) == len(seeds)
             return out
 
-        metric = "pages/sec (DocumentAnalyzer @1600x1200, lite model set)"
-        workload = (f"Full DocumentAnalyzer per page (BASELINE.json configs[3]): DBNet dbnetv2_1 + PARSeq parseq-tiny-dynw-v4 "
-                    f"(dynamic_width, batch_bucketing) + RT-DETRv2 layout + RT-DETRv2 table structure + host post-processing "
-                    f"and aggregation; {args.pages} synthetic 1600x1200 pages per step per GPU, dealt to {n_procs} process(es) x "
-                    f"{args.workers} pages in flight each; "
-                    f"stage hand-overs use ground truth ({np.mean([len(p.quads) for p in pages]):.0f} text lines, "
-                    f"{np.mean([len(p.tables) for p in pages]):.1f} tables, {np.mean([len(p.paragraphs) for p in pages]):.0f} "
-                    f"paragraphs per page) because seeded random weights detect noise")
+        names = {"lite": "DBNet dbnetv2_1 + PARSeq parseq-tiny-dynw-v4 (dynamic_width, batch_bucketing, source_downscale)",
+                 "default": "DBNet dbnetv2_1 + PARSeq parseq-large-v4_1 (fixed 800 px canvas, batch_size 128 per page)"}
+        metric = f"pages/sec (DocumentAnalyzer @1600x1200, {args.model_set} model set)"
+        workload = (f"Full DocumentAnalyzer (BASELINE.json configs[{4 if args.total_pages else 3}]): {names[args.model_set]} + RT-DETRv2 layout + "
+                    f"RT-DETRv2 table structure + host post-processing and aggregation, through DocumentAnalyzer.analyze_pages; "
+                    f"{len(seeds)} synthetic 1600x1200 pages per step on this GPU, in waves of {args.wave} pages (device batches "
+                    f"across the pages of a wave), {n_procs} process(es) x {args.workers} waves in flight; stage hand-overs use ground "
+                    f"truth ({np.mean([len(p.quads) for p in pages]):.0f} text lines, {np.mean([len(p.tables) for p in pages]):.1f} tables, "
+                    f"{np.mean([len(p.paragraphs) for p in pages]):.0f} paragraphs per page) and the DB box extraction runs on a map "
+                    f"rendered from the true lines, because seeded random weights detect noise")
     else:
         from yomitoku_amd.nets import DBNet
 
@@ -398,148 +531,128 @@ def main():
         metric = "pages/sec (TextDetector DBNet forward @1600x1200 -> 3x1600x1184)"
         workload = f"TextDetector DBNet forward alone, batch={args.pages} synthetic 1600x1200 pages per GPU (BASELINE.json configs[1])"
 
-    for _ in range(args.warmup):
-        step()
-    device_sync()
-    if world > 1:
-        torch.distributed.barrier()
-    device_sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    device_sync()
-    if world > 1:
-        torch.distributed.barrier()
-    device_sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
-    assert out is not None
+    dt = None
+    out = None
+    if not args.roofline_only:
+        for _ in range(args.warmup):
+            step()
+        device_sync()
+        if world > 1:
+            torch.distributed.barrier()
+        device_sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        device_sync()
+        if world > 1:
+            torch.distributed.barrier()
+        device_sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tt.item())
+        assert out is not None
 
     if helpers:
         helpers.close()
 
-    # ---- roofline leg: per-launch HIP events around the conv kernel.  The event bookkeeping is
-    # single-threaded, so this pass walks the pages serially with ONE analyzer and ONE worker thread.
+    # ---- roofline leg: per-launch HIP events around the conv kernel, in a SERIAL pass of the same program: one analyzer,
+    # one wave at a time, the two chains of a wave one after the other on one stream - so that a launch's event pair
+    # brackets that kernel alone.  `python bench.py --roofline-only` under rocprofv3 is the same pass (profiles/).
     roof = None
     if rank == 0 and not DRY:
+        kern = "conv_igemm / conv_splitk (fp32 MFMA implicit GEMM: every conv / linear layer of the four nets)"
         if args.workload == "analyzer":
-            from concurrent.futures import ThreadPoolExecutor
-
             solo = pool.workers[0]
-            solo.analyzer._pool.shutdown(wait=True)
-            solo.analyzer._pool = ThreadPoolExecutor(max_workers=1)
+            solo.analyzer.serial_chains = True
             solo.analyzer.stats = {"det_boxes": [], "layout_boxes": [], "cells": []}
-            prof_pages = pages[: min(8, len(pages))]
+            prof_waves = waves[: max(1, 16 // args.wave)]
+            units = sum(len(w) for w in prof_waves)
+            for w in prof_waves:  # shapes of the serial pass seen once (workspace growth stays out of the events)
+                solo(w)
+            torch.cuda.synchronize()
+            solo.analyzer.stats = {"det_boxes": [], "layout_boxes": [], "cells": []}
 
             def prof_step():
-                for p in prof_pages:
-                    solo(p)
-
-            units = len(prof_pages)
+                for w in prof_waves:
+                    solo(w)
         else:
             prof_step, units = step, args.pages
-        _lib.check(lib.ymk_prof_begin())
-        prof_step()
-        torch.cuda.synchronize()
-        ms, fl, ln = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-        _lib.check(lib.ymk_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(ln)))
-        alg_bytes = ctypes.c_double()
-        _lib.check(lib.ymk_prof_bytes(ctypes.byref(alg_bytes)))
-        if ms.value > 0:
-            achieved = fl.value / (ms.value * 1e-3) / 1e12
-            roof = {
-                "bound": "mfma",
-                "kernel": "conv_igemm / conv_splitk (fp32 MFMA implicit GEMM: every conv / linear layer of the four nets)",
-                "achieved": round(achieved, 2),
-                "peak": FP32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": None,
-                "algorithmic_bytes_per_launch": int(alg_bytes.value // max(1, ln.value)),
-                "launches_per_page": int(ln.value // units),
-                "avg_launch_us": round(ms.value * 1e3 / max(1, ln.value), 2),
-                "kernel_ms_per_page": round(ms.value / units, 3),
-                "gflop_per_page": round(fl.value / units / 1e9, 1),
-            }
-        pmc = os.path.join(ROOT, "profiles", f"r01_{args.workload}_pmc_conv_traffic.json")
+        roof = conv_roofline(lib, prof_step, units, "page", kern)
+        pmc = os.path.join(ROOT, "profiles", f"r02_{args.workload}_pmc_conv_traffic.json")
         if roof is not None and os.path.exists(pmc):
-            # HBM bytes per conv launch from the PMC passes of this same workload (rocprofv3 cannot run inside bench.py:
+            # HBM bytes per conv launch from the PMC passes of this same serial pass (rocprofv3 cannot run inside bench.py:
             # profiles/README.md has the commands); compare with algorithmic_bytes_per_launch
             with open(pmc) as f:
                 t = json.load(f)
             roof["traffic"] = t["hbm_bytes_per_launch"]
             roof["traffic_source"] = os.path.relpath(pmc, ROOT)
+        if roof is not None and dt is not None:
+            # the same FLOPs over the WALL clock of the timed region (all kernels, host gaps and overlap included)
+            wall_tf = roof["gflop_per_page"] * 1e-3 * pages_job * args.steps / dt / max(1, world)
+            roof["wall_implied"] = {"achieved": round(wall_tf, 2), "frac": round(wall_tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                                    "note": "gflop_per_page x pages/s per GPU: lower than `achieved` because the wall clock also holds "
+                                            "the non-conv kernels, D2H copies and host gaps; kernel_ms_per_page x pages_per_step <= ms_per_step "
+                                            "is asserted below"}
+            roof["conv_share_of_wall"] = round(roof["kernel_ms_per_page"] * len(seeds) * args.steps / (dt * 1e3), 4)
+            assert roof["conv_share_of_wall"] <= 1.05, "serial conv time exceeds the wall clock of the timed region"
         if args.workload == "analyzer" and roof is not None:
             # the north star quotes MFMA utilisation "on DBNet conv": the same measurement over the detector's launches alone
             det = solo.analyzer.text_detector
-            _lib.check(lib.ymk_prof_begin())
-            for p in prof_pages[:4]:
-                det.model(det.preprocess(p.dev))
-            torch.cuda.synchronize()
-            _lib.check(lib.ymk_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(ln)))
-            d_ach = fl.value / (ms.value * 1e-3) / 1e12
-            roof["dbnet_conv"] = {"achieved": round(d_ach, 2), "frac": round(d_ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                                  "launches_per_page": int(ln.value // 4), "kernel_ms_per_page": round(ms.value / 4, 3),
-                                  "gflop_per_page": round(fl.value / 4 / 1e9, 1)}
-        if args.workload == "analyzer" and not DRY:
+            d_roof = conv_roofline(lib, lambda: det.forward_pages([p.dev for p in prof_waves[0]]), len(prof_waves[0]), "page", kern)
+            roof["dbnet_conv"] = {k: d_roof[k] for k in ("achieved", "frac", "launches_per_page", "kernel_ms_per_page", "gflop_per_page")}
+            roof["dbnet_conv"]["batch"] = len(prof_waves[0])
             st = solo.analyzer.stats
             extra["measured_units_per_page"] = {
-                "ar_steps_last_batch": int(solo.analyzer.text_recognizer.model.last_ar_steps),
-                "noise_detector_boxes": float(np.mean(st["det_boxes"])),
+                "ar_steps_last_forward": int(solo.analyzer.text_recognizer.model.last_ar_steps),
+                "db_boxes_extracted": float(np.mean(st["det_boxes"])),
                 "noise_layout_boxes": float(np.mean(st["layout_boxes"])),
                 "table_cells": float(np.mean(st["cells"])),
             }
 
     # ---- CPU baseline leg (rank 0, N=1): oracle chain on the host cores, bounded sample
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not DRY:
-        t1 = time.perf_counter()
-        n_cpu = 0
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not DRY and not args.roofline_only:
         if args.workload == "analyzer":
             charset = pool.workers[0].analyzer.text_recognizer.charset
-            while n_cpu < 1 or (time.perf_counter() - t1 < 12.0 and n_cpu < 3):
-                cpu_analyzer_page(sds, pages[n_cpu % len(pages)], charset)
-                n_cpu += 1
-            sample = (f"{n_cpu} of the same synthetic pages through the oracle restatement (PyTorch-CPU fp32) of the `--lite` "
-                      "chain: detector + recogniser + layout + table nets with their pre/post-processing, "
-                      "PyTorch path for the detector too (onnxruntime is not installed)")
+            times = cpu_timed(lambda i: cpu_analyzer_page(sds, pages[i % len(pages)], charset, args.model_set), 2, 3, 90.0)
+            sample = (f"the same synthetic pages through the oracle restatement (PyTorch-CPU fp32) of the `-d cpu` chain with the "
+                      f"{args.model_set} model set: detector + recogniser + layout + table nets with their pre/post-processing (PyTorch "
+                      f"path for the detector too: onnxruntime is not installed); 2 warm-up pages, {len(times)} timed, median")
         else:
             from oracle.dbnet import dbnet_forward
 
             xc = x[:1].cpu()
-            while n_cpu < 2 or (time.perf_counter() - t1 < 10.0 and n_cpu < 6):
-                dbnet_forward(sds["det"], xc)
-                n_cpu += 1
-            sample = f"{n_cpu} pages of 1x3x1600x1184 through oracle/dbnet.py (detector net only)"
-        cdt = time.perf_counter() - t1
-        cpu = {"value": round(n_cpu / cdt, 4), "unit": "pages/s", "cores": torch.get_num_threads(), "kind": "port",
-               "sample": sample}
+            times = cpu_timed(lambda i: dbnet_forward(sds["det"], xc), 1, 4, 30.0)
+            sample = f"1x3x1600x1184 through oracle/dbnet.py (detector net only); 1 warm-up, {len(times)} timed, median"
+        cpu = {"value": round(1.0 / float(np.median(times)), 4), "unit": "pages/s", "cores": torch.get_num_threads(), "kind": "port",
+               "runs": [round(1.0 / t, 4) for t in times], "sample": sample}
 
     if rank == 0:
-        total_pages = args.pages * args.steps * world
         line = {
             "metric": metric,
-            "value": round(total_pages / dt, 3),
+            "value": round(pages_job * args.steps / dt, 3) if dt else None,
             "unit": "pages/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "ms_per_step": round(dt / args.steps * 1e3, 3) if dt else None,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": workload, "pages_per_step_per_gpu": args.pages,
-                       "parallelism": (f"page-sharded x{world} GPU(s), {n_procs} process(es) x {args.workers} pages in flight per GPU"
+            "config": {"workload": workload, "pages_per_step_per_gpu": len(seeds) if args.total_pages else args.pages,
+                       "parallelism": (f"page-sharded x{world} GPU(s), waves of {args.wave} pages, {n_procs} process(es) x {args.workers} "
+                                       f"waves in flight per GPU"
                                        if args.workload == "analyzer" else f"page-sharded x{world} GPU(s), one batch of {args.pages} per forward"),
                        "checkpoints": "seeded synthetic (no network)", **extra},
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        if args.total_pages:
+            line["config"]["total_pages_per_step"] = args.total_pages
         if DRY:
             line["dry_run"] = True
             line["metric"] = "DRY RUN - orchestration rehearsal with stub page workers, not a measurement"

@@ -16,7 +16,7 @@ class Page:
         self.paragraphs = [[0, 0, 100, 20], [0, 30, 100, 50]]
 
 
-def make_checkpoints():
+def make_checkpoints(model_set="lite"):
     return {k: OrderedDict(w=torch.arange(8, dtype=torch.float32) + i, steps=torch.tensor(7 + i, dtype=torch.int64))
             for i, k in enumerate(("det", "rec", "lay", "tab"))}
 
@@ -25,16 +25,16 @@ def calibrate_heads(sds, device, page):
     return sds
 
 
-def build_analyzer(device, sds):
+def build_analyzer(device, sds, model_set="lite"):
     want = make_checkpoints()
 
-    def work(page):
+    def work(wave):
         for k, sd in want.items():  # the broadcast / hand-over to helper processes kept every tensor intact
             for name, t in sd.items():
                 got = sds[k][name]
                 assert torch.equal(torch.as_tensor(got).to(t.dtype), t), (k, name)
-        time.sleep(0.002)
-        return page.seed
+        time.sleep(0.002 * len(wave))
+        return [page.seed for page in wave]
 
     work.analyzer = None
     return work

@@ -26,13 +26,19 @@ def _worker(rank, world, port, q):
     if rank == 0:
         g = torch.Generator().manual_seed(3)
         sd = {"a.weight": torch.randn(4, 3, 2, 2, generator=g), "a.bias": torch.randn(4, generator=g),
-              "bn.num_batches_tracked": torch.tensor(7, dtype=torch.int64)}
+              "bn.num_batches_tracked": torch.tensor(7, dtype=torch.int64),
+              "h.bf16": torch.tensor([0.3359375, -2.5, 1e-3], dtype=torch.bfloat16),
+              "h.f64": torch.tensor([1.0 + 2.0 ** -40, -3.0], dtype=torch.float64)}
     got = yd.broadcast_state_dict(sd, src=0, device=torch.device("cpu"))
     g = torch.Generator().manual_seed(3)
     exp_w = torch.randn(4, 3, 2, 2, generator=g)
     exp_b = torch.randn(4, generator=g)
     ok = torch.equal(got["a.weight"], exp_w) and torch.equal(got["a.bias"], exp_b)
-    ok = ok and int(got["bn.num_batches_tracked"]) == 7 and list(got) == ["a.weight", "a.bias", "bn.num_batches_tracked"]
+    ok = ok and int(got["bn.num_batches_tracked"]) == 7
+    ok = ok and list(got) == ["a.weight", "a.bias", "bn.num_batches_tracked", "h.bf16", "h.f64"]
+    # half-precision tensors are not truncated to integers, doubles are not narrowed to fp32 on the way
+    ok = ok and got["h.bf16"].dtype == torch.bfloat16 and torch.equal(got["h.bf16"], torch.tensor([0.3359375, -2.5, 1e-3], dtype=torch.bfloat16))
+    ok = ok and got["h.f64"].dtype == torch.float64 and torch.equal(got["h.f64"], torch.tensor([1.0 + 2.0 ** -40, -3.0], dtype=torch.float64))
     n_items = 7
     mine = yd.shard_indices(n_items, rank, world)
     merged = yd.gather_in_order([f"page{i}" for i in mine], n_items, rank, world)

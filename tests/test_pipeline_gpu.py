@@ -205,6 +205,62 @@ def test_document_analyzer_end_to_end(dev, page):
     assert orders == list(range(len(orders)))
 
 
+def _assert_same_schema(a, b, score_rtol=1e-4, box_tol=0):
+    """Two model_dump() trees: same structure, strings and integers; floats within score_rtol; integer box / point
+    coordinates within box_tol pixels."""
+    assert type(a) is type(b), (a, b)
+    if isinstance(a, dict):
+        assert a.keys() == b.keys()
+        for k in a:
+            if k in ("box", "points") and box_tol:
+                assert np.abs(np.asarray(a[k]) - np.asarray(b[k])).max() <= box_tol, (k, a[k], b[k])
+            else:
+                _assert_same_schema(a[k], b[k], score_rtol, box_tol)
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b), (len(a), len(b))
+        for x, y in zip(a, b):
+            _assert_same_schema(x, y, score_rtol, box_tol)
+    elif isinstance(a, float):
+        assert abs(a - b) <= score_rtol * max(abs(a), abs(b)) + 1e-9, (a, b)
+    else:
+        assert a == b, (a, b)
+
+
+def test_analyze_pages_equals_per_page_calls(dev, page):
+    """DocumentAnalyzer.analyze_pages shares device batches across the pages of a wave (DBNet / RT-DETR forwards over
+    several pages, one grouped PARSeq forward).  Every page's DocumentAnalyzerSchema must be the one `__call__` returns
+    for that page alone: same words, strings, cells, paragraphs and reading order; scores to 1e-4 (the implicit-GEMM
+    kernel picks its tile / split-K shape from the launch's M, so logits may differ in their last bits)."""
+    from yomitoku_amd import DocumentAnalyzer
+    from yomitoku_amd.utils.synth import dbnet_state_dict, parseq_state_dict, synthetic_page_with_truth
+    from yomitoku_amd.utils.synth_rtdetr import rtdetr_state_dict
+
+    configs = {
+        "ocr": {
+            "text_detector": {"from_pretrained": False},
+            "text_recognizer": {"model_name": "parseq-tiny-dynw-v4", "from_pretrained": False, "dynamic_width": True,
+                                "batch_bucketing": True, "source_downscale": True},
+        },
+        "layout_analyzer": {"layout_parser": {"from_pretrained": False},
+                            "table_structure_recognizer": {"from_pretrained": False}},
+    }
+    an = DocumentAnalyzer(configs=configs, device="cuda:0")
+    an.text_detector.model.load_state_dict(dbnet_state_dict(1234, out_bias=-3.0))
+    an.text_recognizer.model.load_state_dict(parseq_state_dict(1235, eos_bias=6.0))
+    an.layout.layout_parser.model.load_state_dict(rtdetr_state_dict(1240, num_classes=6, score_bias=-2.0))
+    an.layout.table_structure_recognizer.model.load_state_dict(rtdetr_state_dict(1241, num_classes=3, score_bias=-1.0))
+    imgs = [page[0], synthetic_page_with_truth(5, 1000, 1400)[0], synthetic_page_with_truth(6, 1400, 1000)[0], page[0]]
+    singles = [an(img)[0].model_dump() for img in imgs]
+    assert sum(len(s["words"]) for s in singles) > 0
+    for wave in (4, 3):
+        multi = an.analyze_pages(imgs, wave=wave)
+        assert len(multi) == len(imgs)
+        for one, (many, ocr_vis, lay_vis) in zip(singles, multi):
+            assert ocr_vis is None and lay_vis is None
+            _assert_same_schema(one, many.model_dump())
+    assert an.analyze_pages([]) == []
+
+
 def test_nested_configs_reach_the_modules(dev, tmp_path):
     """tests/test_document_analyzer.py::test_initialize and tests/test_ocr.py::test_ocr of the reference: per-module YAML
     overrides given through the nested `configs` dict land in the right module (on the cuda device instead of "cpu")."""

@@ -1,0 +1,80 @@
+"""One wave of pages through the truth-driven analyzer of bench.py, stage by stage (wall time with a device sync after
+each stage), then a cProfile of a whole wave (host hot spots) and - with YMK_PROF_DUMP=1 - the per-launch conv table."""
+import cProfile
+import ctypes
+import os
+import pstats
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import bench
+from yomitoku_amd import _lib
+
+dev = torch.device("cuda:0")
+W = int(os.environ.get("W", 8))
+SET = os.environ.get("SET", "lite")
+sds = bench.make_checkpoints(SET)
+pages = bench.make_pages(range(1000, 1000 + 2 * W), dev)
+sds = bench.calibrate_heads(sds, dev, bench.Page(0, dev))
+run = bench.build_analyzer(dev, sds, SET)
+an = run.analyzer
+an.serial_chains = True
+wave = pages[:W]
+run(wave)
+run(pages[W:])
+torch.cuda.synchronize()
+
+
+def T(label, f, *a):
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    r = f(*a)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"{label:28s} host {1e3 * (t1 - t):8.2f} ms   +drain {1e3 * (t2 - t1):7.2f} ms   per page {1e3 * (t2 - t) / W:6.2f} ms", flush=True)
+    return r
+
+
+an.truth = {p.dev.data_ptr(): p for p in wave}
+devs = [p.dev for p in wave]
+det, rec = an.text_detector, an.text_recognizer
+maps = T("det.forward_pages (+D2H)", det.forward_pages, devs)
+sizes = [tuple(int(v) for v in p.shape[:2]) for p in devs]
+T("det.extract_boxes(truth)", det.extract_boxes, [p.truth_map for p in wave], sizes)
+preps = T("rec.preprocess x W", lambda: [rec.preprocess(d, p.quads) for d, p in zip(devs, wave)])
+jobs = [(ds, plans) for batches, _, ds, _ in preps for plans in batches]
+print("mini-batches", len(jobs), "lines", sum(len(j[1]) for j in jobs))
+tensors = T("rec.collate all", lambda: [rec._collate(ds, plans) for ds, plans in jobs])
+out = T("rec.forward_groups", rec.model.forward_groups, tensors)
+print("   ar steps per group: max", max(out[2]), "mean", sum(out[2]) / len(out[2]))
+st = T("rec.token_stats+cpu", lambda: [t.cpu().numpy() for t in rec.model.token_stats(out[0])])
+T("rec.recognize_pages total", rec.recognize_pages, devs, [p.quads for p in wave])
+lp, ts = an.layout.layout_parser, an.layout.table_structure_recognizer
+T("layout.parse_pages", lp.parse_pages, devs)
+T("tables.recognize_pages", ts.recognize_pages, devs, [p.tables for p in wave])
+print("tables in wave", sum(len(p.tables) for p in wave))
+T("_ocr_pages", an._ocr_pages, devs)
+lays = T("_layout_pages", an._layout_pages, devs)
+T("wave total (serial chains)", run, wave)
+an.serial_chains = False
+T("wave total (2 streams)", run, wave)
+an.serial_chains = True
+
+pr = cProfile.Profile()
+pr.enable()
+run(wave)
+pr.disable()
+pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+
+if os.environ.get("YMK_PROF_DUMP"):
+    lib = _lib.load()
+    lib.ymk_prof_begin()
+    run(wave)
+    torch.cuda.synchronize()
+    ms, fl, ln = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+    lib.ymk_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(ln))
+    print("conv total ms", ms.value, "GF", fl.value / 1e9, "launches", ln.value)

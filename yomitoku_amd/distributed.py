@@ -74,34 +74,30 @@ def broadcast_state_dict(sd: Mapping[str, torch.Tensor] | None, src: int = 0, de
     meta = meta[0]
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    f_numel = sum(int(torch.Size(s).numel()) for _, s, d in meta if d.startswith("float"))
-    i_numel = sum(int(torch.Size(s).numel()) for _, s, d in meta if not d.startswith("float"))
-    fbuf = torch.empty(f_numel, dtype=torch.float32, device=device)
-    ibuf = torch.empty(max(i_numel, 1), dtype=torch.int64, device=device)
+    def kind(d):  # which flat message a tensor travels in: fp32 (incl. f16 / bf16, widened losslessly), fp64, or int64
+        dt = getattr(torch, d)
+        return "f64" if dt == torch.float64 else ("f32" if dt.is_floating_point else "i64")
+
+    wire = {"f32": torch.float32, "f64": torch.float64, "i64": torch.int64}
+    numel = {k: sum(int(torch.Size(s).numel()) for _, s, d in meta if kind(d) == k) for k in wire}
+    bufs = {k: torch.empty(max(numel[k], 1), dtype=dt, device=device) for k, dt in wire.items()}
     if rank == src:
-        fo = io = 0
+        off = dict.fromkeys(wire, 0)
         for k, s, d in meta:
-            v = sd[k]
+            v, c = sd[k], kind(d)
             n = v.numel()
-            if d.startswith("float"):
-                fbuf[fo : fo + n] = v.reshape(-1).to(device=device, dtype=torch.float32)
-                fo += n
-            else:
-                ibuf[io : io + n] = v.reshape(-1).to(device=device, dtype=torch.int64)
-                io += n
-    dist.broadcast(fbuf, src=src)
-    dist.broadcast(ibuf, src=src)
+            bufs[c][off[c] : off[c] + n] = v.reshape(-1).to(device=device, dtype=wire[c])
+            off[c] += n
+    for c in wire:
+        if numel[c]:
+            dist.broadcast(bufs[c], src=src)
     if rank == src:
         return sd
     out = OrderedDict()
-    fcpu, icpu = fbuf.cpu(), ibuf.cpu()
-    fo = io = 0
+    host = {c: b.cpu() for c, b in bufs.items()}
+    off = dict.fromkeys(wire, 0)
     for k, s, d in meta:
-        n = int(torch.Size(s).numel())
-        if d.startswith("float"):
-            out[k] = fcpu[fo : fo + n].reshape(s).to(getattr(torch, d)).clone()
-            fo += n
-        else:
-            out[k] = icpu[io : io + n].reshape(s).to(getattr(torch, d)).clone()
-            io += n
+        n, c = int(torch.Size(s).numel()), kind(d)
+        out[k] = host[c][off[c] : off[c] + n].reshape(s).to(getattr(torch, d)).clone()
+        off[c] += n
     return out

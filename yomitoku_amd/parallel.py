@@ -11,23 +11,20 @@ Per-page results are identical to the serial path: replicas share nothing mutabl
 
 from __future__ import annotations
 
-import os
 import queue
-import sys
 from concurrent.futures import ThreadPoolExecutor
 from typing import Callable, Iterable, List
 
 
 class PageParallel:
-    def __init__(self, make_worker: Callable[[int], Callable], n_workers: int = 4, switch_interval: float = 2e-4):
-        """make_worker(i) -> callable(page_item) that owns everything it mutates (its own analyzer).
+    def __init__(self, make_worker: Callable[[int], Callable], n_workers: int = 4):
+        """make_worker(i) -> callable(item) that owns everything it mutates (its own analyzer); an item is a page
+        or a wave of pages (DocumentAnalyzer.analyze_pages).
 
-        switch_interval: every library call returns into Python by re-taking the GIL; with CPython's default
-        5 ms switch interval a worker coming back from a 50 us kernel launch can wait 5 ms behind another
-        worker's post-processing loop, and the device drains meanwhile.  The workers are launch-latency
-        bound, so the interval is lowered for the process (None leaves it alone)."""
-        if switch_interval is not None:
-            sys.setswitchinterval(float(os.environ.get("YMK_SWITCH_INTERVAL", switch_interval)))
+        Note for applications: every library call returns into Python by re-taking the GIL; with CPython's default
+        5 ms switch interval a worker coming back from a 50 us kernel launch can wait 5 ms behind another worker's
+        post-processing loop.  `sys.setswitchinterval(2e-4)` in the APPLICATION helps (bench.py does it); this
+        library does not touch process-wide interpreter settings."""
         self.n_workers = int(n_workers)
         self._free: "queue.Queue" = queue.Queue()
         self.workers = [make_worker(i) for i in range(self.n_workers)]

@@ -35,12 +35,13 @@ class DBnetPostProcessor:
         self.unclip_ratio = unclip_ratio
         self._pinned = {}
 
-    def maps_to_host(self, maps: torch.Tensor) -> np.ndarray:
-        """n x 1 x H x W device maps -> one pinned host array n x H x W (one DMA for the whole batch)."""
+    def maps_to_host(self, maps: torch.Tensor, slot: int = 0) -> np.ndarray:
+        """n x 1 x H x W device maps -> one pinned host array n x H x W (one DMA for the whole batch).  `slot` names the
+        pinned buffer: forwards of one call whose maps must stay valid together use different slots."""
         shape = (maps.shape[0], maps.shape[2], maps.shape[3])
-        host = self._pinned.get(shape)
+        host = self._pinned.get((slot,) + shape)
         if host is None:
-            host = self._pinned[shape] = torch.empty(shape, dtype=torch.float32, pin_memory=True)
+            host = self._pinned[(slot,) + shape] = torch.empty(shape, dtype=torch.float32, pin_memory=True)
         host.copy_(maps.detach().to(torch.float32).reshape(shape), non_blocking=True)
         torch.cuda.current_stream(maps.device).synchronize()
         return host.numpy()
@@ -103,33 +104,46 @@ class TextDetector(BaseModule):
 
     MAX_PAGES_PER_FORWARD = 8  # bounds the activation workspace (a 1600 x 1184 page holds ~2 GB of fp32 maps)
 
-    def detect_pages(self, imgs):
-        """`__call__` for several pages: pages whose network input has the same size share DBNet forwards of up to
-        MAX_PAGES_PER_FORWARD images (images of a batch are independent), the probability maps come back in one DMA per
-        forward and the box extraction (C++, GIL released) runs for the pages of a forward concurrently.
-        Returns one TextDetectorSchema per page, in input order."""
-        from concurrent.futures import ThreadPoolExecutor
-
+    def forward_pages(self, imgs):
+        """Pre-processing + DBNet forward for several pages: pages whose network input has the same size share forwards
+        of up to MAX_PAGES_PER_FORWARD images (images of a batch are independent); the probability maps of a forward
+        come back in one DMA.  Returns one host map (H' x W' float32, a view of a pinned buffer that the next
+        forward_pages call of this module reuses) per page, in input order."""
         pages = [img if isinstance(img, torch.Tensor) else imaging.page_to_device(img, self.device) for img in imgs]
         cfg = self._cfg.data
         by_size = {}
         for i, page in enumerate(pages):
             dims = imaging.resize_shortest_edge_dims(page.shape[0], page.shape[1], cfg.shortest_size, cfg.limit_size)
             by_size.setdefault(dims, []).append(i)
-        results = [None] * len(pages)
-        if not hasattr(self, "_post_pool"):
-            self._post_pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="ymk-dbpost")
+        maps = [None] * len(pages)
+        slot = 0
         for (oh, ow), members in by_size.items():
             for start in range(0, len(members), self.MAX_PAGES_PER_FORWARD):
                 idx = members[start : start + self.MAX_PAGES_PER_FORWARD]
                 x = torch.empty((len(idx), 3, oh, ow), dtype=torch.float32, device=pages[idx[0]].device)
                 for k, i in enumerate(idx):
                     imaging.detector_tensor(pages[i], cfg.shortest_size, cfg.limit_size, out=x[k])
-                maps = self.post_processor.maps_to_host(self.model(x)["binary"])
-                sizes = [tuple(int(v) for v in pages[i].shape[:2]) for i in idx]
-                for i, (quads, scores) in zip(idx, self._post_pool.map(self.post_processor, list(maps), sizes)):
-                    results[i] = TextDetectorSchema(points=quads, scores=scores)
-        return results
+                host = self.post_processor.maps_to_host(self.model(x)["binary"], slot)
+                slot += 1
+                for k, i in enumerate(idx):
+                    maps[i] = host[k]
+        return maps
+
+    def extract_boxes(self, maps, sizes):
+        """DB box extraction (C++, GIL released) for several maps concurrently; sizes: original (height, width) per
+        page.  Returns one TextDetectorSchema per map."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        if not hasattr(self, "_post_pool"):
+            self._post_pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="ymk-dbpost")
+        return [TextDetectorSchema(points=quads, scores=scores)
+                for quads, scores in self._post_pool.map(self.post_processor, list(maps), list(sizes))]
+
+    def detect_pages(self, imgs):
+        """`__call__` for several pages (forward_pages + extract_boxes); one TextDetectorSchema per page."""
+        pages = [img if isinstance(img, torch.Tensor) else imaging.page_to_device(img, self.device) for img in imgs]
+        maps = self.forward_pages(pages)
+        return self.extract_boxes(maps, [tuple(int(v) for v in p.shape[:2]) for p in pages])
 
     def __call__(self, img):
         ori_h, ori_w = img.shape[:2]
