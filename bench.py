@@ -185,12 +185,6 @@ def build_analyzer(device, sds, model_set="lite"):
 
         truth = None  # {device pointer of the page: Page}
         stats = None
-        serial_chains = False  # roofline pass: the two chains one after the other (clean per-kernel durations)
-
-        def _on_stream(self, name, fn, *args):
-            if self.serial_chains:
-                return fn(*args)
-            return super()._on_stream(name, fn, *args)
 
         def _ocr_pages(self, pages):
             truth = [self.truth[p.data_ptr()] for p in pages]
@@ -565,7 +559,7 @@ def main():
         kern = "conv_igemm / conv_splitk (fp32 MFMA implicit GEMM: every conv / linear layer of the four nets)"
         if args.workload == "analyzer":
             solo = pool.workers[0]
-            solo.analyzer.serial_chains = True
+            solo.analyzer.concurrent_chains = False  # the two chains one after the other: an event pair brackets one kernel
             solo.analyzer.stats = {"det_boxes": [], "layout_boxes": [], "cells": []}
             prof_waves = waves[: max(1, 16 // args.wave)]
             units = sum(len(w) for w in prof_waves)

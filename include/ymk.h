@@ -127,6 +127,11 @@ int ymk_db_postprocess(const float* prob_host, int h, int w, float thresh, float
  * ymk_prof_bytes: algorithmic HBM bytes of the launches since the last begin (input view + weights + output
  * [+ residual], each counted once) - what the PMC traffic of the same launches is compared with. */
 int ymk_prof_begin(void);
+/* Test / measurement knobs, process-wide (never touched by the product path; defaults in parentheses):
+ *   "splitk_force" (-1)  >= 0: that split-K tile shape for every eligible launch      "no_splitk" (0)  1: conv_igemm only
+ *   "conv_variant" (0)   experimental conv_igemm schedules (tools/conv_sweep.py)       "prof_dump" (0)  1: ymk_prof_end
+ *   prints one line per launch      "parseq_unfused" (0)  1: per-op PARSeq decoder step at every width */
+int ymk_debug_option(const char* key, int value);
 int ymk_prof_end(double* conv_ms, double* conv_flop, int64_t* conv_launches);
 int ymk_prof_bytes(double* conv_bytes);
 

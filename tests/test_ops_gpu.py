@@ -53,16 +53,25 @@ CASES = [
 
 # kernel routing: the library's own choice, conv_igemm only, or one fixed split-K shape
 # (ymk_conv.hip try_splitk candidates: 64x64/4, 64x32/4, 64x32/8, 32x32/4, 32x32/8 waves)
-ROUTES = [("auto", {}), ("igemm", {"YMK_NO_SPLITK": "1"})] + [(f"splitk{i}", {"YMK_SPLITK_FORCE": str(i)}) for i in range(5)]
+ROUTES = ([("auto", {}), ("igemm", {"no_splitk": 1})] + [(f"splitk{i}", {"splitk_force": i}) for i in range(5)]
+          + [(f"variant{v}", {"no_splitk": 1, "conv_variant": v}) for v in range(1, 7)])
 
 
 @pytest.mark.parametrize("route", ROUTES, ids=[r[0] for r in ROUTES])
 @pytest.mark.parametrize("case", CASES)
-def test_conv2d_matches_torch(dev, case, route, monkeypatch):
-    from yomitoku_amd import hipops
+def test_conv2d_matches_torch(dev, case, route):
+    from yomitoku_amd import _lib, hipops
 
-    for key, val in route[1].items():
-        monkeypatch.setenv(key, val)
+    try:
+        for key, val in route[1].items():
+            _lib.debug_option(key, val)
+        _conv_case(dev, case, hipops)
+    finally:
+        for key, val in (("splitk_force", -1), ("no_splitk", 0), ("conv_variant", 0)):
+            _lib.debug_option(key, val)
+
+
+def _conv_case(dev, case, hipops):
     n, cin, h, w, cout, k, stride, pad, dil = case
     g = torch.Generator().manual_seed(hash(case) % (2**31))
     x = torch.randn(n, cin, h, w, generator=g)

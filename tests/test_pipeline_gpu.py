@@ -188,7 +188,7 @@ def test_document_analyzer_end_to_end(dev, page):
 
     from yomitoku_amd.utils.synth_rtdetr import rtdetr_state_dict
 
-    an.text_detector.model.load_state_dict(dbnet_state_dict(1234, out_bias=-3.0))
+    an.text_detector.model.load_state_dict(dbnet_state_dict(1234, out_bias=-2.0))
     an.layout.layout_parser.model.load_state_dict(rtdetr_state_dict(1240, num_classes=6, score_bias=-2.0))
     an.layout.table_structure_recognizer.model.load_state_dict(rtdetr_state_dict(1241, num_classes=3, score_bias=-1.0))
     results, ocr_vis, layout_vis = an(img)
@@ -245,7 +245,7 @@ def test_analyze_pages_equals_per_page_calls(dev, page):
                             "table_structure_recognizer": {"from_pretrained": False}},
     }
     an = DocumentAnalyzer(configs=configs, device="cuda:0")
-    an.text_detector.model.load_state_dict(dbnet_state_dict(1234, out_bias=-3.0))
+    an.text_detector.model.load_state_dict(dbnet_state_dict(1234, out_bias=-2.0))
     an.text_recognizer.model.load_state_dict(parseq_state_dict(1235, eos_bias=6.0))
     an.layout.layout_parser.model.load_state_dict(rtdetr_state_dict(1240, num_classes=6, score_bias=-2.0))
     an.layout.table_structure_recognizer.model.load_state_dict(rtdetr_state_dict(1241, num_classes=3, score_bias=-1.0))

@@ -1,6 +1,5 @@
-"""Per-launch conv/GEMM timings (YMK_PROF_DUMP) for each net at the shapes the analyzer bench uses."""
+"""Per-launch conv/GEMM timings (ymk_debug_option prof_dump) for each net at the shapes the analyzer bench uses."""
 import ctypes, os, sys, time
-os.environ["YMK_PROF_DUMP"] = "1"
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 import bench
@@ -9,6 +8,7 @@ from yomitoku_amd.nets import DBNet, PARSeq, RTDETRv2
 
 dev = torch.device("cuda:0")
 lib = _lib.load()
+_lib.debug_option("prof_dump", 1)
 sds = bench.make_checkpoints()
 
 

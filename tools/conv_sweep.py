@@ -1,0 +1,70 @@
+"""conv_igemm schedule experiments: the analyzer's heavy shapes x ymk_debug_option("conv_variant", v), timed by the
+library's own per-launch HIP events (ymk_prof_*).  Prints TFLOP/s per (shape, variant); median of 5 launches."""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from yomitoku_amd import _lib
+
+dev = torch.device("cuda:0")
+lib = _lib.load()
+# (name, n, h, w, cin, cout, k, stride, pad, dil, act, residual)
+SHAPES = [
+    ("dbnet l4 3x3 512->512 d2", 8, 100, 74, 512, 512, 3, 1, 2, 2, 1, 0),
+    ("dbnet l4 1x1 1024->2048", 1, 1, 59200, 1024, 2048, 1, 1, 0, 1, 1, 1),
+    ("dbnet l4 1x1 512->2048", 1, 1, 59200, 512, 2048, 1, 1, 0, 1, 1, 1),
+    ("dbnet l4 1x1 2048->512", 1, 1, 59200, 2048, 512, 1, 1, 0, 1, 1, 0),
+    ("dbnet l3 3x3 256->256", 8, 100, 74, 256, 256, 3, 1, 1, 1, 1, 0),
+    ("dbnet l2 3x3 128->128", 8, 200, 148, 128, 128, 3, 1, 1, 1, 1, 0),
+    ("dbnet l1 1x1 64->256 +res", 1, 1, 947200, 64, 256, 1, 1, 0, 1, 1, 1),
+    ("dbnet dec 1x1 256->256", 1, 1, 947200, 256, 256, 1, 1, 0, 1, 0, 0),
+    ("rtdetr enc 3x3 256->256 80x80", 8, 80, 80, 256, 256, 3, 1, 1, 1, 2, 0),
+    ("rtdetr bb 1x1 256->1024 40x40", 1, 1, 12800, 256, 1024, 1, 1, 0, 1, 1, 1),
+    ("parseq qkv 192->576", 1, 1, 176496, 192, 576, 1, 1, 0, 1, 0, 0),
+    ("parseq fc1 192->768 gelu", 1, 1, 176496, 192, 768, 1, 1, 0, 1, 4, 0),
+    ("parseq fc2 768->192 +res", 1, 1, 176496, 768, 192, 1, 1, 0, 1, 0, 1),
+    ("parseq proj 192->192 +res", 1, 1, 176496, 192, 192, 1, 1, 0, 1, 0, 1),
+    ("parseq head 192->7119", 1, 1, 66155, 192, 7119, 1, 1, 0, 1, 0, 0),
+]
+VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "0,1,2,3,4,5,6").split(",")]
+
+
+def run(shape, variant, reps=5):
+    name, n, h, w, cin, cout, k, stride, pad, dil, act, res = shape
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = torch.randn(n, h, w, cin, generator=g).to(dev)
+    wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).contiguous()
+    sc = torch.rand(cout, generator=g).add_(0.5).contiguous()
+    bi = torch.randn(cout, generator=g).contiguous()
+    oh = (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    ow = (w + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    y = torch.empty(n, oh, ow, cout, device=dev)
+    r = torch.randn(n, oh, ow, cout, generator=g).to(dev) if res else None
+    _lib.debug_option("conv_variant", variant)
+    times = []
+    for i in range(reps + 1):
+        _lib.check(lib.ymk_prof_begin())
+        _lib.check(lib.ymk_op_conv2d(x.data_ptr(), n, h, w, cin, wt.data_ptr(), cout, cin, k, k, sc.data_ptr(), bi.data_ptr(),
+                                     _lib.ptr(r), stride, pad, dil, act, 0, y.data_ptr(), None))
+        ms, fl, ln = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        _lib.check(lib.ymk_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(ln)))
+        if i:
+            times.append(ms.value)
+    _lib.debug_option("conv_variant", 0)
+    t = float(np.median(times))
+    return fl.value / (t * 1e-3) / 1e12, t * 1e3, float(y.flatten()[:4096].double().sum().item())
+
+
+print(f"{'shape':34s} " + " ".join(f"{'v' + str(v):>14s}" for v in VARIANTS))
+for shape in SHAPES:
+    cells = []
+    ref = None
+    for v in VARIANTS:
+        tf, us, chk = run(shape, v)
+        ref = chk if ref is None else ref
+        cells.append(f"{tf:6.1f}TF{us:6.0f}us" + ("" if abs(chk - ref) <= 1e-3 * max(1.0, abs(ref)) else "!"))
+    print(f"{shape[0]:34s} " + " ".join(cells), flush=True)

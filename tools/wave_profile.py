@@ -21,7 +21,7 @@ pages = bench.make_pages(range(1000, 1000 + 2 * W), dev)
 sds = bench.calibrate_heads(sds, dev, bench.Page(0, dev))
 run = bench.build_analyzer(dev, sds, SET)
 an = run.analyzer
-an.serial_chains = True
+an.concurrent_chains = False
 wave = pages[:W]
 run(wave)
 run(pages[W:])
@@ -56,13 +56,20 @@ T("rec.recognize_pages total", rec.recognize_pages, devs, [p.quads for p in wave
 lp, ts = an.layout.layout_parser, an.layout.table_structure_recognizer
 T("layout.parse_pages", lp.parse_pages, devs)
 T("tables.recognize_pages", ts.recognize_pages, devs, [p.tables for p in wave])
+from yomitoku_amd import imaging as _im
+flat = [(d, b) for d, p in zip(devs, wave) for b in p.tables]
+xb = torch.empty((len(flat), 3, 640, 640), dtype=torch.float32, device=dev)
+metas = T("  tables: resize crops", lambda: [_im.rtdetr_tensor(d, b, (640, 640), out=xb[k])[1:] for k, (d, b) in enumerate(flat)])
+preds = T("  tables: forward", ts.model, xb)
+lg, bx = T("  tables: D2H", lambda: (preds["pred_logits"].cpu().numpy(), preds["pred_boxes"].cpu().numpy()))
+T("  tables: postprocess", lambda: [ts.postprocess({"pred_logits": lg[k:k+1], "pred_boxes": bx[k:k+1]}, {"size": m[0], "offset": m[1]}) for k, m in enumerate(metas)])
 print("tables in wave", sum(len(p.tables) for p in wave))
 T("_ocr_pages", an._ocr_pages, devs)
 lays = T("_layout_pages", an._layout_pages, devs)
 T("wave total (serial chains)", run, wave)
-an.serial_chains = False
+an.concurrent_chains = True
 T("wave total (2 streams)", run, wave)
-an.serial_chains = True
+an.concurrent_chains = False
 
 pr = cProfile.Profile()
 pr.enable()
@@ -72,6 +79,7 @@ pstats.Stats(pr).sort_stats("tottime").print_stats(28)
 
 if os.environ.get("YMK_PROF_DUMP"):
     lib = _lib.load()
+    _lib.debug_option("prof_dump", 1)
     lib.ymk_prof_begin()
     run(wave)
     torch.cuda.synchronize()

@@ -54,6 +54,7 @@ SIGNATURES = {
         [c_void_p, c_int, c_int, c_float, c_float, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_int,
          POINTER(c_int)],
     ),
+    "ymk_debug_option": (c_int, [c_char_p, c_int]),
     "ymk_prof_begin": (c_int, []),
     "ymk_prof_end": (c_int, [POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
     "ymk_prof_bytes": (c_int, [POINTER(c_double)]),
@@ -105,6 +106,11 @@ def check(status: int, what: str = "ymk call"):
     if status != 0:
         msg = load().ymk_last_error()
         raise YmkError(f"{what} failed: {msg.decode('utf-8', 'replace') if msg else status}")
+
+
+def debug_option(key: str, value: int):
+    """Test / measurement knob of the library (include/ymk.h: ymk_debug_option)."""
+    check(load().ymk_debug_option(key.encode(), int(value)), f"ymk_debug_option({key})")
 
 
 def ptr(t):

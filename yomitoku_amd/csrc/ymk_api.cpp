@@ -17,6 +17,8 @@ void row_maxprob(hipStream_t s, const float* logits, int rows, int C, int* ids, 
 void prof_begin();
 void prof_end(double* ms, double* flop, int64_t* launches);
 double prof_bytes();
+bool conv_debug_option(const std::string& key, int value);
+bool parseq_debug_option(const std::string& key, int value);
 }  // namespace ymk
 
 struct ymk_model {
@@ -149,6 +151,14 @@ int ymk_rtdetr_forward(ymk_model* m, const float* x_dev, int b, int h, int w, fl
   YMK_CHECK(m && x_dev && logits_dev && boxes_dev, "null argument");
   YMK_HIP(hipSetDevice(m->device));
   ymk::rtdetr_forward(m->impl, x_dev, b, h, w, logits_dev, boxes_dev, (hipStream_t)stream);
+  YMK_API_END
+}
+
+int ymk_debug_option(const char* key, int value) {
+  YMK_API_BEGIN
+  YMK_CHECK(key != nullptr, "null key");
+  const std::string k(key);
+  YMK_CHECK(ymk::conv_debug_option(k, value) || ymk::parseq_debug_option(k, value), "unknown debug option: " + k);
   YMK_API_END
 }
 

@@ -25,6 +25,7 @@
 // Two kernels share the operand layout and the epilogue: conv_igemm (above) for launches that fill the
 // chip, conv_splitk for grid-starved ones (K split over the waves of a block, see its comment);
 // conv2d() picks per launch from the GEMM shape alone, so a given shape always takes the same path.
+#include <atomic>
 #include <deque>
 #include <mutex>
 
@@ -145,15 +146,22 @@ __device__ __forceinline__ void epilogue_tile(const ConvK& p, const float* Cs, i
   }
 }
 
-template <int BM, int BN, int WM, int WN, int MODE>
-__global__ __launch_bounds__(256, 2) void conv_igemm(ConvK p) {
-  static_assert(WM * WN == 4, "4 waves per block");
+// VAR (experiments, selected per launch through ymk_debug_option("conv_variant")):
+//   bit 0: MFMA order interleaved across the wave's accumulators (k step outermost) instead of 4 dependent steps per tile
+//   bit 1: s_setprio 1 around the MFMA cluster of a K tile
+template <int BM, int BN, int WM, int WN, int MODE, int VAR = 0>
+__global__ __launch_bounds__(64 * WM * WN, (2 * (BM + BN) * LDK * 4 <= 80 * 1024 ? 2 : 1) * WM * WN / 4) void conv_igemm(ConvK p) {
+  constexpr int NT = 64 * WM * WN;             // 4 or 8 waves
+  static_assert(NT == 256 || NT == 512, "4 or 8 waves per block");
   constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;  // 32x32 MFMA tiles per wave
-  constexpr int APASS = BM / 32, BPASS = BN / 32;
+  constexpr int RPP = NT / 8;                  // rows staged per pass (8 threads x 16 B per 32-float row)
+  constexpr int APASS = BM / RPP, BPASS = BN / RPP;
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must divide by the staging pass");
   constexpr int STAGE = (BM + BN) * LDK;
   constexpr int LDC = BN + 4;  // epilogue staging row (floats)
-  static_assert(BM * LDC <= 2 * STAGE, "epilogue tile must fit the staging LDS");
+  constexpr int EROWS = (2 * STAGE / LDC) / 32 * 32 < BM ? (2 * STAGE / LDC) / 32 * 32 : BM;  // rows per epilogue pass
+  static_assert(EROWS >= WTM && EROWS % WTM == 0, "an epilogue pass must hold whole wave tiles");
   __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
   const int t = threadIdx.x;
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvK p) {
   int pixb[APASS], ih0[APASS], iw0[APASS];
 #pragma unroll
   for (int i = 0; i < APASS; ++i) {
-    const int m = m0 + rowb + 32 * i;
+    const int m = m0 + rowb + RPP * i;
     if (m < p.M) {
       const int ohw = p.OH * p.OW;
       const int n = m / ohw, rem = m - n * ohw;
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvK p) {
     }
 #pragma unroll
     for (int j = 0; j < BPASS; ++j)
-      rb[j] = *reinterpret_cast<const f32x4*>(wrow + (size_t)(32 * j) * p.Kpad + kt * 32);
+      rb[j] = *reinterpret_cast<const f32x4*>(wrow + (size_t)(RPP * j) * p.Kpad + kt * 32);
   };
 
   auto store_tile = [&](int buf) {
@@ -237,10 +245,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvK p) {
     float* Bs = As + BM * LDK;
 #pragma unroll
     for (int i = 0; i < APASS; ++i)
-      *reinterpret_cast<f32x4*>(As + (rowb + 32 * i) * LDK + colq * 4) = ra[i];
+      *reinterpret_cast<f32x4*>(As + (rowb + RPP * i) * LDK + colq * 4) = ra[i];
 #pragma unroll
     for (int j = 0; j < BPASS; ++j)
-      *reinterpret_cast<f32x4*>(Bs + (rowb + 32 * j) * LDK + colq * 4) = rb[j];
+      *reinterpret_cast<f32x4*>(Bs + (rowb + RPP * j) * LDK + colq * 4) = rb[j];
   };
 
   // ---- MFMA coordinates
@@ -267,6 +275,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvK p) {
 
     const float* As = lds + buf * STAGE + (wm * WTM + li) * LDK + lh * 4;
     const float* Bs = lds + buf * STAGE + BM * LDK + (wn * WTN + li) * LDK + lh * 4;
+    if (VAR & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) {
       f32x4 fa[TM], fb[TN];
@@ -276,36 +285,53 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvK p) {
 #pragma unroll
       for (int b = 0; b < TN; ++b)
         fb[b] = *reinterpret_cast<const f32x4*>(Bs + b * 32 * LDK + kc * 8);
+      if (VAR & 1) {  // k step outermost: consecutive MFMAs never share an accumulator
 #pragma unroll
-      for (int a = 0; a < TM; ++a)
+        for (int st = 0; st < 4; ++st)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, fb[b].x, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, fb[b].y, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, fb[b].z, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
-        }
+          for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][st], fb[b][st], acc[a][b], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, fb[b].x, acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, fb[b].y, acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, fb[b].z, acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
+          }
+      }
     }
+    if (VAR & 2) __builtin_amdgcn_s_setprio(0);
 
     if (kt + 1 < ktiles) store_tile(buf ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue: accumulators -> LDS tile [BM][LDC] -> 16 B per lane, full rows coalesced.
+  // ---- epilogue: accumulators -> LDS tile [EROWS][LDC] -> 16 B per lane, full rows coalesced; a tile taller than the
+  // staging LDS goes in BM / EROWS passes (the waves owning the rows of a pass write, every thread stores).
   // D[row][col]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* Cs = lds;
 #pragma unroll
-  for (int a = 0; a < TM; ++a)
+  for (int e0 = 0; e0 < BM; e0 += EROWS) {
+    if (e0 > 0) __syncthreads();
+    if (wm * WTM >= e0 && wm * WTM < e0 + EROWS) {
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
+      for (int a = 0; a < TM; ++a)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * WTM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        Cs[row * LDC + wn * WTN + b * 32 + li] = acc[a][b][r];
-      }
-  __syncthreads();
-
-  epilogue_tile<BM, BN, 256>(p, Cs, m0, n0, t);
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = wm * WTM - e0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            Cs[row * LDC + wn * WTN + b * 32 + li] = acc[a][b][r];
+          }
+    }
+    __syncthreads();
+    epilogue_tile<EROWS, BN, NT>(p, Cs, m0 + e0, n0, t);
+  }
 }
 
 // ---- grid-starved shapes (batch-1 RT-DETR stages, decoder linears, the PARSeq head): split K over the
@@ -482,13 +508,20 @@ static ProfState g_prof;
 
 // conv_igemm launches with fewer blocks than this go to the split-K kernel (1.5 blocks per CU)
 constexpr int SPLITK_MAX_GRID = 384;
-static int splitk_forced() {  // YMK_SPLITK_FORCE=<candidate index>: that split-K shape for every launch (kernel tests)
-  const char* e = getenv("YMK_SPLITK_FORCE");
-  return e && e[0] >= '0' && e[0] <= '9' ? e[0] - '0' : -1;
-}
-static bool no_splitk() {  // YMK_NO_SPLITK=1: every launch through conv_igemm (A/B profiling, kernel tests)
-  const char* e = getenv("YMK_NO_SPLITK");
-  return e && e[0] == '1';
+// test / measurement knobs (ymk_debug_option): process-wide, read per launch, never set on the product path
+static std::atomic<int> g_splitk_force{-1};  // >= 0: that split-K candidate for every eligible launch (kernel tests)
+static std::atomic<int> g_no_splitk{0};      // 1: every launch through conv_igemm (A/B profiling, kernel tests)
+static std::atomic<int> g_conv_variant{0};   // conv_igemm experiment selector, see launch_variant()
+static std::atomic<int> g_prof_dump{0};      // 1: ymk_prof_end prints one line per launch to stderr
+static int splitk_forced() { return g_splitk_force.load(std::memory_order_relaxed); }
+static bool no_splitk() { return g_no_splitk.load(std::memory_order_relaxed) != 0; }
+bool conv_debug_option(const std::string& key, int value) {
+  if (key == "splitk_force") g_splitk_force = value;
+  else if (key == "no_splitk") g_no_splitk = value;
+  else if (key == "conv_variant") g_conv_variant = value;
+  else if (key == "prof_dump") g_prof_dump = value;
+  else return false;
+  return true;
 }
 
 void prof_begin() {
@@ -510,7 +543,7 @@ void prof_end(double* ms, double* flop, int64_t* launches) {
     float t = 0.f;
     YMK_HIP(hipEventElapsedTime(&t, g_prof.ev[i].first, g_prof.ev[i].second));
     total += t;
-    if (getenv("YMK_PROF_DUMP"))
+    if (g_prof_dump.load(std::memory_order_relaxed))
       fprintf(stderr, "[ymk-prof] %3zu %s  %8.1f us  %6.1f TFLOP/s\n", i, g_prof.desc[i].c_str(), t * 1e3,
               g_prof.lflop[i] / (t * 1e-3) / 1e12);
   }
@@ -592,14 +625,29 @@ static bool try_splitk(hipStream_t s, ConvK& k) {
   return true;
 }
 
-template <int BM, int BN, int WM, int WN, int MODE = 0>
+template <int BM, int BN, int WM, int WN, int MODE = 0, int VAR = 0>
 static void launch(hipStream_t s, ConvK& k) {
   const int mt = (k.M + BM - 1) / BM, nt = (k.Cout + BN - 1) / BN;
   k.ntiles_n = nt;
   if (MODE == 0 && (mt * nt < SPLITK_MAX_GRID || splitk_forced() >= 0) && !no_splitk() && try_splitk(s, k)) return;
   auto* e = prof_open(s, k, BM, BN, mt * nt, 1);
-  hipLaunchKernelGGL((conv_igemm<BM, BN, WM, WN, MODE>), dim3(mt * nt), dim3(256), 0, s, k);
+  hipLaunchKernelGGL((conv_igemm<BM, BN, WM, WN, MODE, VAR>), dim3(mt * nt), dim3(64 * WM * WN), 0, s, k);
   if (e) YMK_HIP(hipEventRecord(e->second, s));
+}
+
+// conv_variant experiments on the wide-tile path (ymk_debug_option("conv_variant", v); tools/conv_sweep.py):
+//   1: 128x128, interleaved MFMA order   2: 128x128, s_setprio   3: both
+//   4: 128x128 with 8 waves (32x64 wave tiles)   5: 256x128 with 8 waves (64x64 wave tiles)   6: 5 + interleaved order
+static bool launch_variant(hipStream_t s, ConvK& k) {
+  switch (g_conv_variant.load(std::memory_order_relaxed)) {
+    case 1: launch<128, 128, 2, 2, 0, 1>(s, k); return true;
+    case 2: launch<128, 128, 2, 2, 0, 2>(s, k); return true;
+    case 3: launch<128, 128, 2, 2, 0, 3>(s, k); return true;
+    case 4: launch<128, 128, 4, 2, 0, 0>(s, k); return true;
+    case 5: launch<256, 128, 4, 2, 0, 0>(s, k); return true;
+    case 6: launch<256, 128, 4, 2, 0, 1>(s, k); return true;
+    default: return false;
+  }
 }
 
 void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, const Tensor& out) {
@@ -673,7 +721,11 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
     if ((k.M + 127) / 128 >= 256) launch<128, 64, 2, 2>(s, k);
     else launch<64, 64, 2, 2>(s, k);
   } else if (blocks128 >= 384) {
-    launch<128, 128, 2, 2>(s, k);
+    // a 128-wide N tile wastes (-Cout mod 128) columns of MFMA work: 25 % at Cout = 192 (the PARSeq-tiny projections
+    // and FFN outputs).  64-wide tiles cover such a Cout exactly, at a slightly lower rate per tile.
+    const int waste = (128 - w.cout % 128) % 128;
+    if (waste >= 48 && waste * 5 >= w.cout) launch<128, 64, 2, 2>(s, k);
+    else if (!launch_variant(s, k)) launch<128, 128, 2, 2>(s, k);
   } else {
     const long blocks64 = (long)((k.M + 127) / 128) * ((w.cout + 63) / 64);
     if (blocks64 >= 256) launch<128, 64, 2, 2>(s, k);

@@ -176,8 +176,11 @@ __global__ __launch_bounds__(NT) void k_parseq_dec_step(DecStepW W, const int* _
                                                         float* __restrict__ skv, int NS, const float* __restrict__ memkv,
                                                         int L, const int* __restrict__ mem_off,
                                                         const int* __restrict__ mem_len, float* __restrict__ out,
-                                                        const int* __restrict__ prev_not_done) {
+                                                        const int* __restrict__ prev_not_done,
+                                                        const int* __restrict__ gid, const int* __restrict__ gopen, int ng) {
   if (prev_not_done && *prev_not_done == 0) return;  // speculative step after the batch finished
+  // grouped forward: the row's mini-batch finished at an earlier step - its own loop would not run this step at all
+  if (gid && step > 0 && gopen[(size_t)(step - 1) * ng + gid[blockIdx.x]] == 0) return;
   __shared__ __attribute__((aligned(16))) float xa[DMAX], xb[DMAX], q[DMAX], kvcur[2 * DMAX], hid[FMAX], sc[HMAX * LMAX],
       part[4 * NT];
   __shared__ float red[HMAX];
@@ -231,10 +234,10 @@ __global__ __launch_bounds__(NT) void k_parseq_dec_step(DecStepW W, const int* _
 
 void parseq_dec_step(hipStream_t s, const DecStepW& W, const int* tok, int ld_tok, int step, float* skv, int NS,
                      const float* memkv, int L, const int* mem_off, const int* mem_len, float* out, const int* prev_not_done,
-                     int B) {
+                     int B, const int* gid, const int* gopen, int ng) {
   YMK_CHECK(parseq_dec_step_supported(W.D, W.H, W.F, L, NS), "fused decoder step: unsupported geometry");
   hipLaunchKernelGGL(k_parseq_dec_step, dim3(B), dim3(NT), 0, s, W, tok, ld_tok, step, skv, NS, memkv, L, mem_off, mem_len,
-                     out, prev_not_done);
+                     out, prev_not_done, gid, gopen, ng);
   YMK_HIP(hipGetLastError());
 }
 

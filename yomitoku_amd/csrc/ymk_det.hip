@@ -1,5 +1,5 @@
 // Detection-transformer kernels for RT-DETRv2 (models/layers/rtdetrv2_decoder.py): row-wise
-// elementwise helpers, per-image top-k over the 8400 encoder tokens (bitonic sort in LDS), gathers,
+// elementwise helpers, per-image top-k over the encoder tokens (radix select + bitonic sort of the winners in LDS), gathers,
 // box refinement, and the multi-scale deformable-attention sampler.
 //
 // Token rows are stored LEVEL-MAJOR: all images' tokens of level 0, then level 1, then level 2 -
@@ -65,46 +65,120 @@ void mask_rows(hipStream_t s, const float* in, const float* valid, float* out, c
 }
 
 // ---------------------------------------------------------------- top-k per image over max-class logits
-// One 1024-thread block per image: keys (descending value, ascending token id on ties) are bitonic
-// sorted in a 16384-entry LDS array; the first K token ids are written in rank order (torch.topk).
+// torch.topk(enc_outputs_logits.max(-1).values, K) per image (rtdetrv2_decoder.py:752-756): the K best tokens in rank
+// order (descending value, ascending token id among equal values).  One 1024-thread block per image, any token count
+// (8400 at 640^2, 18900 at 960^2 - the cell detector), K <= 2048 (300 / 1500):
+//   1. radix select on the order-preserving 32-bit image of the value (12 + 12 + 8 bits, 4096-bin LDS histograms):
+//      the exact K-th largest value T, how many tokens lie strictly above it, how many of the tokens equal to T are
+//      still needed;
+//   2. the tokens above T are appended to an LDS list in any order; of the ties, the `need` smallest token ids are taken
+//      through a block-wide prefix count in token order (exact also when every value is equal);
+//   3. the K (value, id) keys are bitonic sorted in LDS and written out in rank order.
+__device__ __forceinline__ unsigned topk_key(const float* __restrict__ logits, int nc, const DetGeom& g, int b, int k) {
+  const float* row = logits + (size_t)token_row(g, b, k) * nc;
+  float m = row[0];
+  for (int c = 1; c < nc; ++c) m = fmaxf(m, row[c]);
+  const unsigned u = __float_as_uint(m);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // larger float <=> larger unsigned
+}
+
 __global__ __launch_bounds__(1024) void k_topk_tokens(const float* __restrict__ logits, int nc, DetGeom g, int K,
-                                                      int* __restrict__ out_idx) {
-  constexpr int N = 16384;
-  __shared__ unsigned long long keys[N];
-  const int b = blockIdx.x, t = threadIdx.x;
-  for (int k = t; k < N; k += 1024) {
-    unsigned long long key = ~0ull;
-    if (k < g.ntok) {
-      const float* row = logits + (size_t)token_row(g, b, k) * nc;
-      float m = row[0];
-      for (int c = 1; c < nc; ++c) m = fmaxf(m, row[c]);
-      unsigned u = __float_as_uint(m);
-      u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending-orderable
-      key = ((unsigned long long)(~u) << 32) | (unsigned)k;  // ascending key == descending value
-    }
-    keys[k] = key;
+                                                      unsigned* __restrict__ keys_scratch, int* __restrict__ out_idx) {
+  constexpr int NT = 1024, BINS = 4096, KMAX = 2048;
+  __shared__ unsigned hist[BINS];
+  __shared__ unsigned long long sel[KMAX];
+  __shared__ unsigned s_prefix, s_mask, s_need, s_count;
+  __shared__ int scan[NT];
+  const int b = blockIdx.x, t = threadIdx.x, N = g.ntok;
+  unsigned* keys = keys_scratch + (size_t)b * N;
+  for (int k = t; k < N; k += NT) keys[k] = topk_key(logits, nc, g, b, k);
+  if (t == 0) {
+    s_prefix = 0;
+    s_mask = 0;
+    s_need = (unsigned)K;  // tokens still to be taken among those matching the prefix
   }
   __syncthreads();
-  for (int kk = 2; kk <= N; kk <<= 1) {
+  // ---- 1. radix select, most significant digits first
+  const int shifts[3] = {20, 8, 0}, widths[3] = {12, 12, 8};
+  for (int pass = 0; pass < 3; ++pass) {
+    for (int i = t; i < BINS; i += NT) hist[i] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix, mask = s_mask;
+    const int sh = shifts[pass];
+    const unsigned dm = (1u << widths[pass]) - 1u;
+    for (int k = t; k < N; k += NT) {
+      const unsigned u = keys[k];
+      if ((u & mask) == prefix) atomicAdd(&hist[(u >> sh) & dm], 1u);
+    }
+    __syncthreads();
+    if (t == 0) {
+      unsigned need = s_need, d = dm;
+      for (;; --d) {  // walk the digits from the top: the digit whose bin contains the need-th largest
+        const unsigned c = hist[d];
+        if (c >= need) break;
+        need -= c;
+        if (d == 0) break;  // cannot happen (K <= N)
+      }
+      s_need = need;
+      s_prefix = prefix | (d << sh);
+      s_mask = mask | (dm << sh);
+    }
+    __syncthreads();
+  }
+  const unsigned T = s_prefix, need = s_need;  // exact K-th largest value; ties with T still to take
+  // ---- 2. collect: everything above T, then the first `need` ties in token order
+  if (t == 0) s_count = 0;
+  __syncthreads();
+  const int per = (N + NT - 1) / NT;  // contiguous token range of this thread
+  const int k0 = t * per, k1 = min(N, k0 + per);
+  int ties = 0;
+  for (int k = k0; k < k1; ++k) {
+    const unsigned u = keys[k];
+    if (u > T) sel[atomicAdd(&s_count, 1u)] = ((unsigned long long)(~u) << 32) | (unsigned)k;
+    else if (u == T) ++ties;
+  }
+  scan[t] = ties;
+  __syncthreads();
+  for (int o = 1; o < NT; o <<= 1) {  // inclusive Hillis-Steele scan of the per-thread tie counts
+    const int v = t >= o ? scan[t - o] : 0;
+    __syncthreads();
+    scan[t] += v;
+    __syncthreads();
+  }
+  {
+    int rank = scan[t] - ties;  // ties before this thread's range
+    for (int k = k0; k < k1 && rank < (int)need; ++k)
+      if (keys[k] == T) {
+        sel[atomicAdd(&s_count, 1u)] = ((unsigned long long)(~T) << 32) | (unsigned)k;
+        ++rank;
+      }
+  }
+  __syncthreads();
+  // ---- 3. rank order: ascending (~value, id) == descending value, ascending id
+  int P = 1;
+  while (P < K) P <<= 1;
+  for (int i = K + t; i < P; i += NT) sel[i] = ~0ull;
+  __syncthreads();
+  for (int kk = 2; kk <= P; kk <<= 1) {
     for (int j = kk >> 1; j > 0; j >>= 1) {
-      for (int idx = t; idx < N / 2; idx += 1024) {
+      for (int idx = t; idx < P / 2; idx += NT) {
         const int i = 2 * idx - (idx & (j - 1));
-        const int p = i + j;
-        const unsigned long long a = keys[i], c = keys[p];
+        const int q = i + j;
+        const unsigned long long a = sel[i], c = sel[q];
         const bool up = (i & kk) == 0;
         if ((a > c) == up) {
-          keys[i] = c;
-          keys[p] = a;
+          sel[i] = c;
+          sel[q] = a;
         }
       }
       __syncthreads();
     }
   }
-  for (int r = t; r < K; r += 1024) out_idx[(size_t)b * K + r] = (int)(keys[r] & 0xFFFFFFFFu);
+  for (int r = t; r < K; r += NT) out_idx[(size_t)b * K + r] = (int)(sel[r] & 0xFFFFFFFFu);
 }
-void topk_tokens(hipStream_t s, const float* logits, int nc, const DetGeom& g, int K, int* out_idx) {
-  YMK_CHECK(g.ntok <= 16384 && K <= g.ntok, "topk: at most 16384 tokens");
-  hipLaunchKernelGGL(k_topk_tokens, dim3(g.B), dim3(1024), 0, s, logits, nc, g, K, out_idx);
+void topk_tokens(hipStream_t s, const float* logits, int nc, const DetGeom& g, int K, unsigned* keys_scratch, int* out_idx) {
+  YMK_CHECK(K >= 1 && K <= 2048 && K <= g.ntok, "topk: 1 <= K <= min(2048, tokens)");
+  hipLaunchKernelGGL(k_topk_tokens, dim3(g.B), dim3(1024), 0, s, logits, nc, g, K, keys_scratch, out_idx);
   YMK_HIP(hipGetLastError());
 }
 

@@ -12,6 +12,8 @@
 //   - decoder widths <= 256 run a whole AR step as one kernel (ymk_decstep.hip), wider ones as GEMMs.
 #include <sched.h>
 
+#include <atomic>
+
 #include "ymk_common.h"
 #include "ymk_seq.h"
 #include "ymk_decstep.h"
@@ -19,6 +21,14 @@
 namespace ymk {
 
 void tile_rows(hipStream_t s, const float* src, int rows, int D, float* dst, int B);
+
+static std::atomic<int> g_parseq_unfused{0};  // ymk_debug_option("parseq_unfused", 1): per-op decoder path for every width (tests)
+static bool parseq_unfused() { return g_parseq_unfused.load(std::memory_order_relaxed) != 0; }
+bool parseq_debug_option(const std::string& key, int value) {
+  if (key != "parseq_unfused") return false;
+  g_parseq_unfused = value;
+  return true;
+}
 
 struct PGroup {
   const float* x;
@@ -260,7 +270,8 @@ class ParseqModel : public Model {
     float* hbuf = arena.alloc_f((size_t)M * blocks_[0].fc1.cout);
     float* mem = arena.alloc_f((size_t)M * D);
     float* memkv = arena.alloc_f((size_t)M * 2 * D);
-    int* tab = (int*)arena.alloc_bytes((size_t)2 * B * sizeof(int));  // [B] first token row | [B] token rows
+    int* tab = (int*)arena.alloc_bytes((size_t)3 * B * sizeof(int));  // [B] first token row | [B] token rows | [B] group
+    int* gopen = (int*)arena.alloc_bytes((size_t)nsteps_ * ng * sizeof(int));  // [step][group]: rows still open
     // ---------------- decoder buffers
     const int MR = B * NS;
     float* qsa = arena.alloc_f((size_t)NS * D);        // W_q(norm_q(pos_queries)) - shared by the batch
@@ -284,12 +295,13 @@ class ParseqModel : public Model {
     if (ragged) {
       // the tables travel through a pinned staging buffer owned by the model: a forward returns only after its
       // greedy loop has been observed to finish, so the previous call's copy has long left the buffer
-      if ((size_t)8 * B > stage_cap_) {
+      const size_t want = (size_t)3 * B + (size_t)NS * ng;  // tables out | per-step group counters back
+      if (want > stage_cap_) {
         if (stage_) YMK_HIP(hipHostFree(stage_));
         stage_ = nullptr;
         stage_cap_ = 0;
-        YMK_HIP(hipHostMalloc((void**)&stage_, (size_t)16 * B * sizeof(int), hipHostMallocDefault));
-        stage_cap_ = (size_t)16 * B;
+        YMK_HIP(hipHostMalloc((void**)&stage_, 2 * want * sizeof(int), hipHostMallocDefault));
+        stage_cap_ = 2 * want;
       }
       int row = 0, b = 0;
       for (int g = 0; g < ng; ++g) {
@@ -297,15 +309,19 @@ class ParseqModel : public Model {
         for (int i = 0; i < groups[g].B; ++i, ++b) {
           stage_[b] = row;
           stage_[B + b] = L;
+          stage_[2 * B + b] = g;
           row += L;
         }
       }
-      YMK_HIP(hipMemcpyAsync(tab, stage_, (size_t)2 * B * sizeof(int), hipMemcpyHostToDevice, s));
+      YMK_HIP(hipMemcpyAsync(tab, stage_, (size_t)3 * B * sizeof(int), hipMemcpyHostToDevice, s));
+      YMK_HIP(hipMemsetAsync(gopen, 0, (size_t)NS * ng * sizeof(int), s));
       enc_tab.qoff = enc_tab.koff = mem_tab.koff = tab;
       enc_tab.qlen = enc_tab.klen = mem_tab.klen = tab + B;
     }
     const SeqTab* enc_t = ragged ? &enc_tab : nullptr;
     const SeqTab* mem_t = ragged ? &mem_tab : nullptr;
+    const int* gid = ragged ? tab + 2 * B : nullptr;
+    int* gop = ragged ? gopen : nullptr;
     const int L = Lmax;  // uniform length when not ragged
 
     {
@@ -370,14 +386,14 @@ class ParseqModel : public Model {
       }
     };
     int steps = NS;
-    const bool fused = parseq_dec_step_supported(D, dh_, lin1_.cout, L, NS) && !getenv("YMK_PARSEQ_UNFUSED");
+    const bool fused = parseq_dec_step_supported(D, dh_, lin1_.cout, L, NS) && !parseq_unfused();
     for (int i = 0; i < NS; ++i) {
       const int* prev = i > 0 ? not_done + i - 1 : nullptr;
       if (fused) {
         // the whole query stream of step i in one launch, then the vocabulary head as a GEMM
         DecStepW w = fw_;
         w.qsa = qsa;
-        parseq_dec_step(s, w, tok, NS, i, skv, NS, memkv, L, mem_tab.koff, mem_tab.klen, t1, prev, B);
+        parseq_dec_step(s, w, tok, NS, i, skv, NS, memkv, L, mem_tab.koff, mem_tab.klen, t1, prev, B, gid, gop, ng);
         gemm(s, t1, B, D, D, head_, ACT_NONE, nullptr, 0, arlog + (size_t)i * C, NS * C);
       } else {
         // content row i (token tok[:, i]) -> norm_c -> K|V cache row i
@@ -391,7 +407,7 @@ class ParseqModel : public Model {
       }
       greedy_step(s, arlog + (size_t)i * C, (long)NS * C, C, i, NS, tok, raw, NS, state, eos_, rep_on_, rep_pmax_, rep_p1_,
                   rep_min_, not_done + i, i > 0 ? not_done + i - 1 : nullptr, arrived + i,
-                  i + 1 < NS ? host_flags_dev_ + i : nullptr /* the last step's count is never read */, B);
+                  i + 1 < NS ? host_flags_dev_ + i : nullptr /* the last step's count is never read */, B, gid, gop, ng);
       if (i + 1 < NS && i >= LAG && wait_flag(i - LAG) == 0) {  // every row held an <eos> after step i - LAG
         steps = i - LAG + 1;
         break;
@@ -404,19 +420,20 @@ class ParseqModel : public Model {
           break;
         }
     }
-    // per-group step counts: a group's own loop would have stopped once each of ITS rows held an <eos>
-    // (state[b][3] = steps after which row b did; 0 = never).  One copy, issued before the refinement is queued.
+    // per-group step counts: group g's own loop stops after the first step that leaves none of ITS rows open
+    // (gopen[step][g] == 0); its rows were frozen from then on.  One small copy, before the refinement is queued.
     if (ng > 1) {
-      YMK_HIP(hipMemcpyAsync(stage_ + 4 * B, state, (size_t)B * 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+      int* back = stage_ + 3 * B;
+      YMK_HIP(hipMemcpyAsync(back, gopen, (size_t)NS * ng * sizeof(int), hipMemcpyDeviceToHost, s));
       YMK_HIP(hipStreamSynchronize(s));  // the stream is idle here: the loop above has seen the last real step finish
-      int b = 0;
       for (int g = 0; g < ng; ++g) {
-        int sg = 0;
-        for (int i = 0; i < groups[g].B; ++i, ++b) {
-          const int e = stage_[4 * B + 4 * b + 3];
-          sg = std::max(sg, e > 0 ? e : NS);
-        }
-        ar_steps[g] = std::min(sg, steps);
+        int sg = steps;
+        for (int i = 0; i + 1 < steps; ++i)
+          if (back[(size_t)i * ng + g] == 0) {
+            sg = i + 1;
+            break;
+          }
+        ar_steps[g] = sg;
       }
     } else {
       ar_steps[0] = steps;
@@ -463,7 +480,7 @@ class ParseqModel : public Model {
   unsigned char* qmask_ = nullptr;
   int* host_flags_ = nullptr;      // mapped pinned: (rows still open) + 1 per AR step
   int* host_flags_dev_ = nullptr;  // the same words as the device addresses them
-  int* stage_ = nullptr;           // pinned: ragged tables out (2B ints at 0), per-row decode state back (4B ints at 4B)
+  int* stage_ = nullptr;           // pinned: ragged tables out (3B ints at 0), per-step group counters back (after them)
   size_t stage_cap_ = 0;
   uint64_t shape_key_ = 0;
 };

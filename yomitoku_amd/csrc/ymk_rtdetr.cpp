@@ -343,11 +343,12 @@ class RtdetrModel : public Model {
     float* elog = lin(s, om, R, enc_score_, ACT_NONE);
     float* ebox = mlp3_fwd(s, om, R, enc_bbox_);
     int* idx = (int*)arena.alloc_bytes((size_t)B * nq_ * sizeof(int));
+    unsigned* topk_keys = (unsigned*)arena.alloc_bytes((size_t)R * sizeof(unsigned));
     const int MQ = B * nq_;
     float* tgt = arena.alloc_f((size_t)MQ * D);
     float* ref = arena.alloc_f((size_t)MQ * 4);
     if (!dry()) {
-      topk_tokens(s, elog, nc_, g, nq_, idx);
+      topk_tokens(s, elog, nc_, g, nq_, topk_keys, idx);
       gather_queries(s, om, ebox, anchors_, idx, g, nq_, D, tgt, ref);
     }
     float* vall = lin(s, mem, R, value_all_, ACT_NONE);  // every layer's value projection at once

@@ -434,78 +434,90 @@ __global__ __launch_bounds__(256) void k_greedy_step(const float* __restrict__ l
                                                      int ld_tok, int* __restrict__ state, int eos_id, int rep_on,
                                                      int period_max, int min_run_p1, int min_repeats,
                                                      int* __restrict__ not_done, const int* __restrict__ prev_not_done,
-                                                     int* __restrict__ arrived, int* __restrict__ host_flag) {
+                                                     int* __restrict__ arrived, int* __restrict__ host_flag,
+                                                     const int* __restrict__ gid, int* __restrict__ gopen, int ng) {
   const int b = blockIdx.x, t = threadIdx.x;
   // speculative step issued after every row already held an <eos>: change nothing (not_done stays 0)
   if (prev_not_done && *prev_not_done == 0) return;
-  const float* row = logits + (size_t)b * ld_b;
-  float best = -INFINITY;
-  int bi = 0x7fffffff;
-  for (int c = t; c < C; c += 256) {
-    const float v = row[c];
-    if (v > best) {  // strict: keeps the lowest index among equal values within a thread
-      best = v;
-      bi = c;
-    }
-  }
+  // grouped forward: a row whose mini-batch finished at an earlier step is frozen - its own loop would have stopped
+  // there (models/parseq.py:245-250), so neither tokens nor the repetition detector may advance any further
+  const int g = gid ? gid[b] : 0;
+  const bool frozen = gid && step > 0 && gopen[(size_t)(step - 1) * ng + g] == 0;
   __shared__ float sv[256];
   __shared__ int si[256];
-  sv[t] = best;
-  si[t] = bi;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (t < o) {
-      const float v2 = sv[t + o];
-      const int i2 = si[t + o];
-      if (v2 > sv[t] || (v2 == sv[t] && i2 < si[t])) {  // torch.argmax returns the first maximal index
-        sv[t] = v2;
-        si[t] = i2;
+  if (!frozen) {
+    const float* row = logits + (size_t)b * ld_b;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = t; c < C; c += 256) {
+      const float v = row[c];
+      if (v > best) {  // strict: keeps the lowest index among equal values within a thread
+        best = v;
+        bi = c;
       }
     }
+    sv[t] = best;
+    si[t] = bi;
     __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (t < o) {
+        const float v2 = sv[t + o];
+        const int i2 = si[t + o];
+        if (v2 > sv[t] || (v2 == sv[t] && i2 < si[t])) {  // torch.argmax returns the first maximal index
+          sv[t] = v2;
+          si[t] = i2;
+        }
+      }
+      __syncthreads();
+    }
   }
   if (t != 0) return;
-  const int am = si[0];
-  raw[(size_t)b * ld_tok + step] = am;
   int* st = state + b * 4;
-  const int j = step + 1;
-  if (j < num_steps) {
-    int* trow = tok + (size_t)b * ld_tok;
-    int next = am;
-    if (rep_on && !st[1] && next != eos_id) {
-      // _detect_repeat_onset on seq = trow[1..j] with trow[j] = next (models/parseq.py:108-128)
-      trow[j] = next;
-      const int* seq = trow + 1;
-      const int n = j;
-      for (int pp = 1; pp <= period_max; ++pp) {
-        if (n < 2 * pp) continue;
-        int k = 1, tpos = n - pp;
-        while (tpos - pp >= 0) {
-          bool same = true;
-          for (int u = 0; u < pp; ++u)
-            if (seq[tpos - pp + u] != seq[n - pp + u]) {
-              same = false;
-              break;
-            }
-          if (!same) break;
-          ++k;
-          tpos -= pp;
-        }
-        if (k >= (pp == 1 ? min_run_p1 : min_repeats)) {
-          st[2] = tpos + pp;  // rep_cut: keep the prefix + one unit
-          st[1] = 1;
-          next = eos_id;
-          break;
+  // a frozen row still owns a slot of the shared token table at every step: keep it a valid id (it lies behind the
+  // row's <eos>, so the refinement masks it - but it is used to index the embedding table before the mask applies)
+  if (frozen) raw[(size_t)b * ld_tok + step] = eos_id;
+  if (!frozen) {
+    const int am = si[0];
+    raw[(size_t)b * ld_tok + step] = am;
+    const int j = step + 1;
+    if (j < num_steps) {
+      int* trow = tok + (size_t)b * ld_tok;
+      int next = am;
+      if (rep_on && !st[1] && next != eos_id) {
+        // _detect_repeat_onset on seq = trow[1..j] with trow[j] = next (models/parseq.py:108-128)
+        trow[j] = next;
+        const int* seq = trow + 1;
+        const int n = j;
+        for (int pp = 1; pp <= period_max; ++pp) {
+          if (n < 2 * pp) continue;
+          int k = 1, tpos = n - pp;
+          while (tpos - pp >= 0) {
+            bool same = true;
+            for (int u = 0; u < pp; ++u)
+              if (seq[tpos - pp + u] != seq[n - pp + u]) {
+                same = false;
+                break;
+              }
+            if (!same) break;
+            ++k;
+            tpos -= pp;
+          }
+          if (k >= (pp == 1 ? min_run_p1 : min_repeats)) {
+            st[2] = tpos + pp;  // rep_cut: keep the prefix + one unit
+            st[1] = 1;
+            next = eos_id;
+            break;
+          }
         }
       }
+      trow[j] = next;
+      if (next == eos_id) st[0] = 1;
     }
-    trow[j] = next;
-    if (next == eos_id && !st[0]) {
-      st[0] = 1;
-      st[3] = step + 1;  // AR steps after which this row holds an <eos> (a mini-batch stops at the max over its rows)
+    if (!st[0]) {
+      atomicAdd(not_done, 1);
+      if (gopen) atomicAdd(gopen + (size_t)step * ng + g, 1);
     }
   }
-  if (!st[0]) atomicAdd(not_done, 1);
   if (host_flag) {
     // the last block to arrive publishes (rows still open) + 1 to the mapped host word the AR loop polls
     __threadfence();
@@ -517,9 +529,11 @@ __global__ __launch_bounds__(256) void k_greedy_step(const float* __restrict__ l
 }
 void greedy_step(hipStream_t s, const float* logits, long ld_b, int C, int step, int num_steps, int* tok, int* raw,
                  int ld_tok, int* state, int eos_id, int rep_on, int period_max, int min_run_p1, int min_repeats,
-                 int* not_done, const int* prev_not_done, int* arrived, int* host_flag, int B) {
+                 int* not_done, const int* prev_not_done, int* arrived, int* host_flag, int B, const int* gid, int* gopen,
+                 int ng) {
   hipLaunchKernelGGL(k_greedy_step, dim3(B), dim3(256), 0, s, logits, ld_b, C, step, num_steps, tok, raw, ld_tok, state,
-                     eos_id, rep_on, period_max, min_run_p1, min_repeats, not_done, prev_not_done, arrived, host_flag);
+                     eos_id, rep_on, period_max, min_run_p1, min_repeats, not_done, prev_not_done, arrived, host_flag, gid,
+                     gopen, ng);
   YMK_HIP(hipGetLastError());
 }
 

@@ -325,6 +325,9 @@ class DocumentAnalyzer:
         self.ruby_threshold = ruby_threshold
         self._pool = ThreadPoolExecutor(max_workers=2)
         self._streams = {}
+        # False: the two chains run one after the other on the caller's thread and stream (profiling: a kernel's
+        # timing then brackets that kernel alone); results are the same either way
+        self.concurrent_chains = True
 
     # ---- aggregation (:487-601)
     def aggregate(self, ocr_res, layout_res):
@@ -375,6 +378,19 @@ class DocumentAnalyzer:
         }
 
     # ---- the two concurrent chains, each on its own HIP stream
+    def _submit(self, name, fn, *args):
+        """A chain as a future: on its own thread + HIP stream, or - concurrent_chains False - run right here."""
+        if self.concurrent_chains:
+            return self._pool.submit(self._on_stream, name, fn, *args)
+        from concurrent.futures import Future
+
+        f = Future()
+        try:
+            f.set_result(fn(*args))
+        except BaseException as exc:  # noqa: BLE001 - delivered by f.result(), like a pool future
+            f.set_exception(exc)
+        return f
+
     def _on_stream(self, name, fn, *args):
         dev = self.text_detector.device
         stream = self._streams.get(name)
@@ -393,15 +409,15 @@ class DocumentAnalyzer:
 
     def run(self, page):
         if self.split_text_across_cells:
-            f_det = self._pool.submit(self._on_stream, "ocr", self.text_detector, page)
-            f_lay = self._pool.submit(self._on_stream, "layout", self.layout, page)
+            f_det = self._submit("ocr", self.text_detector, page)
+            f_lay = self._submit("layout", self.layout, page)
             results_det, _ = f_det.result()
             results_layout, layout = f_lay.result()
             results_det = _split_text_across_cells(results_det, results_layout)
             results_rec, ocr = self.text_recognizer(page, results_det.points, None)
         else:
-            f_ocr = self._pool.submit(self._on_stream, "ocr", self._detect_and_recognize, page)
-            f_lay = self._pool.submit(self._on_stream, "layout", self.layout, page)
+            f_ocr = self._submit("ocr", self._detect_and_recognize, page)
+            f_lay = self._submit("layout", self.layout, page)
             results_det, results_rec, ocr = f_ocr.result()
             results_layout, layout = f_lay.result()
         results_ocr = OCRSchema(words=ocr_aggregate(results_det, results_rec))
@@ -435,14 +451,14 @@ class DocumentAnalyzer:
             chunk = imgs[start : start + max(1, int(wave))]
             pages = [img if isinstance(img, torch.Tensor) else imaging.page_to_device(img, dev) for img in chunk]
             if self.split_text_across_cells:
-                f_det = self._pool.submit(self._on_stream, "ocr", self.text_detector.detect_pages, pages)
-                f_lay = self._pool.submit(self._on_stream, "layout", self._layout_pages, pages)
+                f_det = self._submit("ocr", self.text_detector.detect_pages, pages)
+                f_lay = self._submit("layout", self._layout_pages, pages)
                 dets, lays = f_det.result(), f_lay.result()
                 dets = [_split_text_across_cells(d, l) for d, l in zip(dets, lays)]
-                recs = self._on_stream("ocr", self.text_recognizer.recognize_pages, pages, [d.points for d in dets])
+                recs = self._submit("ocr", self.text_recognizer.recognize_pages, pages, [d.points for d in dets]).result()
             else:
-                f_ocr = self._pool.submit(self._on_stream, "ocr", self._ocr_pages, pages)
-                f_lay = self._pool.submit(self._on_stream, "layout", self._layout_pages, pages)
+                f_ocr = self._submit("ocr", self._ocr_pages, pages)
+                f_lay = self._submit("layout", self._layout_pages, pages)
                 dets, recs = f_ocr.result()
                 lays = f_lay.result()
             for img, det, rec, lay in zip(chunk, dets, recs, lays):

@@ -155,6 +155,8 @@ class CropPlan:
     desc: CropDesc
     content_width: int      # calc_resize_without_padding width (batch bucketing key)
     canvas_width: int       # width of this crop's own tensor (800, or the dynamic canvas)
+    table: Optional[np.ndarray] = None  # the page's descriptor records (`desc` is a view of row `row`), for bulk gathers
+    row: int = 0
 
 
 def validate_quad(shape_hw, quad) -> bool:
@@ -251,7 +253,7 @@ def plan_crops(shape_hw, quads, img_size=(32, 800), dynamic_width=False, align=8
     rec["fast_x"], rec["fast_y"] = np.where(fast, fx, 0), np.where(fast, fy, 0)
     descs = (CropDesc * m).from_buffer(rec)  # views into `rec`; each element keeps the buffer alive
     for k, (i, cw, cv) in enumerate(zip(shaped, nw.tolist(), canvas.tolist())):
-        plans[i] = CropPlan(index=i, desc=descs[k], content_width=cw, canvas_width=cv)
+        plans[i] = CropPlan(index=i, desc=descs[k], content_width=cw, canvas_width=cv, table=rec, row=k)
     return plans
 
 
@@ -364,21 +366,30 @@ def build_crop_batch(page_dev, plans: Sequence[CropPlan], out_h: int = 32, batch
     n = len(plans)
     if batch_w is None:
         batch_w = max(p.canvas_width for p in plans)
-    arr = (CropDesc * n)()
-    off = 0
-    max_w = max_h = 1
+    # the mini-batch's descriptor records, gathered per source table (one per pyramid level) instead of plan by plan
+    arr = np.empty(n, dtype=_CROP_DTYPE)
+    by_table = {}
     for slot, p in enumerate(plans):
-        ctypes.memmove(ctypes.byref(arr[slot]), ctypes.byref(p.desc), ctypes.sizeof(CropDesc))
-        arr[slot].slot = slot
-        arr[slot].flip = 1 if flip else 0
-        arr[slot].warp_off = off
-        if p.desc.level >= len(levels) or levels[p.desc.level] is None:
-            raise ValueError(f"crop plan wants pyramid level {p.desc.level}, which was not built")
-        off += p.desc.ww * p.desc.wh * 3
-        off = (off + 15) & ~15
-        max_w, max_h = max(max_w, p.desc.ww), max(max_h, p.desc.wh)
+        if p.table is None:  # a stand-alone descriptor (scalar planner)
+            arr[slot] = np.frombuffer(p.desc, dtype=_CROP_DTYPE, count=1)[0]
+        else:
+            by_table.setdefault(id(p.table), (p.table, [], []))
+            by_table[id(p.table)][1].append(slot)
+            by_table[id(p.table)][2].append(p.row)
+    for table, slots, rows in by_table.values():
+        arr[slots] = table[rows]
+    lv = arr["level"]
+    if int(lv.max()) >= len(levels) or any(levels[int(k)] is None for k in np.unique(lv)):
+        raise ValueError(f"crop plan wants pyramid level {int(lv.max())}, which was not built")
+    arr["slot"] = np.arange(n)
+    arr["flip"] = 1 if flip else 0
+    sizes = (arr["ww"].astype(np.int64) * arr["wh"] * 3 + 15) & ~15
+    ends = np.cumsum(sizes)
+    arr["warp_off"] = ends - sizes
+    off = int(ends[-1])
+    max_w, max_h = max(1, int(arr["ww"].max())), max(1, int(arr["wh"].max()))
     dev = page0.device
-    descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    descs = torch.from_numpy(arr.view(np.uint8)).to(dev)
     scratch = torch.empty(max(off, 16), dtype=torch.uint8, device=dev)
     out = torch.empty((n, 3, out_h, batch_w), dtype=torch.float32, device=dev)
     nl = len(levels)

@@ -56,7 +56,7 @@ def filter_contained_cells_within_spancell(cells, span_boxes):
 
 class TableStructureRecognizer(BaseModule):
     model_catalog = TableStructureRecognizerModelCatalog()
-    MAX_TABLES_PER_FORWARD = 8  # bounds the activation workspace (80x80x512 fp32 maps per table)
+    MAX_TABLES_PER_FORWARD = 16  # bounds the activation workspace (80x80x512 fp32 maps per table)
 
     def __init__(self, model_name="rtdetrv2", path_cfg=None, device="cuda", visualize=False, from_pretrained=True,
                  infer_onnx=False):

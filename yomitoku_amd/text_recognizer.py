@@ -41,6 +41,7 @@ class ParseqTokenizer:
     def __init__(self, charset: str):
         self._itos = (self.EOS,) + tuple(charset) + (self.BOS, self.PAD)
         self._stoi = {s: i for i, s in enumerate(self._itos)}
+        self._chars = np.array(self._itos, dtype=object)
         self.eos_id, self.bos_id, self.pad_id = (self._stoi[s] for s in (self.EOS, self.BOS, self.PAD))
 
     def __len__(self):
@@ -49,15 +50,17 @@ class ParseqTokenizer:
     def decode_stats(self, ids: np.ndarray, probs: np.ndarray):
         """Greedy decode from per-position (arg-max id, max prob): cut at the first <eos>, the score is
         the product of the kept probabilities including the <eos> one (parseq_tokenizer.py:64-88,117-126)."""
-        texts, scores = [], []
-        for row_ids, row_p in zip(ids, probs):
-            row_ids = row_ids.tolist()
-            try:
-                e = row_ids.index(self.eos_id)
-            except ValueError:
-                e = len(row_ids)
-            texts.append("".join(self._itos[i] for i in row_ids[:e]))
-            scores.append(float(np.asarray(row_p[: e + 1], dtype=np.float32).prod()))
+        ids = np.asarray(ids)
+        if ids.ndim != 2 or ids.shape[0] == 0:
+            return [], []
+        n, s = ids.shape
+        is_eos = ids == self.eos_id
+        end = np.where(is_eos.any(1), is_eos.argmax(1), s)  # tokens kept per row
+        # float32 running product, left to right = np.prod of the float32 slice row_p[: e + 1]
+        run = np.cumprod(np.asarray(probs, dtype=np.float32), axis=1, dtype=np.float32)
+        scores = run[np.arange(n), np.minimum(end, s - 1)].astype(np.float64).tolist()
+        chars = self._chars
+        texts = ["".join(chars[row[:e]].tolist()) for row, e in zip(ids, end.tolist())]
         return texts, scores
 
     def decode(self, token_dists):
@@ -185,12 +188,12 @@ class TextRecognizer(BaseModule):
             ids, probs = ids.cpu().numpy(), probs.cpu().numpy()
         pred, score = self.tokenizer.decode_stats(ids, probs)
         pred = [unicodedata.normalize("NFKC", x) for x in pred]
-        directions = []
-        for point in points:
-            point = np.array(point)
-            w = np.linalg.norm(point[0] - point[1])
-            h = np.linalg.norm(point[1] - point[2])
-            directions.append("vertical" if h > w * 2 else "horizontal")
+        if len(points) == 0:
+            return pred, score, []
+        q = np.asarray(points).reshape(len(points), 4, 2)  # np.array(point) of integer quads: int64, like the reference's
+        w = np.sqrt(((q[:, 0] - q[:, 1]) ** 2).sum(1).astype(np.float64))
+        h = np.sqrt(((q[:, 1] - q[:, 2]) ** 2).sum(1).astype(np.float64))
+        directions = np.where(h > w * 2, "vertical", "horizontal").tolist()
         return pred, score, directions
 
     def _infer_groups(self, jobs, flip=False, fixed_width=False):
