@@ -121,6 +121,13 @@ int ymk_db_postprocess(const float* prob_host, int h, int w, float thresh, float
                        int max_candidates, float unclip_ratio, int dest_w, int dest_h, int16_t* quads_out,
                        double* scores_out, int capacity, int* count);
 
+/* ---- table cell detector post-processing on the host (replaces find_holes_as_rects, table_cell_detector.py:116-143:
+ * cv2.rectangle / morphologyEx(OPEN, close_ksize x close_ksize box, 3 iterations) / floodFill / findContours(EXTERNAL) /
+ * boundingRect).  cell_boxes: int [n][4] (x1, y1, x2, y2) relative to the h x w table crop; rects_out: int [capacity][4],
+ * each hole's bounding rectangle grown by `pad`, holes below min_area dropped; HOST pointers. */
+int ymk_table_hole_rects(int h, int w, const int* cell_boxes, int n, int pad, int close_ksize, int min_area, int* rects_out,
+                         int capacity, int* count);
+
 /* ---- measurement aid for bench.py (not on the product path): between begin/end every launch of
  * the implicit-GEMM convolution kernel is bracketed by HIP events on its own stream; end returns
  * the summed kernel time, the algorithmic FLOPs (2*M*Cout*KH*KW*Cin, unpadded) and launch count.
@@ -129,7 +136,7 @@ int ymk_db_postprocess(const float* prob_host, int h, int w, float thresh, float
 int ymk_prof_begin(void);
 /* Test / measurement knobs, process-wide (never touched by the product path; defaults in parentheses):
  *   "splitk_force" (-1)  >= 0: that split-K tile shape for every eligible launch      "no_splitk" (0)  1: conv_igemm only
- *   "conv_variant" (0)   experimental conv_igemm schedules (tools/conv_sweep.py)       "prof_dump" (0)  1: ymk_prof_end
+ *   "conv_variant" (0)   alternative conv_igemm schedules for A/B runs (tools/conv_sweep.py)       "prof_dump" (0)  1: ymk_prof_end
  *   prints one line per launch      "parseq_unfused" (0)  1: per-op PARSeq decoder step at every width */
 int ymk_debug_option(const char* key, int value);
 int ymk_prof_end(double* conv_ms, double* conv_flop, int64_t* conv_launches);

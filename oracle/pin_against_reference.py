@@ -96,7 +96,7 @@ def pin_rtdetr():
     mod = ref_import("yomitoku.models.rtdetr")
     import omegaconf  # the stub: RTDETRTransformerv2 wants num_points as a ListConfig
 
-    for tag, nc, seed in (("layout", 6, 1240), ("table", 3, 1241)):
+    for tag, nc, seed, size, nq in (("layout", 6, 1240, 640, 300), ("table", 3, 1241, 640, 300), ("cell", 6, 1243, 960, 1500)):
         cfg = AttrDict(
             PResNet={"depth": 50, "variant": "d", "freeze_at": 0, "return_idx": [1, 2, 3], "num_stages": 4,
                      "freeze_norm": True},
@@ -104,26 +104,34 @@ def pin_rtdetr():
                            "use_encoder_idx": [2], "num_encoder_layers": 1, "nhead": 8, "dim_feedforward": 1024,
                            "dropout": 0.0, "enc_act": "gelu", "expansion": 1.0, "depth_mult": 1, "act": "silu"},
             RTDETRTransformerv2={"num_classes": nc, "feat_channels": [256, 256, 256], "feat_strides": [8, 16, 32],
-                                 "hidden_dim": 256, "num_levels": 3, "num_layers": 6, "num_queries": 300,
+                                 "hidden_dim": 256, "num_levels": 3, "num_layers": 6, "num_queries": nq,
                                  "num_denoising": 100, "label_noise_ratio": 0.5, "box_noise_scale": 1.0,
-                                 "eval_spatial_size": [640, 640], "eval_idx": -1,
+                                 "eval_spatial_size": [size, size], "eval_idx": -1,
                                  "num_points": omegaconf.ListConfig([4, 4, 4]), "cross_attn_method": "default",
                                  "query_select_method": "default"},
         )
-        sd = rtdetr_state_dict(seed, num_classes=nc)
+        sd = rtdetr_state_dict(seed, num_classes=nc, eval_size=(size, size), enc_score_gain=1.0 if size == 640 else 12.0)
         model = mod.RTDETRv2(cfg)
         res = model.load_state_dict(sd, strict=True)
         model.eval()
-        x = torch.rand(1, 3, 640, 640, generator=torch.Generator().manual_seed(seed))
+        x = torch.rand(1, 3, size, size, generator=torch.Generator().manual_seed(seed))
         with torch.inference_mode():
             ref = model(x)
-        ours = rtdetr_forward(sd, x)
+        ours = rtdetr_forward(sd, x, num_queries=nq)
         e1 = (ref["pred_logits"] - ours["pred_logits"]).abs().max().item()
         e2 = (ref["pred_boxes"] - ours["pred_boxes"]).abs().max().item()
         sc = ref["pred_logits"].sigmoid()
         print(f"[rtdetr/{tag}] reference vs oracle: logits {e1:.3e} boxes {e2:.3e}; scores>0.5: {(sc > 0.5).sum().item()} ({res})")
-        assert e1 < 1e-5 and e2 < 1e-6, (e1, e2)
-        np.savez_compressed(os.path.join(GOLDEN, f"rtdetr_ref_{tag}.npz"), seed=seed, num_classes=nc,
+        if e1 >= 1e-5 or e2 >= 1e-6:
+            # 1500 of 18900 tokens: two query candidates whose encoder scores differ by fp32 summation noise can swap
+            # ranks between two implementations (torch.topk's order under near-ties is not defined); rows are then
+            # permuted, not different - match them one to one inside a +-2 rank band, as the GPU test does
+            from tests.test_rtdetr_gpu import assert_same_detections
+
+            assert_same_detections(ours["pred_logits"].numpy(), ours["pred_boxes"].numpy(), ref["pred_logits"].numpy(),
+                                   ref["pred_boxes"].numpy(), tol_logit=2e-5, tol_box=2e-6)
+            print(f"[rtdetr/{tag}]   rows equal up to near-tie rank swaps (2e-5 / 2e-6 after one-to-one matching)")
+        np.savez_compressed(os.path.join(GOLDEN, f"rtdetr_ref_{tag}.npz"), seed=seed, num_classes=nc, size=size, num_queries=nq,
                             x_seed=seed, logits=ref["pred_logits"].numpy(), boxes=ref["pred_boxes"].numpy())
 
 
@@ -404,6 +412,98 @@ def pin_filters():
           f"kept detections: {[len(c['labels']) for c in post_cases]}")
 
 
+def pin_cells():
+    """Table cell detector post-processing (table_cell_detector.py:41-192,339-489): the reference's own functions and
+    CellDetector methods, lifted by ast, on seeded random detections -> tests/golden/cells.json.  The one piece that
+    cannot run here is find_holes_as_rects (OpenCV): the product's C++ restatement stands in for it on BOTH sides, so
+    this golden pins everything around it (class filters, whole-crop rejection, hole adoption by adjacency, roles, ids,
+    noise-cell removal, kv / grid regions); the hole finder itself has its own second-source test."""
+    import json
+    import math
+    import types
+
+    import torch
+
+    from yomitoku_amd import schemas as my_schemas
+    from yomitoku_amd.table_cell_detector import find_holes_as_rects
+
+    misc_names = ["filter_by_flag", "calc_intersection", "calc_overlap_ratio", "is_contained", "calc_iou", "clamp",
+                  "point_to_segment_distance", "right_edge_to_left_edge_dist", "top_edge_to_bottom_edge_dist", "overlap_interval",
+                  "point_distance", "is_right_adjacent", "is_bottom_adjacent"]
+    env = {"math": math}
+    env.update(zip(misc_names, _ref_functions("utils/misc.py", misc_names, env)))
+    env = dict(env)
+    # re-lift so that the helpers see each other (they are looked up in the namespace they were compiled in)
+    env.update(zip(misc_names, _ref_functions("utils/misc.py", misc_names, env)))
+    fn_names = ["filter_contained_rectangles_with_category", "filter_contained_rectangles_across_categories", "choose_role",
+                "calc_adjacent_holes_to_cells"]
+    env.update(zip(fn_names, _ref_functions("table_cell_detector.py", fn_names, env)))
+    env.update(find_holes_as_rects=find_holes_as_rects, torch=torch, CellSchema=my_schemas.CellSchema,
+               RegionSchema=my_schemas.RegionSchema)
+    tv = sys.modules.get("torchvision") or types.ModuleType("torchvision")
+    if not hasattr(tv, "ops"):
+        def box_convert(boxes, in_fmt, out_fmt):
+            assert (in_fmt, out_fmt) == ("cxcywh", "xyxy")
+            cx, cy, w, h = boxes.unbind(-1)
+            return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], dim=-1)
+
+        tv.ops = types.SimpleNamespace(box_convert=box_convert)
+        sys.modules.setdefault("torchvision", tv)
+    pp = ref_import("yomitoku.postprocessor.rtdetr_postprocessor")
+    m_names = ["is_fully_contained", "postprocess", "remove_noise_cells", "extract_cell_elements"]
+    methods = dict(zip(m_names, _ref_methods("table_cell_detector.py", "CellDetector", m_names, env)))
+    categories = ["table", "cell", "header", "empty", "kv_item", "grid"]
+    det = types.SimpleNamespace(device="cpu", thresh_score=0.5, label_mapper=dict(enumerate(categories)),
+                                postprocessor=pp.RTDETRPostProcessor(num_classes=6, num_top_queries=1500))
+    for name, fn in methods.items():
+        setattr(det, name, types.MethodType(fn, det))
+    rng = np.random.default_rng(515)
+    cases = []
+    for k in range(40):
+        w, h = int(rng.integers(200, 900)), int(rng.integers(120, 600))
+        ox, oy = int(rng.integers(0, 300)), int(rng.integers(0, 300))
+        rows, cols = int(rng.integers(1, 7)), int(rng.integers(1, 7))
+        boxes, logits = [], []
+        for r in range(rows):
+            for c in range(cols):
+                if rng.random() < 0.18:
+                    continue  # a missing cell: a hole candidate
+                cx, cy = (c + 0.5) / cols + rng.normal(0, 0.004), (r + 0.5) / rows + rng.normal(0, 0.004)
+                bw, bh = 1.0 / cols * rng.uniform(0.9, 1.0), 1.0 / rows * rng.uniform(0.9, 1.0)
+                boxes.append([cx, cy, bw, bh])
+                lg = np.full(6, -6.0)
+                lg[int(rng.choice([1, 1, 1, 2, 3]))] = rng.uniform(0.5, 4.0)
+                logits.append(lg)
+                if rng.random() < 0.15:  # a duplicate, slightly smaller or larger, maybe of another class
+                    boxes.append([cx, cy, bw * rng.uniform(0.8, 1.05), bh * rng.uniform(0.8, 1.05)])
+                    lg2 = np.full(6, -6.0)
+                    lg2[int(rng.choice([1, 2, 3]))] = rng.uniform(0.2, 3.0)
+                    logits.append(lg2)
+        for cls in (0, 4, 5):  # whole-crop table box, kv_item / grid regions
+            if rng.random() < 0.7:
+                boxes.append([0.5, 0.5, rng.uniform(0.93, 1.0), rng.uniform(0.93, 1.0)])
+                lg = np.full(6, -6.0)
+                lg[cls] = rng.uniform(0.5, 3.0)
+                logits.append(lg)
+        n = len(boxes)
+        pad = 1500 - n
+        bx = np.concatenate([np.asarray(boxes, dtype=np.float32).reshape(n, 4), rng.random((pad, 4)).astype(np.float32) * 0.3 + 0.1])
+        lg = np.concatenate([np.asarray(logits, dtype=np.float32).reshape(n, 6), np.full((pad, 6), -8.0, dtype=np.float32)])
+        preds = {"pred_logits": torch.from_numpy(lg)[None], "pred_boxes": torch.from_numpy(bx)[None]}
+        table_box = [ox, oy, ox + w, oy + h]
+        cells, kv, grid = det.postprocess(preds, {"size": (h, w), "offset": (ox, oy)}, table_box)
+        cases.append({"size": [h, w], "offset": [ox, oy], "table_box": table_box, "n_real": n, "logits": lg[:n].tolist(),
+                      "boxes": bx[:n].tolist(), "cells": [c.model_dump() for c in cells], "kv": [r.model_dump() for r in kv],
+                      "grid": [r.model_dump() for r in grid]})
+    with open(os.path.join(GOLDEN, "cells.json"), "w") as f:
+        json.dump({"cases": cases}, f)
+    roles = {}
+    for c in cases:
+        for cell in c["cells"]:
+            roles[cell["role"]] = roles.get(cell["role"], 0) + 1
+    print(f"[cells] wrote {len(cases)} cases; cells by role: {roles}; kv {sum(len(c['kv']) for c in cases)}, grid {sum(len(c['grid']) for c in cases)}")
+
+
 def _ref_methods(relpath, cls, names, env):
     """Like _ref_functions for methods of a reference class: returned as plain functions taking `self` first."""
     import ast
@@ -548,7 +648,7 @@ def main(argv):
     what = argv[1] if len(argv) > 1 else "all"
     os.makedirs(GOLDEN, exist_ok=True)
     todo = {"dbnet": pin_dbnet, "parseq": pin_parseq, "rtdetr": pin_rtdetr, "host": pin_host_logic, "aggregate": pin_aggregate,
-            "filters": pin_filters, "geometry": pin_geometry,
+            "filters": pin_filters, "geometry": pin_geometry, "cells": pin_cells,
             "configs": pin_configs}
     for k, fn in todo.items():
         if what in (k, "all"):

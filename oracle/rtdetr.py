@@ -181,6 +181,7 @@ def rtdetr_decoder(sd, feats, prefix="decoder.", num_queries=300, num_layers=6):
 
 
 @torch.inference_mode()
-def rtdetr_forward(sd, x):
-    """models/rtdetr.py:16-21: fp32 N x 3 x 640 x 640 -> pred_logits N x 300 x nc, pred_boxes N x 300 x 4."""
-    return rtdetr_decoder(sd, hybrid_encoder(sd, presnet(sd, x)))
+def rtdetr_forward(sd, x, num_queries=300):
+    """models/rtdetr.py:16-21: fp32 N x 3 x S x S -> pred_logits N x num_queries x nc, pred_boxes N x num_queries x 4
+    (S = 640 with 300 queries: layout / table structure; S = 960 with 1500: the cell detector; sd's anchors fix S)."""
+    return rtdetr_decoder(sd, hybrid_encoder(sd, presnet(sd, x)), num_queries=num_queries)

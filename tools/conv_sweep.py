@@ -15,6 +15,9 @@ lib = _lib.load()
 # (name, n, h, w, cin, cout, k, stride, pad, dil, act, residual)
 SHAPES = [
     ("dbnet l4 3x3 512->512 d2", 8, 100, 74, 512, 512, 3, 1, 2, 2, 1, 0),
+    ("dbnet dec 3x3 256->64 400x296", 8, 400, 296, 256, 64, 3, 1, 1, 1, 1, 0),
+    ("dbnet l1 3x3 64->64 400x296", 8, 400, 296, 64, 64, 3, 1, 1, 1, 1, 0),
+    ("dbnet l1 1x1 256->64", 1, 1, 947200, 256, 64, 1, 1, 0, 1, 1, 0),
     ("dbnet l4 1x1 1024->2048", 1, 1, 59200, 1024, 2048, 1, 1, 0, 1, 1, 1),
     ("dbnet l4 1x1 512->2048", 1, 1, 59200, 512, 2048, 1, 1, 0, 1, 1, 1),
     ("dbnet l4 1x1 2048->512", 1, 1, 59200, 2048, 512, 1, 1, 0, 1, 1, 0),

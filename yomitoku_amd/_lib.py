@@ -54,6 +54,7 @@ SIGNATURES = {
         [c_void_p, c_int, c_int, c_float, c_float, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_int,
          POINTER(c_int)],
     ),
+    "ymk_table_hole_rects": (c_int, [c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, POINTER(c_int)]),
     "ymk_debug_option": (c_int, [c_char_p, c_int]),
     "ymk_prof_begin": (c_int, []),
     "ymk_prof_end": (c_int, [POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),

@@ -245,6 +245,20 @@ TableStructureRecognizerRTDETRv2Config = make_dataclass(
     ],
 )
 
+# configs/cfg_table_cell_parser_rtdtrv2.py: the same RT-DETRv2 at 960 x 960 with 1500 queries (dense tables reach ~1000 cells)
+TableCellParserRTDETRv2Config = make_dataclass(
+    "TableCellParserRTDETRv2Config",
+    [
+        ("hf_hub_repo", str, "KotaroKinoshita/yomitoku-cell-detector-rtdtrv2-v1"),
+        ("thresh_score", float, 0.5),
+        ("data", RtData, _sub(RtData, img_size=[960, 960])),
+        ("PResNet", RtBackBone, _sub(RtBackBone)),
+        ("HybridEncoder", RtEncoder, _sub(RtEncoder)),
+        ("RTDETRTransformerv2", RtDecoder, _sub(RtDecoder, num_classes=6, num_queries=1500, eval_spatial_size=[960, 960])),
+        ("category", List[str], field(default_factory=lambda: ["table", "cell", "header", "empty", "kv_item", "grid"])),
+    ],
+)
+
 DEFAULT_CONFIGS = [
     TextRecognizerPARSeqLargeV41Config,
     TextDetectorDBNetV2_1Config,
@@ -257,5 +271,5 @@ __all__ = [
     "TextRecognizerPARSeqConfig", "TextRecognizerPARSeqTinyConfig", "TextRecognizerPARSeqSmallConfig",
     "TextRecognizerPARSeqV2Config", "TextRecognizerPARSeqLargeV41Config", "TextRecognizerPARSeqTinyDynwV4Config",
     "LayoutParserRTDETRv2Config", "LayoutParserRTDETRv2V2Config", "TableStructureRecognizerRTDETRv2Config",
-    "DEFAULT_CONFIGS",
+    "TableCellParserRTDETRv2Config", "DEFAULT_CONFIGS",
 ]

@@ -16,7 +16,7 @@
 // K is consumed in chunks of 8 with the in-chunk order permuted so that each half-wave reads
 // 4 consecutive k with one ds_read_b128: step s of chunk kc multiplies k = kc*8 + 4*(l>>5) + s.
 //
-// Block = 256 threads = 4 waves; block tile BM x BN, K tile 32, LDS rows padded to 36 floats
+// Block = 4, 8 or 16 waves (the wide 128 x 128 tile runs with 8: 32 x 64 per wave); block tile BM x BN, K tile 32, LDS rows padded to 36 floats
 // (144 B = 9 x 16 B slots: the 16-lane groups of ds_read_b128 hit 16 distinct slots, guide G4).
 // Global -> register -> LDS double buffering, one barrier per K tile.
 // blockIdx is remapped so that each XCD (private L2) owns a contiguous range of tiles, n fastest,
@@ -146,13 +146,13 @@ __device__ __forceinline__ void epilogue_tile(const ConvK& p, const float* Cs, i
   }
 }
 
-// VAR (experiments, selected per launch through ymk_debug_option("conv_variant")):
-//   bit 0: MFMA order interleaved across the wave's accumulators (k step outermost) instead of 4 dependent steps per tile
-//   bit 1: s_setprio 1 around the MFMA cluster of a K tile
-template <int BM, int BN, int WM, int WN, int MODE, int VAR = 0>
+// PF: K tiles the global loads run ahead of the MFMAs (1: the tile consumed next; 2: one more - two register sets, so a
+// load has two compute phases to come back from MALL / HBM before its ds_write waits for it)
+template <int BM, int BN, int WM, int WN, int MODE, int PF = 1>
 __global__ __launch_bounds__(64 * WM * WN, (2 * (BM + BN) * LDK * 4 <= 80 * 1024 ? 2 : 1) * WM * WN / 4) void conv_igemm(ConvK p) {
-  constexpr int NT = 64 * WM * WN;             // 4 or 8 waves
-  static_assert(NT == 256 || NT == 512, "4 or 8 waves per block");
+  static_assert(PF == 1 || PF == 2, "prefetch distance 1 or 2");
+  constexpr int NT = 64 * WM * WN;             // 4, 8 or 16 waves
+  static_assert(NT == 256 || NT == 512 || NT == 1024, "4, 8 or 16 waves per block");
   constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;  // 32x32 MFMA tiles per wave
   constexpr int RPP = NT / 8;                  // rows staged per pass (8 threads x 16 B per 32-float row)
@@ -198,13 +198,13 @@ __global__ __launch_bounds__(64 * WM * WN, (2 * (BM + BN) * LDK * 4 <= 80 * 1024
   const float* wrow = p.w + (size_t)(n0 + rowb) * p.Kpad + colq * 4;
 
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
-  f32x4 ra[APASS], rb[BPASS];
+  f32x4 ra[PF][APASS], rb[PF][BPASS];
 
   // K-tile cursor (wave-uniform, kept in scalar registers): tap (kh, kw) and channel tile cc
   int cur_kh = 0, cur_kw = 0, cur_cc = 0;
 
   // branch-free gather of one K tile: out-of-image / padded taps read a safe address and are zeroed
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt, int set) {
     int dh, dw, c;
     bool tapok;
     if (MODE == 0) {
@@ -233,22 +233,22 @@ __global__ __launch_bounds__(64 * WM * WN, (2 * (BM + BN) * LDK * 4 <= 80 * 1024
       const bool ok = tapok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
       const unsigned off = ((unsigned)(pixb[i] + ih * p.W + iw) * (unsigned)p.in_ld + (unsigned)c) * 4u;
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok ? off : OOB_OFFSET), 0, 0);
-      ra[i] = __builtin_bit_cast(f32x4, v);
+      ra[set][i] = __builtin_bit_cast(f32x4, v);
     }
 #pragma unroll
     for (int j = 0; j < BPASS; ++j)
-      rb[j] = *reinterpret_cast<const f32x4*>(wrow + (size_t)(RPP * j) * p.Kpad + kt * 32);
+      rb[set][j] = *reinterpret_cast<const f32x4*>(wrow + (size_t)(RPP * j) * p.Kpad + kt * 32);
   };
 
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, int set) {
     float* As = lds + buf * STAGE;
     float* Bs = As + BM * LDK;
 #pragma unroll
     for (int i = 0; i < APASS; ++i)
-      *reinterpret_cast<f32x4*>(As + (rowb + RPP * i) * LDK + colq * 4) = ra[i];
+      *reinterpret_cast<f32x4*>(As + (rowb + RPP * i) * LDK + colq * 4) = ra[set][i];
 #pragma unroll
     for (int j = 0; j < BPASS; ++j)
-      *reinterpret_cast<f32x4*>(Bs + (rowb + RPP * j) * LDK + colq * 4) = rb[j];
+      *reinterpret_cast<f32x4*>(Bs + (rowb + RPP * j) * LDK + colq * 4) = rb[set][j];
   };
 
   // ---- MFMA coordinates
@@ -265,17 +265,10 @@ __global__ __launch_bounds__(64 * WM * WN, (2 * (BM + BN) * LDK * 4 <= 80 * 1024
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const int ktiles = p.Kpad >> 5;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
 
-  for (int kt = 0; kt < ktiles; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < ktiles) load_tile(kt + 1);
-
+  auto compute = [&](int buf) {
     const float* As = lds + buf * STAGE + (wm * WTM + li) * LDK + lh * 4;
     const float* Bs = lds + buf * STAGE + BM * LDK + (wn * WTN + li) * LDK + lh * 4;
-    if (VAR & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) {
       f32x4 fa[TM], fb[TN];
@@ -285,30 +278,44 @@ __global__ __launch_bounds__(64 * WM * WN, (2 * (BM + BN) * LDK * 4 <= 80 * 1024
 #pragma unroll
       for (int b = 0; b < TN; ++b)
         fb[b] = *reinterpret_cast<const f32x4*>(Bs + b * 32 * LDK + kc * 8);
-      if (VAR & 1) {  // k step outermost: consecutive MFMAs never share an accumulator
 #pragma unroll
-        for (int st = 0; st < 4; ++st)
+      for (int a = 0; a < TM; ++a)
 #pragma unroll
-          for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][st], fb[b][st], acc[a][b], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int b = 0; b < TN; ++b) {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, fb[b].x, acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, fb[b].y, acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, fb[b].z, acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
-          }
-      }
+        for (int b = 0; b < TN; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, fb[b].x, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, fb[b].y, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, fb[b].z, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
+        }
     }
-    if (VAR & 2) __builtin_amdgcn_s_setprio(0);
+  };
 
-    if (kt + 1 < ktiles) store_tile(buf ^ 1);
-    __syncthreads();
+  load_tile(0, 0);
+  store_tile(0, 0);
+  if (PF == 2 && ktiles > 1) load_tile(1, 1);
+  __syncthreads();
+
+  if (PF == 1) {
+    for (int kt = 0; kt < ktiles; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < ktiles) load_tile(kt + 1, 0);
+      compute(buf);
+      if (kt + 1 < ktiles) store_tile(buf ^ 1, 0);
+      __syncthreads();
+    }
+  } else {
+    // tile t travels in register set t & 1: loaded at the top of step t - 2, written to LDS[t & 1] at the end of step t - 1
+    for (int kt = 0; kt < ktiles; kt += 2) {
+      if (kt + 2 < ktiles) load_tile(kt + 2, 0);
+      compute(0);
+      if (kt + 1 < ktiles) store_tile(1, PF - 1);
+      __syncthreads();
+      if (kt + 1 >= ktiles) break;
+      if (kt + 3 < ktiles) load_tile(kt + 3, PF - 1);
+      compute(1);
+      if (kt + 2 < ktiles) store_tile(0, 0);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: accumulators -> LDS tile [EROWS][LDC] -> 16 B per lane, full rows coalesced; a tile taller than the
@@ -511,7 +518,7 @@ constexpr int SPLITK_MAX_GRID = 384;
 // test / measurement knobs (ymk_debug_option): process-wide, read per launch, never set on the product path
 static std::atomic<int> g_splitk_force{-1};  // >= 0: that split-K candidate for every eligible launch (kernel tests)
 static std::atomic<int> g_no_splitk{0};      // 1: every launch through conv_igemm (A/B profiling, kernel tests)
-static std::atomic<int> g_conv_variant{0};   // conv_igemm experiment selector, see launch_variant()
+static std::atomic<int> g_conv_variant{0};   // conv_igemm schedule selector for A/B runs, see launch_wide()
 static std::atomic<int> g_prof_dump{0};      // 1: ymk_prof_end prints one line per launch to stderr
 static int splitk_forced() { return g_splitk_force.load(std::memory_order_relaxed); }
 static bool no_splitk() { return g_no_splitk.load(std::memory_order_relaxed) != 0; }
@@ -625,28 +632,42 @@ static bool try_splitk(hipStream_t s, ConvK& k) {
   return true;
 }
 
-template <int BM, int BN, int WM, int WN, int MODE = 0, int VAR = 0>
+template <int BM, int BN, int WM, int WN, int MODE = 0, int PF = 1>
 static void launch(hipStream_t s, ConvK& k) {
   const int mt = (k.M + BM - 1) / BM, nt = (k.Cout + BN - 1) / BN;
   k.ntiles_n = nt;
   if (MODE == 0 && (mt * nt < SPLITK_MAX_GRID || splitk_forced() >= 0) && !no_splitk() && try_splitk(s, k)) return;
   auto* e = prof_open(s, k, BM, BN, mt * nt, 1);
-  hipLaunchKernelGGL((conv_igemm<BM, BN, WM, WN, MODE, VAR>), dim3(mt * nt), dim3(64 * WM * WN), 0, s, k);
+  hipLaunchKernelGGL((conv_igemm<BM, BN, WM, WN, MODE, PF>), dim3(mt * nt), dim3(64 * WM * WN), 0, s, k);
   if (e) YMK_HIP(hipEventRecord(e->second, s));
 }
 
-// conv_variant experiments on the wide-tile path (ymk_debug_option("conv_variant", v); tools/conv_sweep.py):
-//   1: 128x128, interleaved MFMA order   2: 128x128, s_setprio   3: both
-//   4: 128x128 with 8 waves (32x64 wave tiles)   5: 256x128 with 8 waves (64x64 wave tiles)   6: 5 + interleaved order
-static bool launch_variant(hipStream_t s, ConvK& k) {
+// Schedules.  Measured on MI355X (tools/conv_sweep.py, random operands; profiles/r02_conv_sweep*.txt): the 128 x 128
+// tile with EIGHT waves (32 x 64 wave tiles, 4 waves per SIMD at 2 blocks per CU) beats the four-wave form of round 1
+// everywhere - +3..8 % on the K >= 512 layers of DBNet, +10 % on the K = 192 GEMMs of PARSeq, +30 % on the memory-bound
+// 64 -> 256 expands; SIXTEEN waves add a few per cent more where K is short (<= 512: the loop is mostly prologue and
+// epilogue) and lose a little on the long-K layers; the 128 x 64 tile likewise gains from eight waves.  Interleaving the
+// MFMA order across accumulators, s_setprio around the MFMA cluster and a 256 x 128 tile changed nothing or lost.
+// conv_variant (ymk_debug_option) keeps the alternatives reachable for A/B runs:
+//   wide path (Cout > 64):  0 = by K (default)   1 = 4 waves (round 1)   2 = 16 waves   4 = 8 waves   5 = 8 waves, loads 2 K tiles ahead
+//   narrow path (128 x 64): 0 = 8 waves (default)   3 = 4 waves (round 1)   6 = 8 waves, loads 2 K tiles ahead
+static void launch_wide(hipStream_t s, ConvK& k) {
   switch (g_conv_variant.load(std::memory_order_relaxed)) {
-    case 1: launch<128, 128, 2, 2, 0, 1>(s, k); return true;
-    case 2: launch<128, 128, 2, 2, 0, 2>(s, k); return true;
-    case 3: launch<128, 128, 2, 2, 0, 3>(s, k); return true;
-    case 4: launch<128, 128, 4, 2, 0, 0>(s, k); return true;
-    case 5: launch<256, 128, 4, 2, 0, 0>(s, k); return true;
-    case 6: launch<256, 128, 4, 2, 0, 1>(s, k); return true;
-    default: return false;
+    case 1: launch<128, 128, 2, 2>(s, k); break;
+    case 2: launch<128, 128, 4, 4>(s, k); break;
+    case 4: launch<128, 128, 4, 2>(s, k); break;
+    case 5: launch<128, 128, 4, 2, 0, 2>(s, k); break;
+    default:
+      if (k.Kpad <= 512) launch<128, 128, 4, 4>(s, k);
+      else launch<128, 128, 4, 2>(s, k);
+      break;
+  }
+}
+static void launch_n64(hipStream_t s, ConvK& k) {
+  switch (g_conv_variant.load(std::memory_order_relaxed)) {
+    case 3: launch<128, 64, 2, 2>(s, k); break;
+    case 6: launch<128, 64, 4, 2, 0, 2>(s, k); break;
+    default: launch<128, 64, 4, 2>(s, k); break;
   }
 }
 
@@ -718,17 +739,17 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
   } else if (w.cout <= 32) {
     launch<128, 32, 4, 1>(s, k);
   } else if (w.cout <= 64) {
-    if ((k.M + 127) / 128 >= 256) launch<128, 64, 2, 2>(s, k);
+    if ((k.M + 127) / 128 >= 256) launch_n64(s, k);
     else launch<64, 64, 2, 2>(s, k);
   } else if (blocks128 >= 384) {
     // a 128-wide N tile wastes (-Cout mod 128) columns of MFMA work: 25 % at Cout = 192 (the PARSeq-tiny projections
     // and FFN outputs).  64-wide tiles cover such a Cout exactly, at a slightly lower rate per tile.
     const int waste = (128 - w.cout % 128) % 128;
-    if (waste >= 48 && waste * 5 >= w.cout) launch<128, 64, 2, 2>(s, k);
-    else if (!launch_variant(s, k)) launch<128, 128, 2, 2>(s, k);
+    if (waste >= 48 && waste * 5 >= w.cout) launch_n64(s, k);
+    else launch_wide(s, k);
   } else {
     const long blocks64 = (long)((k.M + 127) / 128) * ((w.cout + 63) / 64);
-    if (blocks64 >= 256) launch<128, 64, 2, 2>(s, k);
+    if (blocks64 >= 256) launch_n64(s, k);
     else launch<64, 64, 2, 2>(s, k);
   }
   YMK_HIP(hipGetLastError());

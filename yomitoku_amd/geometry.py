@@ -75,3 +75,86 @@ def quad_to_xyxy(quad):
     xs = [p[0] for p in quad]
     ys = [p[1] for p in quad]
     return min(xs), min(ys), max(xs), max(ys)
+
+
+# ---------------------------------------------------------------------------------------------- table cell detector
+# utils/misc.py:182-441 of the reference: IoU and the "is B the right / bottom neighbour of A" predicates that
+# calc_adjacent_holes_to_cells (table_cell_detector.py:161-192) uses; plain float arithmetic, same order.
+import math  # noqa: E402
+
+
+def calc_iou(rect_a, rect_b):
+    inter = calc_intersection(rect_a, rect_b)
+    if inter is None:
+        return 0
+    ix1, iy1, ix2, iy2 = inter
+    bx1, by1, bx2, by2 = rect_b
+    ax1, ay1, ax2, ay2 = rect_a
+    overlap = (ix2 - ix1) * (iy2 - iy1)
+    return overlap / ((ax2 - ax1) * (ay2 - ay1) + (bx2 - bx1) * (by2 - by1) - overlap)
+
+
+def point_to_segment_distance(px, py, ax, ay, bx, by):
+    abx, aby = bx - ax, by - ay
+    apx, apy = px - ax, py - ay
+    denom = abx * abx + aby * aby
+    if denom == 0:
+        return math.hypot(px - ax, py - ay)
+    t = max(0.0, min(1.0, (apx * abx + apy * aby) / denom))
+    return math.hypot(px - (ax + t * abx), py - (ay + t * aby))
+
+
+def _edge_distances(p1, p2, q1, q2):
+    """(max(d1, d4), max(d2, d3), max(d3, d4), max(d1, d2)) for the facing edges p1-p2 (of A) and q1-q2 (of B)."""
+    d1 = point_to_segment_distance(*p1, *q1, *q2)
+    d2 = point_to_segment_distance(*p2, *q1, *q2)
+    d3 = point_to_segment_distance(*q1, *p1, *p2)
+    d4 = point_to_segment_distance(*q2, *p1, *p2)
+    return max(d1, d4), max(d2, d3), max(d3, d4), max(d1, d2)
+
+
+def _overlap_interval(i1, i2, j1, j2):
+    return max(0.0, min(i2, j2) - max(i1, j1))
+
+
+def _adjacent(dists, hard, rule, dist_threshold):
+    d1, d2, d3, d4 = dists
+    if rule == "hard":
+        return hard
+    if rule == "soft":
+        return d1 < dist_threshold or d2 < dist_threshold or d3 < dist_threshold or d4 < dist_threshold
+    if rule == "nest":
+        return d3 < dist_threshold
+    if rule == "child":
+        return (not hard) and d3 < dist_threshold
+    return False
+
+
+def is_right_adjacent(box_a, box_b, dist_threshold=15, overlap_ratio_th=0.1, ignore_dist_threshold=10, rule="soft"):
+    """Is box_b the right-hand neighbour of box_a (utils/misc.py:299-352)."""
+    ax1, ay1, ax2, ay2 = box_a
+    bx1, by1, bx2, by2 = box_b
+    if bx1 < ax1:
+        return False
+    if _overlap_interval(ay1, ay2, by1, by2) < overlap_ratio_th * min(ay2 - ay1, by2 - by1):
+        return False
+    if math.hypot(ax2 - bx1, ay2 - by1) < ignore_dist_threshold or math.hypot(ax2 - bx1, ay1 - by2) < ignore_dist_threshold:
+        return False
+    dists = _edge_distances((ax2, ay1), (ax2, ay2), (bx1, by1), (bx1, by2))
+    hard = math.hypot(ax2 - bx1, ay1 - by1) < dist_threshold and math.hypot(ax2 - bx1, ay2 - by2) < dist_threshold
+    return bool(_adjacent(dists, hard, rule, dist_threshold))
+
+
+def is_bottom_adjacent(box_a, box_b, dist_threshold=15, overlap_ratio_th=0.1, ignore_dist_threshold=10, rule="soft"):
+    """Is box_b the neighbour below box_a (utils/misc.py:355-441)."""
+    ax1, ay1, ax2, ay2 = box_a
+    bx1, by1, bx2, by2 = box_b
+    if by1 < ay1:
+        return False
+    if _overlap_interval(ax1, ax2, bx1, bx2) < overlap_ratio_th * min(ax2 - ax1, bx2 - bx1):
+        return False
+    if math.hypot(ax2 - bx1, ay2 - by1) < ignore_dist_threshold or math.hypot(ax1 - bx2, ay2 - by1) < ignore_dist_threshold:
+        return False
+    dists = _edge_distances((ax1, ay2), (ax2, ay2), (bx1, by1), (bx2, by1))
+    hard = math.hypot(ax1 - bx1, ay2 - by1) < dist_threshold and math.hypot(ax2 - bx2, ay2 - by1) < dist_threshold
+    return bool(_adjacent(dists, hard, rule, dist_threshold))

@@ -12,7 +12,7 @@ import torch
 from . import imaging
 from .base import BaseModelCatalog, BaseModule, load_config, logger
 from .configs import LayoutParserRTDETRv2Config, LayoutParserRTDETRv2V2Config
-from .geometry import filter_by_flag, is_contained
+from .geometry import containment_matrix, filter_by_flag, is_contained
 from .nets import RTDETRv2
 from .schemas import LayoutParserSchema
 
@@ -57,7 +57,29 @@ class RTDETRPostProcessor:
 
 def filter_contained_rectangles_within_category(category_elements):
     """Per category, drop every box more than 80 % inside another one (mutual containment keeps the
-    larger) - layout_parser.py:31-61."""
+    larger) - layout_parser.py:31-61.  The pair decisions do not depend on each other, so all of them come from one
+    containment matrix (a table with a few hundred detections costs ~40 k scalar predicates otherwise)."""
+    for category, elements in category_elements.items():
+        n = len(elements)
+        if n < 2:
+            continue
+        boxes = [e["box"] for e in elements]
+        inside = containment_matrix(boxes, boxes, 0.8)  # inside[i][j]: box j lies in box i
+        b = np.asarray(boxes, dtype=np.float64).reshape(n, 4)
+        area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+        upper = np.triu(np.ones((n, n), dtype=bool), 1)  # pairs i < j
+        j_in_i, i_in_j = inside & upper, inside.T & upper
+        both = j_in_i & i_in_j
+        bigger_i = area[:, None] > area[None, :]
+        drop_j = (both & bigger_i) | (j_in_i & ~i_in_j)
+        drop_i = (both & ~bigger_i) | (i_in_j & ~j_in_i)
+        keep = ~(drop_j.any(axis=0) | drop_i.any(axis=1))
+        category_elements[category] = filter_by_flag(elements, keep.tolist())
+    return category_elements
+
+
+def _filter_within_category_scalar(category_elements):
+    """The pair loop of layout_parser.py:31-61, statement for statement (tests compare the matrix form with it)."""
     for category, elements in category_elements.items():
         boxes = [e["box"] for e in elements]
         keep = [True] * len(boxes)

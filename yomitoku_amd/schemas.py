@@ -3,9 +3,9 @@ names, types and validation (extra fields forbidden, validate on assignment)."""
 
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import Any, Dict, List, Optional
 
-from pydantic import conlist
+from pydantic import Field, conlist
 
 from .base import BaseSchema
 
@@ -103,3 +103,32 @@ class TextRecognizerSchema(BaseSchema):
     directions: List[str]
     scores: List[float]
     points: List[Quad]
+
+
+# ---- table cell detector (reference schemas/table_semantic_parser.py:62-145: the model-stage records)
+class CellSchema(BaseSchema):
+    meta: Dict[str, Any] = Field(default_factory=dict)
+    contents: Optional[str]
+    role: Optional[str]
+    id: Optional[str]
+    box: Box
+    row: Optional[int]
+    col: Optional[int]
+    row_span: Optional[int]
+    col_span: Optional[int]
+
+
+class RegionSchema(BaseSchema):
+    id: Optional[str] = None
+    box: Box
+    role: str
+    score: float = 1.0
+
+
+class TableDetectorSchema(BaseSchema):
+    id: Optional[str]
+    box: Box
+    role: Optional[str]
+    cells: List[CellSchema]
+    kv_regions: List[RegionSchema] = Field(default_factory=list)
+    grid_regions: List[RegionSchema] = Field(default_factory=list)

@@ -43,7 +43,8 @@ def sincos_pos_embed(w: int, h: int, dim: int = 256, temperature: float = 10000.
 
 
 def rtdetr_state_dict(seed: int = 1240, num_classes: int = 6, hidden: int = 256, num_layers: int = 6, ffn: int = 1024,
-                      num_queries: int = 300, score_bias: float = 0.0, score_gain: float = 1.0) -> "OrderedDict[str, torch.Tensor]":
+                      num_queries: int = 300, score_bias: float = 0.0, score_gain: float = 1.0,
+                      eval_size=(640, 640), enc_score_gain: float = 1.0) -> "OrderedDict[str, torch.Tensor]":
     d = _Draw(seed)
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
 
@@ -147,7 +148,11 @@ def rtdetr_state_dict(seed: int = 1240, num_classes: int = 6, hidden: int = 256,
         # the score threshold (random heads would otherwise "detect" hundreds of boxes per page, or none)
         sd[f"{t}dec_score_head.{num_layers - 1}.weight"] *= score_gain
         sd[f"{t}dec_score_head.{num_layers - 1}.bias"] += score_bias
-    anchors, valid = generate_anchors()
+    if enc_score_gain != 1.0:
+        # spread the encoder-token scores: with 18900 tokens (960 x 960) the top-1500 cut otherwise falls between two
+        # scores ~1e-6 apart, and WHICH token is query no. 1500 would depend on fp32 summation order
+        sd[t + "enc_score_head.weight"] *= enc_score_gain
+    anchors, valid = generate_anchors(tuple(eval_size))  # 640 x 640: layout / table structure; 960 x 960: cell detector
     sd[t + "anchors"] = anchors
     sd[t + "valid_mask"] = valid
     return sd
