@@ -297,7 +297,9 @@ def offset_round(path, delta, arc_tolerance=0.25):
         j = i
     if -a * 0.5 < 0:
         src.reverse()
-    steps = math.pi / math.acos(1 - arc_tolerance / abs(delta))
+    # ClipperOffset::DoOffset: the arc tolerance is capped at |delta| * 0.25 (matters for |delta| < 1 only)
+    y = min(arc_tolerance, abs(delta) * 0.25)
+    steps = math.pi / math.acos(1 - y / abs(delta))
     steps = min(steps, abs(delta) * math.pi)
     m_sin, m_cos = math.sin(2 * math.pi / steps), math.cos(2 * math.pi / steps)
     per_rad = steps / (2 * math.pi)

@@ -504,6 +504,89 @@ def pin_cells():
     print(f"[cells] wrote {len(cases)} cases; cells by role: {roles}; kv {sum(len(c['kv']) for c in cases)}, grid {sum(len(c['grid']) for c in cases)}")
 
 
+def _export_documents(n=12, seed=808):
+    """Seeded DocumentAnalyzerSchema objects with awkward text (markdown / HTML specials, URLs, line breaks, spans)."""
+    from yomitoku_amd.schemas import (DocumentAnalyzerSchema, FigureSchema, ParagraphSchema, TableCellSchema, TableLineSchema,
+                                      TableStructureRecognizerSchema)
+
+    rng = np.random.default_rng(seed)
+    words = ["請求書", "total*", "a|b", "#1 [x](y)", "see https://example.com/a?b=1&c=<2>", "line1\nline2", "`code`", "5 < 7 & 9 > 8",
+             "~del~", "+1-2", "{k}", "plain text", "表 3", "!bang", "multi\nline\ntext", ""]
+
+    def text():
+        return " ".join(words[int(i)] for i in rng.integers(0, len(words), int(rng.integers(1, 4))))
+
+    docs = []
+    for _ in range(n):
+        order = 0
+        paragraphs, tables, figures = [], [], []
+        for _p in range(int(rng.integers(1, 6))):
+            role = [None, None, "section_headings", "page_header"][int(rng.integers(0, 4))]
+            paragraphs.append(ParagraphSchema(box=[0, order * 10, 100, order * 10 + 8], contents=text(), direction="horizontal", order=order, role=role))
+            order += 1
+        for _t in range(int(rng.integers(0, 3))):
+            n_row, n_col = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+            taken, cells = set(), []
+            for r in range(1, n_row + 1):
+                for c in range(1, n_col + 1):
+                    if (r, c) in taken:
+                        continue
+                    rs = int(rng.integers(1, min(2, n_row - r + 1) + 1))
+                    cs = int(rng.integers(1, min(2, n_col - c + 1) + 1))
+                    if any((r + a, c + b) in taken for a in range(rs) for b in range(cs)):
+                        rs = cs = 1
+                    taken.update((r + a, c + b) for a in range(rs) for b in range(cs))
+                    cells.append(TableCellSchema(col=c, row=r, col_span=cs, row_span=rs, box=[c, r, c + cs, r + rs], contents=text()))
+            line = TableLineSchema(box=[0, 0, 1, 1], score=0.9)
+            tables.append(TableStructureRecognizerSchema(box=[0, order * 10, 100, order * 10 + 8], n_row=n_row, n_col=n_col, rows=[line] * n_row,
+                                                         cols=[line] * n_col, spans=[], cells=cells, order=order))
+            order += 1
+        for _f in range(int(rng.integers(0, 2))):
+            inner = [ParagraphSchema(box=[1, 1, 5, 5], contents=text(), direction="horizontal", order=k, role=None) for k in range(2)]
+            figures.append(FigureSchema(box=[2, 2, 30, 30], order=order, paragraphs=inner, direction="horizontal"))
+            order += 1
+        docs.append(DocumentAnalyzerSchema(paragraphs=paragraphs, tables=tables, words=[], figures=figures))
+    return docs
+
+
+def pin_export():
+    """Exporter text conversions (export/export_csv.py, export_markdown.py, export_html.py): the reference's own functions,
+    lifted by ast, on seeded documents -> tests/golden/export.json.  Figures are not written (export_figure=False): that
+    part needs cv2.imencode; convert_html's lxml pretty-printing is not reproduced either - its ELEMENTS are pinned."""
+    import csv as csv_mod
+    import json
+    import re as re_mod
+    from html import escape
+
+    env_csv = {"csv": csv_mod, "os": os, "save_image": None}
+    t2c, p2c, conv_csv = _ref_functions("export/export_csv.py", ["table_to_csv", "paragraph_to_csv", "convert_csv"], env_csv)
+    env_csv.update(table_to_csv=t2c, paragraph_to_csv=p2c)
+    t2c, p2c, conv_csv = _ref_functions("export/export_csv.py", ["table_to_csv", "paragraph_to_csv", "convert_csv"], env_csv)
+    md_names = ["escape_markdown_special_chars", "paragraph_to_md", "table_to_md", "convert_markdown"]
+    env_md = {"re": re_mod, "os": os}
+    env_md.update(zip(md_names, _ref_functions("export/export_markdown.py", md_names, env_md)))
+    md = dict(zip(md_names, _ref_functions("export/export_markdown.py", md_names, env_md)))
+    html_names = ["convert_text_to_html", "add_td_tag", "add_table_tag", "add_tr_tag", "add_p_tag", "add_h1_tag", "table_to_html",
+                  "paragraph_to_html"]
+    env_html = {"re": re_mod, "os": os, "escape": escape}
+    env_html.update(zip(html_names, _ref_functions("export/export_html.py", html_names, env_html)))
+    hf = dict(zip(html_names, _ref_functions("export/export_html.py", html_names, env_html)))
+    cases = []
+    for doc in _export_documents():
+        for ilb in (False, True):
+            for letter in (False, True):
+                csv_el = conv_csv(doc.model_copy(deep=True), "out.csv", ilb, None, False, letter, "figures")
+                md_text, md_el = md["convert_markdown"](doc.model_copy(deep=True), "out.md", ilb, None, letter, False, 200, "figures")
+                cases.append({"doc": doc.model_dump(), "ignore_line_break": ilb, "figure_letter": letter,
+                              "csv": [{"type": e["type"], "element": e["element"], "order": e["order"]} for e in csv_el],
+                              "markdown": md_text,
+                              "html_tables": [hf["table_to_html"](t, ilb)["html"] for t in doc.tables],
+                              "html_paragraphs": [hf["paragraph_to_html"](p_, ilb)["html"] for p_ in doc.paragraphs]})
+    with open(os.path.join(GOLDEN, "export.json"), "w") as f:
+        json.dump({"cases": cases}, f, ensure_ascii=False)
+    print(f"[export] wrote {len(cases)} cases")
+
+
 def _ref_methods(relpath, cls, names, env):
     """Like _ref_functions for methods of a reference class: returned as plain functions taking `self` first."""
     import ast
@@ -648,7 +731,7 @@ def main(argv):
     what = argv[1] if len(argv) > 1 else "all"
     os.makedirs(GOLDEN, exist_ok=True)
     todo = {"dbnet": pin_dbnet, "parseq": pin_parseq, "rtdetr": pin_rtdetr, "host": pin_host_logic, "aggregate": pin_aggregate,
-            "filters": pin_filters, "geometry": pin_geometry, "cells": pin_cells,
+            "filters": pin_filters, "geometry": pin_geometry, "cells": pin_cells, "export": pin_export,
             "configs": pin_configs}
     for k, fn in todo.items():
         if what in (k, "all"):

@@ -1,0 +1,153 @@
+"""Parity at the configurations BASELINE.json names ("Parity at the configs BASELINE names"):
+
+  configs[1]  DBNet, batch 8 of 1600 x 1200 pages (3 x 1600 x 1184 each): one page against the oracle, every page against
+              its own batch-1 map (to 1e-5: at batch 1 the grid-starved 1/32-scale layers take the split-K kernel, whose
+              partial sums are added in another order than conv_igemm's k-ordered chain);
+  configs[2]  TextRecognizer("parseq") - open-beta geometry, FULL depth 12, refinement on - on 256 synthetic lines through
+              the fixed batch_size = 128 branch of _make_mini_batch (text_recognizer.py:191-203) against
+              oracle.pipeline.recognize; and the default recogniser's geometry (parseq-large-v4_1: D = 768, 8 heads of 96,
+              8 x 8 patches, depth 12) on two widths against the oracle forward;
+  configs[3]  one whole DocumentAnalyzerSchema against the ORACLE chain (not against the product's own stages):
+              continuous stages within tolerance, every discrete stage fed the same upstream tensor on both sides,
+              and the final schema equal to the (reference-pinned) aggregation of the oracle-side stage results.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dbnet_batch8_full_size(dev):
+    from oracle.dbnet import dbnet_forward
+    from oracle.preprocess import detector_preprocess
+    from yomitoku_amd import imaging
+    from yomitoku_amd.nets import DBNet
+    from yomitoku_amd.utils.synth import dbnet_state_dict, synthetic_page
+
+    sd = dbnet_state_dict(1234)
+    net = DBNet().load_state_dict(sd).to(dev)
+    imgs = [synthetic_page(30 + i, 1600, 1200) for i in range(8)]
+    x = torch.cat([imaging.detector_tensor(imaging.page_to_device(im, dev), 1280, 1600) for im in imgs], 0)
+    assert tuple(x.shape) == (8, 3, 1600, 1184)
+    out = net(x)["binary"]
+    ref = dbnet_forward(sd, detector_preprocess(imgs[5]))["binary"]
+    err = (out[5:6].cpu() - ref).abs().max().item()
+    assert err < 1e-3, f"page 5 of the batch: max |dP| = {err}"
+    worst = 0.0
+    for i in range(8):
+        worst = max(worst, (net(x[i : i + 1])["binary"] - out[i : i + 1]).abs().max().item())
+    assert worst < 1e-5, f"batch-8 maps differ from their batch-1 maps by {worst}"
+    assert torch.equal(net(x)["binary"], out)  # the same launch shapes: bit-identical on repeat
+
+
+def test_text_recognizer_open_beta_batch128_branch(dev):
+    from oracle import pipeline as op
+    from oracle.parseq import PRESETS, make_cfg
+    from yomitoku_amd.text_recognizer import TextRecognizer
+    from yomitoku_amd.utils.synth import parseq_state_dict, synthetic_line_sheet
+
+    sheet, quads = synthetic_line_sheet(seed=5, n_lines=256)
+    rec = TextRecognizer(model_name="parseq", from_pretrained=False, device="cuda:0", dynamic_width=True, batch_bucketing=True)
+    assert getattr(rec._cfg.data, "width_budget", None) is None and int(rec._cfg.data.batch_size) == 128
+    assert int(rec._cfg.encoder.depth) == 12 and int(rec.model.refine_iters) == 1
+    sd = parseq_state_dict(1236, patch=(8, 8), enc_dim=512, dec_dim=512, num_tokens=7312, eos_bias=6.5)
+    rec.model.load_state_dict(sd)
+    batches, _, dataset, order = rec.preprocess(sheet, quads)
+    assert [len(b) for b in batches] == [128, 128] and order is not None
+    res, _ = rec(sheet, quads)
+    ocfg = make_cfg(**PRESETS["parseq"])
+    contents, scores, directions = op.recognize(sd, ocfg, sheet, quads, rec.charset, dynamic_width=True, batch_bucketing=True,
+                                                width_budget=None, max_batch_size=None, batch_size=128)
+    assert res.contents == contents and res.directions == directions and res.points == quads
+    assert np.allclose(res.scores, scores, rtol=1e-3, atol=1e-6)
+    print("open-beta: distinct strings", len(set(contents)), "mean length", np.mean([len(c) for c in contents]))
+
+
+@pytest.mark.parametrize("width,batch", [(800, 2), (320, 3)])
+def test_parseq_large_v4_1_geometry(dev, width, batch):
+    """The default recogniser (text_recognizer.py:51, cfg_text_recognizer_parseq_large_v4_1.py): per-op decoder path at
+    D = 768, flash attention with head dim 96, full depth."""
+    from oracle.parseq import PRESETS, make_cfg, parseq_forward
+    from tests.test_parseq_gpu import _net
+    from yomitoku_amd.utils.synth import parseq_state_dict, synthetic_line_batch
+
+    sd = parseq_state_dict(1237, patch=(8, 8), enc_dim=768, dec_dim=768, num_tokens=7121, eos_bias=6.5)
+    ocfg, net = _net(dev, sd, "parseq-large-v4_1")
+    assert (ocfg.enc_dim, ocfg.enc_heads, ocfg.enc_depth) == (768, 8, 12)
+    x = synthetic_line_batch(40 + width, batch, width)
+    ref, steps = parseq_forward(sd, ocfg, x, return_steps=True)
+    out = net(x.to(dev)).cpu()
+    assert net.last_ar_steps == steps and out.shape == ref.shape
+    assert torch.equal(out.argmax(-1), ref.argmax(-1))
+    assert (out - ref).abs().max().item() < 1e-3
+
+
+def test_whole_page_schema_vs_oracle_chain(dev):
+    from oracle import pipeline as op
+    from oracle.dbnet import dbnet_forward
+    from oracle.parseq import PRESETS, make_cfg
+    from oracle.preprocess import detector_preprocess
+    from tests.test_pipeline_gpu import _assert_same_schema
+    from tests.test_rtdetr_gpu import assert_same_detections
+    from yomitoku_amd import DocumentAnalyzer
+    from yomitoku_amd.document_analyzer import ocr_aggregate
+    from yomitoku_amd.schemas import DocumentAnalyzerSchema, LayoutAnalyzerSchema, OCRSchema, TextDetectorSchema, TextRecognizerSchema
+    from yomitoku_amd.utils.synth import dbnet_state_dict, parseq_state_dict, synthetic_page_with_truth
+    from yomitoku_amd.utils.synth_rtdetr import rtdetr_state_dict
+
+    img = synthetic_page_with_truth(3, 1000, 1400)[0]
+    configs = {
+        "ocr": {"text_detector": {"from_pretrained": False},
+                "text_recognizer": {"model_name": "parseq-tiny-dynw-v4", "from_pretrained": False, "dynamic_width": True,
+                                    "batch_bucketing": True, "source_downscale": True}},
+        "layout_analyzer": {"layout_parser": {"from_pretrained": False}, "table_structure_recognizer": {"from_pretrained": False}},
+    }
+    an = DocumentAnalyzer(configs=configs, device="cuda:0")
+    sds = {"det": dbnet_state_dict(1234, out_bias=-2.0), "rec": parseq_state_dict(1235, eos_bias=6.0),
+           "lay": rtdetr_state_dict(1240, num_classes=6, score_bias=-1.5), "tab": rtdetr_state_dict(1241, num_classes=3, score_bias=-1.0)}
+    an.text_detector.model.load_state_dict(sds["det"])
+    an.text_recognizer.model.load_state_dict(sds["rec"])
+    an.layout.layout_parser.model.load_state_dict(sds["lay"])
+    an.layout.table_structure_recognizer.model.load_state_dict(sds["tab"])
+    got, _, _ = an(img)
+
+    # ---- detector: continuous stage vs the oracle, discrete stage on the same upstream tensor
+    det = an.text_detector
+    prob = det.model(det.preprocess(img))["binary"].cpu()
+    ref_prob = dbnet_forward(sds["det"], detector_preprocess(img))["binary"]
+    assert (prob - ref_prob).abs().max().item() < 1e-3
+    _, quads, det_scores = op.detect(sds["det"], img, prob=prob)
+    assert len(quads) >= 5
+    # ---- recogniser: the oracle chain on those quads
+    ocfg = make_cfg(**PRESETS["parseq-tiny-dynw-v4"])
+    contents, rec_scores, directions = op.recognize(sds["rec"], ocfg, img, quads, an.text_recognizer.charset, dynamic_width=True,
+                                                    batch_bucketing=True, width_budget=8000, max_batch_size=64, batch_size=10,
+                                                    source_downscale=True)
+    # ---- layout: logits / boxes vs the oracle forward; the box logic on the product's tensor (same upstream policy)
+    lp, ts = an.layout.layout_parser, an.layout.table_structure_recognizer
+    preds = lp.model(lp.preprocess(img))
+    ref_preds, _ = op.layout(sds["lay"], img)
+    assert_same_detections(preds["pred_logits"].cpu().numpy(), preds["pred_boxes"].cpu().numpy(),
+                           ref_preds["pred_logits"].numpy(), ref_preds["pred_boxes"].numpy())
+    lay = lp.postprocess(preds, img.shape[:2])
+    tables = []
+    if lay.tables:
+        batch, metas = ts.preprocess(img, [t.box for t in lay.tables])
+        tp = ts.model(batch)
+        for i, (t, meta) in enumerate(zip(lay.tables, metas)):
+            (rp, _), = op.tables(sds["tab"], img, [t.box])
+            assert_same_detections(tp["pred_logits"][i : i + 1].cpu().numpy(), tp["pred_boxes"][i : i + 1].cpu().numpy(),
+                                   rp["pred_logits"].numpy(), rp["pred_boxes"].numpy())
+            table = ts.postprocess({"pred_logits": tp["pred_logits"][i : i + 1], "pred_boxes": tp["pred_boxes"][i : i + 1]}, meta)
+            if table.n_row > 0 and table.n_col > 0:
+                tables.append(table)
+    # ---- the schema the reference's aggregation builds from the ORACLE-side stage results
+    det_s = TextDetectorSchema(points=quads, scores=det_scores)
+    rec_s = TextRecognizerSchema(contents=contents, scores=rec_scores, points=quads, directions=directions)
+    an.img = img
+    want = DocumentAnalyzerSchema(**an.aggregate(OCRSchema(words=ocr_aggregate(det_s, rec_s)),
+                                               LayoutAnalyzerSchema(paragraphs=lay.paragraphs, tables=tables, figures=lay.figures)))
+    _assert_same_schema(want.model_dump(), got.model_dump(), score_rtol=1e-3)
+    assert len(got.words) == len(quads) and sum(len(w.content) for w in got.words) > 0
+    print("whole page: words", len(got.words), "paragraphs", len(got.paragraphs), "tables", len(got.tables), "figures", len(got.figures))

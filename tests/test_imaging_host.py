@@ -46,5 +46,9 @@ def test_batched_planner_equals_per_quad_form(seed, dynamic):
 def test_planner_edge_cases():
     assert imaging.plan_crops((100, 100), []) == []
     assert imaging.plan_crops((100, 100), [[[0, 0], [1, 1]]]) == [None]
-    with pytest.raises(ValueError):
-        imaging.plan_crops((100, 100), [[[5, 5], [5, 5], [5, 9], [5, 9]]])  # zero-width line
+    # a zero-width / zero-height quad is dropped like an invalid one (it does not abort the page); its neighbours survive
+    quads = [[[5, 5], [5, 5], [5, 9], [5, 9]], [[5, 5], [60, 5], [60, 25], [5, 25]], [[10, 10], [60, 10], [60, 10], [10, 10]]]
+    for planner in (imaging.plan_crops, imaging._plan_crops_scalar):
+        plans = planner((100, 100), quads)
+        assert [p is None for p in plans] == [True, False, True] and plans[1].index == 1
+    assert imaging.plan_crops((100, 100), quads[:1]) == [None]

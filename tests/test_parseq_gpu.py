@@ -176,3 +176,35 @@ def test_grouped_forward_open_beta_refine(dev):
         assert torch.equal(got.argmax(-1), ref.argmax(-1))
         assert (got - ref).abs().max().item() < LOGIT_TOL
         row += x.shape[0]
+
+
+def test_legacy_parseq_tiny_geometry_head_dim_46(dev):
+    """The old `parseq-tiny` (cfg_text_recognizer_parseq_tiny.py: D = 368, 8 heads -> head dim 46, 8 x 16 patches, 400 px
+    canvas, 50 characters): rows are only 8 B aligned, so attention takes the one-wave-per-query kernel with scalar key
+    loads and the decoder the per-op path.  Single call and grouped (ragged) call vs the oracle."""
+    from oracle.parseq import make_cfg, parseq_forward
+    from yomitoku_amd.nets import PARSeq
+    from yomitoku_amd.utils.synth import parseq_state_dict, synthetic_line_batch
+
+    geo = dict(patch=(8, 16), enc_dim=368, dec_dim=368, num_tokens=7121, max_label_length=50, img_size=(32, 400))
+    sd = parseq_state_dict(1238, enc_depth=3, eos_bias=6.0, **geo)
+    ocfg = make_cfg(patch=(8, 16), enc_dim=368, enc_heads=8, enc_depth=3, dec_dim=368, dec_heads=8, num_tokens=7121,
+                    max_label_length=50, img_size=(32, 400))
+    cfg = {"num_tokens": 7121, "max_label_length": 50, "refine_iters": 1, "decode_ar": 1, "repetition_stop": True,
+           "data": {"img_size": [32, 400]},
+           "encoder": {"patch_size": [8, 16], "num_heads": 8, "embed_dim": 368, "mlp_ratio": 4, "depth": 3},
+           "decoder": {"embed_dim": 368, "num_heads": 8, "mlp_ratio": 4, "depth": 1}}
+    net = PARSeq(cfg).load_state_dict(sd).to(dev)
+    xs = [synthetic_line_batch(61, 3, 400), synthetic_line_batch(62, 2, 160)]
+    for x in xs:
+        ref, steps = parseq_forward(sd, ocfg, x, return_steps=True)
+        out = net(x.to(dev)).cpu()
+        assert net.last_ar_steps == steps and out.shape == ref.shape
+        assert torch.equal(out.argmax(-1), ref.argmax(-1)) and (out - ref).abs().max().item() < LOGIT_TOL
+    logits, out_lens, steps = net.forward_groups([x.to(dev) for x in xs])
+    row = 0
+    for x, n, st in zip(xs, out_lens, steps):
+        ref, ref_steps = parseq_forward(sd, ocfg, x, return_steps=True)
+        got = logits[row : row + x.shape[0], :n].cpu()
+        assert st == ref_steps and torch.equal(got.argmax(-1), ref.argmax(-1)) and (got - ref).abs().max().item() < LOGIT_TOL
+        row += x.shape[0]

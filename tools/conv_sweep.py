@@ -34,9 +34,12 @@ SHAPES = [
     ("parseq head 192->7119", 1, 1, 66155, 192, 7119, 1, 1, 0, 1, 0, 0),
 ]
 VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "0,1,2,3,4,5,6").split(",")]
+if os.environ.get("ONLY"):  # substring filter on the shape names (PMC runs profile one or two shapes)
+    SHAPES = [sh for sh in SHAPES if any(tok in sh[0] for tok in os.environ["ONLY"].split("|"))]
+REPS = int(os.environ.get("REPS", 5))
 
 
-def run(shape, variant, reps=5):
+def run(shape, variant, reps=REPS):
     name, n, h, w, cin, cout, k, stride, pad, dil, act, res = shape
     g = torch.Generator(device="cpu").manual_seed(1)
     x = torch.randn(n, h, w, cin, generator=g).to(dev)

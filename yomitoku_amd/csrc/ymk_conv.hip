@@ -202,16 +202,34 @@ __global__ __launch_bounds__(64 * WM * WN, (2 * (BM + BN) * LDK * 4 <= 80 * 1024
 
   // K-tile cursor (wave-uniform, kept in scalar registers): tap (kh, kw) and channel tile cc
   int cur_kh = 0, cur_kw = 0, cur_cc = 0;
+  // byte offset of this thread's 16 B inside each of its rows for the current TAP, or OOB_OFFSET when the tap falls
+  // outside the image / the row is a tail row: recomputed once per tap, not once per K tile - the channel tile within
+  // a tap only moves the buffer instruction's scalar offset (the range check ignores soffset, so masked lanes stay
+  // out of range and valid lanes stay inside the view)
+  unsigned voff[APASS];
+#pragma unroll
+  for (int i = 0; i < APASS; ++i) voff[i] = OOB_OFFSET;
 
   // branch-free gather of one K tile: out-of-image / padded taps read a safe address and are zeroed
   auto load_tile = [&](int kt, int set) {
-    int dh, dw, c;
-    bool tapok;
     if (MODE == 0) {
-      dh = cur_kh * p.dil;
-      dw = cur_kw * p.dil;
-      c = cur_cc * 32 + colq * 4;
-      tapok = c < p.C;
+      if (cur_cc == 0) {  // wave-uniform: a new filter tap
+        const int dh = cur_kh * p.dil, dw = cur_kw * p.dil;
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+          const int ih = ih0[i] + dh, iw = iw0[i] + dw;
+          const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+          const unsigned off = ((unsigned)(pixb[i] + ih * p.W + iw) * (unsigned)p.in_ld + (unsigned)(colq * 4)) * 4u;
+          voff[i] = ok ? off : OOB_OFFSET;
+        }
+      }
+      const bool chan_ok = cur_cc * 32 + colq * 4 < p.C;  // the last channel tile of a C % 32 != 0 layer is partial
+      const int soff = cur_cc * 128;
+#pragma unroll
+      for (int i = 0; i < APASS; ++i) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(chan_ok ? voff[i] : OOB_OFFSET), soff, 0);
+        ra[set][i] = __builtin_bit_cast(f32x4, v);
+      }
       if (++cur_cc == p.ctiles) {
         cur_cc = 0;
         if (++cur_kw == p.KW) {
@@ -222,18 +240,16 @@ __global__ __launch_bounds__(64 * WM * WN, (2 * (BM + BN) * LDK * 4 <= 80 * 1024
     } else {
       const int tap = kt * 8 + colq;
       const int kh = tap / p.KW, kw = tap - kh * p.KW;
-      dh = kh * p.dil;
-      dw = kw * p.dil;
-      c = 0;
-      tapok = tap < p.KH * p.KW;
-    }
+      const int dh = kh * p.dil, dw = kw * p.dil;
+      const bool tapok = tap < p.KH * p.KW;
 #pragma unroll
-    for (int i = 0; i < APASS; ++i) {
-      const int ih = ih0[i] + dh, iw = iw0[i] + dw;
-      const bool ok = tapok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-      const unsigned off = ((unsigned)(pixb[i] + ih * p.W + iw) * (unsigned)p.in_ld + (unsigned)c) * 4u;
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok ? off : OOB_OFFSET), 0, 0);
-      ra[set][i] = __builtin_bit_cast(f32x4, v);
+      for (int i = 0; i < APASS; ++i) {
+        const int ih = ih0[i] + dh, iw = iw0[i] + dw;
+        const bool ok = tapok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        const unsigned off = ((unsigned)(pixb[i] + ih * p.W + iw) * (unsigned)p.in_ld) * 4u;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok ? off : OOB_OFFSET), 0, 0);
+        ra[set][i] = __builtin_bit_cast(f32x4, v);
+      }
     }
 #pragma unroll
     for (int j = 0; j < BPASS; ++j)

@@ -249,7 +249,10 @@ static std::vector<IPt> offset_round(const std::vector<IPt>& in, double delta) {
     for (int i = 0, j = len - 1; i < len; j = i++) a += ((double)src[j].x + src[i].x) * ((double)src[j].y - src[i].y);
     if (-a * 0.5 < 0) std::reverse(src.begin(), src.end());
   }
-  const double pi = 3.141592653589793238, two_pi = 2 * pi, arc_tol = 0.25;
+  const double pi = 3.141592653589793238, two_pi = 2 * pi;
+  // ClipperOffset::DoOffset: y = ArcTolerance (0.25, the pyclipper default) unless that exceeds |delta| * 0.25 -
+  // for |delta| < 1 the tolerance scales down with the offset, so the acos argument stays in [0.75, 1)
+  const double arc_tol = std::min(0.25, std::fabs(delta) * 0.25);
   double steps = pi / std::acos(1 - arc_tol / std::fabs(delta));
   if (steps > std::fabs(delta) * pi) steps = std::fabs(delta) * pi;
   double m_sin = std::sin(two_pi / steps);

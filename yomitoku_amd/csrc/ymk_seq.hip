@@ -293,7 +293,12 @@ void flash_attention(hipStream_t s, const float* q, const float* k, const float*
   else if (hd == 64) hipLaunchKernelGGL(k_flash_attn<64>, grid, dim3(256), 0, s, p);
   else if (hd == 96) hipLaunchKernelGGL(k_flash_attn<96>, grid, dim3(256), 0, s, p);
   else if (hd == 48) hipLaunchKernelGGL((k_flash_attn<64, 48>), grid, dim3(256), 0, s, p);
-  else throw Error("attention: unsupported head dim " + std::to_string(hd));
+  else {
+    // any other head dim (46: the legacy parseq-tiny) takes the one-wave-per-query kernel - correct, not fast
+    YMK_CHECK(Lk <= 1024 && hd <= 128, "attention: head dim " + std::to_string(hd) + " is only supported for <= 1024 keys per sample");
+    small_attention(s, q, k, v, o, B, H, Lq, Lk, hd, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, scale, nullptr, 0, nullptr, 0, tab);
+    return;
+  }
   YMK_HIP(hipGetLastError());
 }
 
@@ -312,13 +317,17 @@ struct SmallAttnP {
   const unsigned char* kpm;
   int ld_kpm;
   const int *koff, *klen;  // ragged keys/values: sample b reads klen[b] rows from row koff[b] (null = strided, Lk)
+  const int *qoff, *qlen;  // ragged queries / outputs, likewise (null = strided, Lq)
+  int vec4;                // 1: head dim and every base / stride allow 16 B key loads
 };
 __global__ __launch_bounds__(64) void k_small_attn(SmallAttnP p) {
   __shared__ float prob[1024];
   __shared__ float qs[128];
   const int lane = threadIdx.x;
   const int qi = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const float* qr = p.q + (size_t)b * p.bsq + (size_t)qi * p.ldq + h * p.hd;
+  if (p.qoff && qi >= p.qlen[b]) return;  // block-uniform: the grid is sized for the longest sample
+  const size_t qrow0 = p.qoff ? (size_t)p.qoff[b] : 0;
+  const float* qr = (p.qoff ? p.q + qrow0 * p.ldq : p.q + (size_t)b * p.bsq) + (size_t)qi * p.ldq + h * p.hd;
   for (int d = lane; d < p.hd; d += 64) qs[d] = qr[d] * p.scale;
   __syncthreads();
   const float* kb = p.k + (size_t)b * p.bsk + h * p.hd;
@@ -338,9 +347,13 @@ __global__ __launch_bounds__(64) void k_small_attn(SmallAttnP p) {
     if (!blocked) {
       const float* kr = kb + (size_t)k * p.ldk;
       float a = 0.f;
-      for (int d = 0; d < p.hd; d += 4) {
-        const float4 kk = *reinterpret_cast<const float4*>(kr + d);
-        a += qs[d] * kk.x + qs[d + 1] * kk.y + qs[d + 2] * kk.z + qs[d + 3] * kk.w;
+      if (p.vec4) {
+        for (int d = 0; d < p.hd; d += 4) {
+          const float4 kk = *reinterpret_cast<const float4*>(kr + d);
+          a += qs[d] * kk.x + qs[d + 1] * kk.y + qs[d + 2] * kk.z + qs[d + 3] * kk.w;
+        }
+      } else {  // head dim 46 (the legacy parseq-tiny: 368 / 8): rows are only 8 B aligned
+        for (int d = 0; d < p.hd; ++d) a += qs[d] * kr[d];
       }
       sc = a;
     }
@@ -357,7 +370,7 @@ __global__ __launch_bounds__(64) void k_small_attn(SmallAttnP p) {
   sum = wave_sum(sum);
   __syncthreads();
   const float inv = 1.f / sum;
-  float* orow = p.o + (size_t)b * p.bso + (size_t)qi * p.ldo + h * p.hd;
+  float* orow = (p.qoff ? p.o + qrow0 * p.ldo : p.o + (size_t)b * p.bso) + (size_t)qi * p.ldo + h * p.hd;
   for (int d = lane; d < p.hd; d += 64) {
     float a = 0.f;
     for (int k = 0; k < Lk; ++k) a += prob[k] * vb[(size_t)k * p.ldv + d];
@@ -368,10 +381,11 @@ void small_attention(hipStream_t s, const float* q, const float* k, const float*
                      int hd, int ldq, int ldk, int ldv, int ldo, long bsq, long bsk, long bsv, long bso, float scale,
                      const unsigned char* mask_qk, int ld_mask, const unsigned char* kpm, int ld_kpm, const SeqTab* tab) {
   if (B == 0 || Lq == 0) return;
-  YMK_CHECK(Lk > 0 && Lk <= 1024 && hd <= 128 && hd % 4 == 0, "small attention: Lk <= 1024, hd <= 128");
+  YMK_CHECK(Lk > 0 && Lk <= 1024 && hd <= 128, "small attention: Lk <= 1024, hd <= 128");
+  const int vec4 = hd % 4 == 0 && ldk % 4 == 0 && bsk % 4 == 0 && ((uintptr_t)k & 15) == 0;
   SmallAttnP p{q, k, v, o, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, Lq, Lk, H, hd, scale, mask_qk, ld_mask, kpm, ld_kpm,
-               tab ? tab->koff : nullptr, tab ? tab->klen : nullptr};
-  YMK_CHECK(!tab || (!tab->qoff && !mask_qk && !kpm), "small attention: ragged keys only, without masks");
+               tab ? tab->koff : nullptr, tab ? tab->klen : nullptr, tab ? tab->qoff : nullptr, tab ? tab->qlen : nullptr, vec4};
+  YMK_CHECK(!tab || (!mask_qk && !kpm), "small attention: ragged batches come without masks");
   hipLaunchKernelGGL(k_small_attn, dim3(Lq, H, B), dim3(64), 0, s, p);
   YMK_HIP(hipGetLastError());
 }

@@ -33,7 +33,8 @@ def resize_shortest_edge_dims(h: int, w: int, shortest_edge_length: int, max_len
 
 
 def page_to_device(img: np.ndarray, device) -> torch.Tensor:
-    """uint8 H x W x 3 BGR page -> contiguous device tensor (one H2D copy per page)."""
+    """uint8 H x W x 3 BGR page -> contiguous device tensor (one H2D copy per page, from pageable memory: the
+    synchronous form.  yomitoku_amd.data.PageStager is the pinned, asynchronous one for streams of pages)."""
     if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
         raise ValueError("page must be a uint8 H x W x 3 BGR array")
     return torch.from_numpy(np.ascontiguousarray(img)).to(device, non_blocking=True)
@@ -90,18 +91,31 @@ def pil_bilinear_coeffs(in_size: int, out_size: int):
     return bounds, coefs, ksize
 
 
+# Coefficient tables on the device, per (sizes, device, STREAM): a table is allocated and uploaded on the stream that
+# first needs it and only ever used by kernels queued on that same stream, so the caching allocator's stream-ordered
+# reuse rules hold without record_stream; each stream's cache is a small LRU (table crops bring a new (width, 640)
+# pair per table).
 _COEF_CACHE = {}
+_COEF_CACHE_LIMIT = 512
+_COEF_LOCK = __import__("threading").Lock()
 
 
 def _coeffs_on_device(in_size, out_size, device):
-    key = (in_size, out_size, str(device))
-    hit = _COEF_CACHE.get(key)
-    if hit is None:
-        b, c, k = pil_bilinear_coeffs(in_size, out_size)
-        hit = (torch.from_numpy(b).to(device), torch.from_numpy(c).to(device), k)
-        if len(_COEF_CACHE) > 256:
-            _COEF_CACHE.clear()
-        _COEF_CACHE[key] = hit
+    from collections import OrderedDict
+
+    stream = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
+    with _COEF_LOCK:
+        cache = _COEF_CACHE.setdefault((str(device), stream), OrderedDict())
+        hit = cache.get((in_size, out_size))
+        if hit is not None:
+            cache.move_to_end((in_size, out_size))
+            return hit
+    b, c, k = pil_bilinear_coeffs(in_size, out_size)
+    hit = (torch.from_numpy(b).to(device), torch.from_numpy(c).to(device), k)
+    with _COEF_LOCK:
+        cache[(in_size, out_size)] = hit
+        while len(cache) > _COEF_CACHE_LIMIT:
+            cache.popitem(last=False)  # least recently used; its last kernel was queued on this stream before any reuse
     return hit
 
 
@@ -217,9 +231,16 @@ def plan_crops(shape_hw, quads, img_size=(32, 800), dynamic_width=False, align=8
     rel = q - np.stack([bx, by], axis=1)[:, None, :]
     width = np.sqrt(((rel[:, 0] - rel[:, 1]) ** 2).sum(1).astype(np.float64)).astype(np.int64)
     height = np.sqrt(((rel[:, 1] - rel[:, 2]) ** 2).sum(1).astype(np.float64)).astype(np.int64)
-    bad = (width <= 0) | (height <= 0)
-    if bad.any():
-        raise ValueError(f"degenerate text quad {quads[shaped[int(np.flatnonzero(bad)[0])]]}")
+    ok = (width > 0) & (height > 0)
+    if not ok.all():
+        # a quad whose first or second edge is shorter than one pixel: the reference hands OpenCV an empty dsize there
+        # (the output is then whatever warpPerspective makes of a singular transform); here such a quad is dropped like
+        # one that fails validate_quads, instead of aborting the page
+        shaped = [i for i, keep in zip(shaped, ok.tolist()) if keep]
+        q, bx, by, bx2, by2, rel, width, height = q[ok], bx[ok], by[ok], bx2[ok], by2[ok], rel[ok], width[ok], height[ok]
+        m = len(shaped)
+        if m == 0:
+            return plans
     # cv2.getPerspectiveTransform(rel -> [[0,0],[w,0],[w,h],[0,h]]) for every quad
     x, y = rel[:, :, 0].astype(np.float64), rel[:, :, 1].astype(np.float64)
     wf, hf = width.astype(np.float64), height.astype(np.float64)
@@ -274,8 +295,9 @@ def _plan_crops_scalar(shape_hw, quads, img_size=(32, 800), dynamic_width=False,
         rel[:, 1] -= by
         width = int(np.linalg.norm(rel[0] - rel[1]))
         height = int(np.linalg.norm(rel[1] - rel[2]))
-        if width <= 0 or height <= 0:
-            raise ValueError(f"degenerate text quad {quad}")
+        if width <= 0 or height <= 0:  # dropped, like a quad that fails validation (see plan_crops)
+            plans.append(None)
+            continue
         M = perspective_matrix(np.float32(rel), np.float32([[0, 0], [width, 0], [width, height], [0, height]]))
         minv = np.linalg.inv(M)
         rot = 1 if height > 2 * width else 0

@@ -97,6 +97,27 @@ class DocumentAnalyzerSchema(BaseSchema):
     words: List[WordPrediction]
     figures: List[FigureSchema]
 
+    # exporters (reference schemas/document_analyzer.py:221-231 -> export/*.py)
+    def to_html(self, out_path: str, **kwargs):
+        from .export import export_html
+
+        return export_html(self, out_path, **kwargs)
+
+    def to_markdown(self, out_path: str, **kwargs):
+        from .export import export_markdown
+
+        return export_markdown(self, out_path, **kwargs)
+
+    def to_csv(self, out_path: str, **kwargs):
+        from .export import export_csv
+
+        return export_csv(self, out_path, **kwargs)
+
+    def to_json(self, out_path: str, **kwargs):
+        from .export import export_json
+
+        return export_json(self, out_path, **kwargs)
+
 
 class TextRecognizerSchema(BaseSchema):
     contents: List[str]
