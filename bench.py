@@ -2,7 +2,7 @@
 """Benchmark of the MI355X DocumentAnalyzer hot path (contract: task prompt / DESIGN.md §8).
 
     python bench.py --gpus N --steps K --warmup W [--workload analyzer|detector|recognizer] [--model-set lite|default]
-                    [--pages 64] [--wave 8] [--workers 2] [--procs 1]
+                    [--pages 64] [--wave 8] [--workers 2] [--procs 2]
 
 One rank per GPU.  Under torchrun the rank comes from the environment; `python bench.py --gpus N` without one
 spawns its own N ranks (same protocol: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  A "step" is one pass of the hot
@@ -424,7 +424,7 @@ def main():
     ap.add_argument("--total-pages", type=int, default=0, help="strong scaling (configs[4]: 512): pages per step over ALL GPUs")
     ap.add_argument("--wave", type=int, default=8, help="pages per device batch (analyzer workload)")
     ap.add_argument("--workers", type=int, default=2, help="waves in flight per process (analyzer workload)")
-    ap.add_argument("--procs", type=int, default=1, help="processes per GPU (analyzer workload): each has its own interpreter/GIL")
+    ap.add_argument("--procs", type=int, default=2, help="processes per GPU (analyzer workload): each has its own interpreter/GIL")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true",
                     help="skip the timed region: only the serial roofline pass (the command profiles/ runs under rocprofv3)")

@@ -44,6 +44,12 @@ def run(shape, variant, reps=REPS):
     g = torch.Generator(device="cpu").manual_seed(1)
     x = torch.randn(n, h, w, cin, generator=g).to(dev)
     wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).contiguous()
+    data = os.environ.get("DATA", "random")  # "zeros" / "relu": how much of the rate is the chip's power management
+    if data == "zeros":
+        x.zero_()
+        wt.zero_()
+    elif data == "relu":
+        x.clamp_(min=0)
     sc = torch.rand(cout, generator=g).add_(0.5).contiguous()
     bi = torch.randn(cout, generator=g).contiguous()
     oh = (h + 2 * pad - dil * (k - 1) - 1) // stride + 1

@@ -95,6 +95,10 @@ struct ConvArgs {
   int epi = EPI_STORE;
   const Tensor* res = nullptr;  // residual added before the activation ...
   bool res_post = false;        // ... or after it (y = res + act(conv))
+  // GEMM rows that may be skipped (grouped PARSeq greedy loop): output row m belongs to group row_group[m]; an M tile
+  // all of whose rows sit in groups with group_open[g] == 0 is not computed (its outputs keep their old contents)
+  const int* row_group = nullptr;
+  const int* group_open = nullptr;
 };
 
 // out must be pre-shaped (n, oh, ow, cout[, ld]); for EPI_DECONV2X2 out is (n, 2h, 2w, cout/4).
@@ -103,7 +107,7 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
 // Row-major GEMM view of the same kernel: out[m][:] = act(A[m][:] . W^T * scale + bias + res[m][:]).
 // `res_ld == 0` broadcasts one residual row to every m.
 void gemm(hipStream_t s, const float* A, int M, int K, int lda, const ConvW& w, int act, const float* res, int res_ld,
-          float* out, int out_ld);
+          float* out, int out_ld, const int* row_group = nullptr, const int* group_open = nullptr);
 
 // Host-side packing: OIHW fp32 -> panel. `cin_pad4` packs for the tap4 mode (cin<=4).
 void pack_conv_weight(const float* oihw, int cout, int cin, int kh, int kw, bool tap4,

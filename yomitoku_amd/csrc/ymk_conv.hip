@@ -51,7 +51,21 @@ struct ConvK {
   int ntiles_n;
   unsigned in_bytes;  // extent of the input view (buffer descriptor range)
   int vec;      // 1: Cout, leading dims and pointers allow 16 B epilogue accesses
+  const int* row_group;   // optional (ConvArgs): row m -> group id ...
+  const int* group_open;  // ... and the per-group "still needed" word; M tiles without a needed row return at once
 };
+
+// true when some row of the block's M tile [m0, m0 + BM) is still needed (or no row predicate was given); block-uniform
+template <int BM, int NT>
+__device__ __forceinline__ bool tile_needed(const ConvK& p, int m0, int t) {
+  if (!p.row_group) return true;
+  int live = 0;
+  for (int r = t; r < BM; r += NT) {
+    const int m = m0 + r;
+    if (m < p.M && p.group_open[p.row_group[m]] != 0) live = 1;
+  }
+  return __syncthreads_or(live) != 0;
+}
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
@@ -174,6 +188,7 @@ __global__ __launch_bounds__(64 * WM * WN, (2 * (BM + BN) * LDK * 4 <= 80 * 1024
   }
   const int tile_m = tile / p.ntiles_n, tile_n = tile - tile_m * p.ntiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (!tile_needed<BM, NT>(p, m0, t)) return;
 
   // ---- staging coordinates: thread loads 16 B (4 k) of row (t>>3)+32*i
   const int colq = t & 7, rowb = t >> 3;
@@ -384,6 +399,7 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk(ConvK p) {
   }
   const int tile_m = tile / p.ntiles_n, tile_n = tile - tile_m * p.ntiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (!tile_needed<BM, NT>(p, m0, t)) return;
 
   int pixb[TM], ih0[TM], iw0[TM];
 #pragma unroll
@@ -717,6 +733,9 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
   k.M = in.n * k.OH * k.OW;
   k.act = a.act;
   k.epi = a.epi;
+  k.row_group = a.row_group;
+  k.group_open = a.group_open;
+  YMK_CHECK((a.row_group == nullptr) == (a.group_open == nullptr), "conv: row_group and group_open come together");
   YMK_CHECK(w.w != nullptr, "conv weight not packed");
   if (w.mode == 0) {
     YMK_CHECK(in.c == w.cin, "conv: input channels " + std::to_string(in.c) + " != weight cin " + std::to_string(w.cin));
@@ -772,7 +791,7 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
 }
 
 void gemm(hipStream_t s, const float* A, int M, int K, int lda, const ConvW& w, int act, const float* res, int res_ld,
-          float* out, int out_ld) {
+          float* out, int out_ld, const int* row_group, const int* group_open) {
   YMK_CHECK(K == w.cin, "gemm: K " + std::to_string(K) + " != weight in-features " + std::to_string(w.cin));
   Tensor in{const_cast<float*>(A), 1, 1, M, K, lda};
   Tensor o{out, 1, 1, M, w.cout, out_ld};
@@ -780,6 +799,8 @@ void gemm(hipStream_t s, const float* A, int M, int K, int lda, const ConvW& w, 
   ConvArgs a;
   a.act = act;
   a.res = res ? &r : nullptr;
+  a.row_group = row_group;
+  a.group_open = group_open;
   conv2d(s, in, w, a, o);
 }
 

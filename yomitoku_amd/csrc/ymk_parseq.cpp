@@ -394,7 +394,9 @@ class ParseqModel : public Model {
         DecStepW w = fw_;
         w.qsa = qsa;
         parseq_dec_step(s, w, tok, NS, i, skv, NS, memkv, L, mem_tab.koff, mem_tab.klen, t1, prev, B, gid, gop, ng);
-        gemm(s, t1, B, D, D, head_, ACT_NONE, nullptr, 0, arlog + (size_t)i * C, NS * C);
+        // the vocabulary head skips the M tiles whose rows all sit in mini-batches that finished at an earlier step
+        const int* open_prev = (gop && i > 0) ? gop + (size_t)(i - 1) * ng : nullptr;
+        gemm(s, t1, B, D, D, head_, ACT_NONE, nullptr, 0, arlog + (size_t)i * C, NS * C, open_prev ? gid : nullptr, open_prev);
       } else {
         // content row i (token tok[:, i]) -> norm_c -> K|V cache row i
         ctx_embed_ln(s, tok, NS, i, 1, emb_, posq_, ncg_, ncb_, 1e-5f, cn, NS, D, B);

@@ -202,8 +202,10 @@ __global__ __launch_bounds__(256, 1) void k_flash_attn(AttnP p) {
     if (tt + 1 < ntiles) load_kv((tt + 1) * KT);
     const float* Ks = lds + buf * (2 * KT * LDH);
     const float* Vs = Ks + KT * LDH;
+    // a wave whose 32 queries all lie past the sample's last query still stages K / V and meets the barriers, but
+    // skips the products (ragged batches: the last 128-query block of a sample is mostly such waves)
 #pragma unroll
-    for (int sub = 0; sub < KT / 32; ++sub) {
+    for (int sub = 0; sub < (q0 < Lq ? KT / 32 : 0); ++sub) {
       const int kbase = tt * KT + sub * 32;
       if (kbase >= Lk) break;  // wave-uniform
       // ---- S^T[key][q] for 32 keys x 32 queries
