@@ -1,0 +1,12 @@
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+O=gpurun_out/r02p; rm -rf $O; mkdir -p $O
+B="python bench.py --roofline-only --procs 1 --workers 1 --no-cpu-baseline"
+timeout 500 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $B > $O/line_kt.json 2> $O/kt.log || tail -5 $O/kt.log
+timeout 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o f -- $B > $O/line_f.json 2> $O/f.log || tail -5 $O/f.log
+timeout 500 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -o w -- $B > $O/line_w.json 2> $O/w.log || tail -5 $O/w.log
+python tools/roofline_crosscheck.py $O/line_kt.json $O/kt $O/crosscheck.json $O/fetch $O/write $O/traffic.json
+python tools/pmc_aggregate.py sum $O/fetch $O/fetch_by_kernel.csv; python tools/pmc_aggregate.py sum $O/write $O/write_by_kernel.csv
+find $O -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
+find $O -name "*_kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete
+du -sh $O
+timeout 1200 python -m pytest tests -m gpu -q -x 2>&1 | tail -8

@@ -1,0 +1,80 @@
+"""Sum rocprofv3 PMC counters per kernel name, and derive the conv kernels' HBM bytes per launch.
+
+    python tools/pmc_aggregate.py sum <rocprof_out_dir> <out.csv>
+        every *counter_collection.csv under the directory -> one row per (kernel, counter): dispatch rows and the sum
+
+    python tools/pmc_aggregate.py traffic <fetch.csv> <write.csv> <out.json> "<command the passes profiled>"
+        the two per-kernel files of separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes -> the JSON bench.py reads as
+        `roofline.traffic` (profiles/r02_<workload>_pmc_conv_traffic.json).  Units and the gfx950 correction follow
+        /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KB; FETCH_SIZE tallies a wide coalesced
+        read at half its bytes, so it is doubled; WRITE_SIZE is taken as reported.
+"""
+
+from __future__ import annotations
+
+import csv
+import json
+import os
+import sys
+from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _rocprof_io import counter_rows  # noqa: E402
+
+CONV = ("ymk::conv_igemm<", "ymk::conv_splitk<")
+
+
+def _sum(out_dir, dst):
+    acc = defaultdict(lambda: [0, 0.0])
+    for row in counter_rows(out_dir):
+        key = (row["Kernel_Name"], row["Counter_Name"])
+        acc[key][0] += 1
+        acc[key][1] += float(row["Counter_Value"])
+    with open(dst, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "counter", "dispatch_rows", "sum"])
+        for (kernel, counter), (n, total) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+            w.writerow([kernel, counter, n, round(total, 1)])
+    print(f"{dst}: {len(acc)} (kernel, counter) rows")
+
+
+def _conv_rows(path, counter):
+    rows, total = 0, 0.0
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if row["counter"] == counter and any(tag in row["kernel"] for tag in CONV):
+                rows += int(row["dispatch_rows"])
+                total += float(row["sum"])
+    return rows, total
+
+
+def _traffic(fetch_csv, write_csv, dst, command):
+    n_f, fetch_kb = _conv_rows(fetch_csv, "FETCH_SIZE")
+    n_w, write_kb = _conv_rows(write_csv, "WRITE_SIZE")
+    if n_f == 0 or n_w == 0:
+        raise SystemExit("no conv kernel rows in the PMC files")
+    fetch = fetch_kb * 1024.0 / n_f
+    write = write_kb * 1024.0 / n_w
+    out = {
+        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- {command}",
+        "kernels": "conv_igemm<*> + conv_splitk<*>",
+        "launches": n_f,
+        "launches_write_pass": n_w,
+        "fetch_bytes_per_launch_as_reported": round(fetch),
+        "write_bytes_per_launch": round(write),
+        "hbm_bytes_per_launch": round(2.0 * fetch + write),
+        "note": "FETCH_SIZE doubled per the guide's gfx950 correction for wide coalesced reads (MI355X_MICROARCH.md, HBM section); "
+                "WRITE_SIZE as reported; per-XCD rows of one dispatch are summed before the division by dispatches",
+    }
+    with open(dst, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) >= 4 and sys.argv[1] == "sum":
+        _sum(sys.argv[2], sys.argv[3])
+    elif len(sys.argv) >= 6 and sys.argv[1] == "traffic":
+        _traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
+    else:
+        raise SystemExit(__doc__)

@@ -1,0 +1,106 @@
+"""Cross-check bench.py's live HIP-event roofline against rocprofv3 of the same command.
+
+    rocprofv3 --kernel-trace --stats -d DIR -o kt -- python bench.py --roofline-only --procs 1 --workers 1 > line.json
+    python tools/roofline_crosscheck.py line.json DIR out.json [FETCH_DIR WRITE_DIR traffic.json]
+
+`bench.py --roofline-only` runs, in this order: the serial pass once untimed (shapes seen once), the SAME serial pass
+with a HIP event pair around every conv launch (L launches: `launches_per_page` x pages of the pass), then one DBNet
+forward.  The conv dispatches of the kernel trace therefore END with [L warm][L timed][DBNet]; this script takes the
+timed block and compares its average duration with the live `avg_launch_us`.  With the two PMC directories (separate
+`--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of the same command) it also writes the HBM bytes per launch of the same
+block, corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes (KB units; FETCH_SIZE doubled on gfx950).
+"""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _rocprof_io import counter_rows, kernel_rows  # noqa: E402
+
+CONV = ("ymk::conv_igemm<", "ymk::conv_splitk<")
+
+
+def _is_conv(name):
+    return any(tag in name for tag in CONV)
+
+
+def _timed_block(rows, launches, tail):
+    """The conv dispatches of the timed serial pass: the `launches` before the last `tail` (the closing DBNet forward).
+    Counted from the END of the trace, because model set-up (bias calibration forwards) also launches convs."""
+    conv = [r for r in rows if _is_conv(r["Kernel_Name"])]
+    if len(conv) < 2 * launches + tail:
+        raise SystemExit(f"{len(conv)} conv dispatches in the trace, expected at least {2 * launches + tail}")
+    return conv[len(conv) - tail - launches: len(conv) - tail], len(conv)
+
+
+def _counter_block(pmc_dir, counter, launches, tail):
+    rows = [r for r in counter_rows(pmc_dir) if r["Counter_Name"] == counter]
+    block, total = _timed_block(rows, launches, tail)
+    return sum(float(r["Counter_Value"]) for r in block) * 1024.0 / len(block), total
+
+
+def main(argv):
+    line_path, kt_dir, out_path = argv[1:4]
+    with open(line_path) as f:
+        line = json.loads([ln for ln in f.read().splitlines() if ln.startswith("{")][-1])
+    roof = line["roofline"]
+    pages = 16  # bench.py: prof_waves = waves[:max(1, 16 // wave)]
+    if "launches_per_page" not in roof:
+        raise SystemExit("not an analyzer/detector roofline line")
+    launches = int(round(roof["launches_per_page"] * pages))
+    db = roof.get("dbnet_conv")
+    tail = int(round(db["launches_per_page"] * db["batch"])) if db else 0
+    rows = kernel_rows(kt_dir)
+    block, total = _timed_block(rows, launches, tail)
+    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in block]
+    by_kernel = {}
+    for r, d in zip(block, dur):
+        k = by_kernel.setdefault(r["Kernel_Name"], [0, 0])
+        k[0] += 1
+        k[1] += d
+    span = int(block[-1]["End_Timestamp"]) - int(block[0]["Start_Timestamp"])
+    in_span = [r for r in rows if int(block[0]["Start_Timestamp"]) <= int(r["Start_Timestamp"]) <= int(block[-1]["End_Timestamp"])]
+    all_kernels_ns = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in in_span)
+    out = {
+        "command": "rocprofv3 --kernel-trace --stats -- python bench.py --roofline-only --procs 1 --workers 1",
+        "conv_dispatches_in_trace": total, "timed_block_launches": launches, "pages_in_block": pages,
+        "rocprof_avg_launch_us": round(sum(dur) / len(dur) / 1e3, 2), "bench_avg_launch_us": roof["avg_launch_us"],
+        "rocprof_conv_ms_per_page": round(sum(dur) / 1e6 / pages, 4), "bench_kernel_ms_per_page": roof["kernel_ms_per_page"],
+        "rocprof_tflops": round(roof["gflop_per_page"] * pages / (sum(dur) / 1e9) / 1e3, 2), "bench_tflops": roof["achieved"],
+        "all_kernels_ms_per_page_in_block": round(all_kernels_ns / 1e6 / pages, 4),
+        "conv_share_of_gpu_time_in_block": round(sum(dur) / all_kernels_ns, 4),
+        "block_span_ms_per_page": round(span / 1e6 / pages, 4),
+        "per_kernel_in_block": {k: {"calls": c, "total_ms": round(t / 1e6, 3), "avg_us": round(t / c / 1e3, 2)}
+                                for k, (c, t) in sorted(by_kernel.items(), key=lambda kv: -kv[1][1])},
+    }
+    ratio = out["rocprof_avg_launch_us"] / out["bench_avg_launch_us"]
+    out["rocprof_over_bench"] = round(ratio, 4)
+    with open(out_path, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k != "per_kernel_in_block"}))
+    if len(argv) >= 7:
+        fetch, n_f = _counter_block(argv[4], "FETCH_SIZE", launches, tail)
+        write, n_w = _counter_block(argv[5], "WRITE_SIZE", launches, tail)
+        traffic = {
+            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --roofline-only "
+                      "--procs 1 --workers 1; conv dispatches of the timed serial pass only",
+            "kernels": "conv_igemm<*> + conv_splitk<*>", "launches": launches,
+            "conv_dispatches_in_fetch_pass": n_f, "conv_dispatches_in_write_pass": n_w,
+            "fetch_bytes_per_launch_as_reported": round(fetch), "write_bytes_per_launch": round(write),
+            "hbm_bytes_per_launch": round(2.0 * fetch + write),
+            "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"],
+            "note": "FETCH_SIZE doubled per the guide's gfx950 correction for wide coalesced reads (MI355X_MICROARCH.md, HBM section); "
+                    "WRITE_SIZE as reported (uncalibrated per the guide)",
+        }
+        with open(argv[6], "w") as f:
+            json.dump(traffic, f, indent=1)
+        print(json.dumps(traffic))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) not in (4, 7):
+        raise SystemExit(__doc__)
+    main(sys.argv)
