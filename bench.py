@@ -256,12 +256,13 @@ def _helper_init(local_rank, sds, shares, workers, wave, model_set, index):
     pool.map(waves[:workers])  # first-call allocations happen before the parent starts its clock
     device_sync()
 
-    def step(_payload):
-        pool.map(waves)
+    def run_steps(k):  # k steps back to back: the pool keeps `workers` waves in flight across the step boundaries
+        k = int(k or 1)
+        pool.map(waves * k)
         device_sync()
-        return len(pages)
+        return len(pages) * k
 
-    return step
+    return run_steps
 
 
 def make_pages(seeds, device):
@@ -494,14 +495,20 @@ def main():
         pool = PageParallel(lambda i: build_analyzer(device, sds, args.model_set), n_workers=args.workers)
         waves = make_waves(pages, args.wave)
 
-        def step():  # every process of the rank walks its share of the rank's pages; the step ends when all have
+        def run_steps(k):
+            """k steps (k passes over the rank's pages) as ONE streaming job: every process of the rank walks its share
+            k times and keeps `workers` waves in flight across the step boundaries (no drain between steps); returns
+            when all processes have finished all k passes."""
             if helpers:
-                helpers.start([None] * len(helpers))
-            out = pool.map(waves)[-1]
+                helpers.start([k] * len(helpers))
+            out = pool.map(waves * k)[-1]
             device_sync()
             if helpers:
-                assert sum(helpers.finish()) + len(pages) == len(seeds)
+                assert sum(helpers.finish()) + len(pages) * k == len(seeds) * k
             return out
+
+        def step():
+            return run_steps(1)
 
         names = {"lite": "DBNet dbnetv2_1 + PARSeq parseq-tiny-dynw-v4 (dynamic_width, batch_bucketing, source_downscale)",
                  "default": "DBNet dbnetv2_1 + PARSeq parseq-large-v4_1 (fixed 800 px canvas, batch_size 128 per page)"}
@@ -509,7 +516,8 @@ def main():
         workload = (f"Full DocumentAnalyzer (BASELINE.json configs[{4 if args.total_pages else 3}]): {names[args.model_set]} + RT-DETRv2 layout + "
                     f"RT-DETRv2 table structure + host post-processing and aggregation, through DocumentAnalyzer.analyze_pages; "
                     f"{len(seeds)} synthetic 1600x1200 pages per step on this GPU, in waves of {args.wave} pages (device batches "
-                    f"across the pages of a wave), {n_procs} process(es) x {args.workers} waves in flight; stage hand-overs use ground "
+                    f"across the pages of a wave), {n_procs} process(es) x {args.workers} waves in flight, the K steps of the timed region "
+                    f"streamed back to back (waves of step k+1 start while the last waves of step k finish); stage hand-overs use ground "
                     f"truth ({np.mean([len(p.quads) for p in pages]):.0f} text lines, {np.mean([len(p.tables) for p in pages]):.1f} tables, "
                     f"{np.mean([len(p.paragraphs) for p in pages]):.0f} paragraphs per page) and the DB box extraction runs on a map "
                     f"rendered from the true lines, because seeded random weights detect noise")
@@ -522,21 +530,26 @@ def main():
         def step():
             return net(x)["binary"]
 
+        def run_steps(k):
+            out = None
+            for _ in range(k):
+                out = step()
+            return out
+
         metric = "pages/sec (TextDetector DBNet forward @1600x1200 -> 3x1600x1184)"
         workload = f"TextDetector DBNet forward alone, batch={args.pages} synthetic 1600x1200 pages per GPU (BASELINE.json configs[1])"
 
     dt = None
     out = None
     if not args.roofline_only:
-        for _ in range(args.warmup):
-            step()
+        if args.warmup:
+            run_steps(args.warmup)
         device_sync()
         if world > 1:
             torch.distributed.barrier()
         device_sync()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
+        out = run_steps(args.steps)  # exactly K steps; the analyzer's follow each other without a drain (streaming job)
         device_sync()
         if world > 1:
             torch.distributed.barrier()

@@ -208,3 +208,43 @@ def test_legacy_parseq_tiny_geometry_head_dim_46(dev):
         got = logits[row : row + x.shape[0], :n].cpu()
         assert st == ref_steps and torch.equal(got.argmax(-1), ref.argmax(-1)) and (got - ref).abs().max().item() < LOGIT_TOL
         row += x.shape[0]
+
+
+@pytest.mark.parametrize("refine", [1, 0])
+def test_fused_step_rows_per_block_agree_bit_for_bit(dev, refine):
+    """The fused greedy step for 2 / 4 samples per block (forwards with more rows than resident blocks) against the
+    one-sample-per-block kernel: same chain of operations per value, so logits, tokens and step counts must be identical
+    bits - including groups that finish early (frozen rows inside a live block), a row count that is no multiple of 4,
+    and refine_iters = 0 (the AR logits themselves are the output)."""
+    from yomitoku_amd import _lib
+    from yomitoku_amd.utils.synth import parseq_state_dict
+
+    sd = parseq_state_dict(1235, eos_bias=5.5)
+    _, net = _net(dev, sd, refine_iters=refine)
+    xs = [x.to(dev) for x in _groups(23, [(7, 160), (3, 800), (9, 72), (1, 96), (6, 320), (5, 64)])]
+    outs = {}
+    try:
+        for rows in (1, 2, 4):
+            _lib.debug_option("dec_rows", rows)
+            logits, out_lens, steps = net.forward_groups(xs)
+            outs[rows] = (logits.cpu(), list(out_lens), list(steps))
+    finally:
+        _lib.debug_option("dec_rows", 0)
+    assert len(set(outs[1][2])) > 1, "the groups should stop at different steps (frozen rows next to live ones)"
+    for rows in (2, 4):
+        assert outs[rows][1] == outs[1][1] and outs[rows][2] == outs[1][2]
+        row = 0
+        for x, n in zip(xs, outs[1][1]):  # positions past a group's out_len are not part of the result
+            a, b = outs[rows][0][row : row + x.shape[0], :n], outs[1][0][row : row + x.shape[0], :n]
+            assert torch.equal(a, b), f"{rows} rows per block differ from the one-row kernel"
+            row += x.shape[0]
+    # a single mini-batch (no group tables): rows per block on the plain entry point
+    x = xs[0]
+    try:
+        _lib.debug_option("dec_rows", 1)
+        one = net(x).cpu()
+        _lib.debug_option("dec_rows", 4)
+        four = net(x).cpu()
+    finally:
+        _lib.debug_option("dec_rows", 0)
+    assert torch.equal(one, four)  # nets.PARSeq.forward returns logits[:, :out_len]

@@ -19,6 +19,7 @@ void prof_end(double* ms, double* flop, int64_t* launches);
 double prof_bytes();
 bool conv_debug_option(const std::string& key, int value);
 bool parseq_debug_option(const std::string& key, int value);
+bool decstep_debug_option(const std::string& key, int value);
 }  // namespace ymk
 
 struct ymk_model {
@@ -158,7 +159,7 @@ int ymk_debug_option(const char* key, int value) {
   YMK_API_BEGIN
   YMK_CHECK(key != nullptr, "null key");
   const std::string k(key);
-  YMK_CHECK(ymk::conv_debug_option(k, value) || ymk::parseq_debug_option(k, value), "unknown debug option: " + k);
+  YMK_CHECK(ymk::conv_debug_option(k, value) || ymk::parseq_debug_option(k, value) || ymk::decstep_debug_option(k, value), "unknown debug option: " + k);
   YMK_API_END
 }
 

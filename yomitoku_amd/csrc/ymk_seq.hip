@@ -442,6 +442,77 @@ void ctx_embed_ln(hipStream_t s, const int* tok, int ld_tok, int pos0, int npos,
   YMK_HIP(hipGetLastError());
 }
 
+// ---- one block of 256 threads reduces one row of C logits: arg-max (first maximal index, as torch.argmax) and, on
+// request, sum(exp(x - max)).  Thread t owns c = t, t + 256, ...; rows of up to 256 * ROW_RV values are held in
+// registers, so all of a thread's loads are in flight together (a greedy step is a chain of such reductions: 28
+// dependent L2 round trips per row otherwise) and the softmax sum needs no second pass over memory.  The per-thread
+// order and the LDS tree are the same on both paths, so the results do not depend on which one ran.
+constexpr int ROW_RV = 32;
+template <bool WITH_SUM>
+__device__ __forceinline__ void row_reduce_256(const float* __restrict__ row, int C, float* sv, int* si, float& mx, int& am,
+                                               float& sum) {
+  const int t = threadIdx.x;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  float v[ROW_RV];
+  const bool in_regs = C <= 256 * ROW_RV;
+  if (in_regs) {
+#pragma unroll
+    for (int i = 0; i < ROW_RV; ++i) {
+      const int c = t + 256 * i;
+      v[i] = c < C ? row[c] : -INFINITY;
+    }
+#pragma unroll
+    for (int i = 0; i < ROW_RV; ++i)
+      if (v[i] > best) {  // strict: keeps the lowest index among equal values within a thread
+        best = v[i];
+        bi = t + 256 * i;
+      }
+  } else {
+    for (int c = t; c < C; c += 256) {
+      const float x = row[c];
+      if (x > best) {
+        best = x;
+        bi = c;
+      }
+    }
+  }
+  sv[t] = best;
+  si[t] = bi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) {
+      const float v2 = sv[t + o];
+      const int i2 = si[t + o];
+      if (v2 > sv[t] || (v2 == sv[t] && i2 < si[t])) {  // torch.argmax returns the first maximal index
+        sv[t] = v2;
+        si[t] = i2;
+      }
+    }
+    __syncthreads();
+  }
+  mx = sv[0];
+  am = si[0];
+  if (WITH_SUM) {
+    __syncthreads();
+    float acc = 0.f;
+    if (in_regs) {
+#pragma unroll
+      for (int i = 0; i < ROW_RV; ++i)
+        if (t + 256 * i < C) acc += expf(v[i] - mx);
+    } else {
+      for (int c = t; c < C; c += 256) acc += expf(row[c] - mx);
+    }
+    sv[t] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (t < o) sv[t] += sv[t + o];
+      __syncthreads();
+    }
+    sum = sv[0];
+  }
+}
+
 // greedy step (models/parseq.py:222-250): argmax over C of logits[b][step][:], write the raw argmax,
 // the context token for position step+1 (forced to <eos> when a repetition loop is detected), and the
 // per-sample flags; one block per sample.  state[b] = {has_eos, rep_done, rep_cut(-1 = none)}.
@@ -461,31 +532,10 @@ __global__ __launch_bounds__(256) void k_greedy_step(const float* __restrict__ l
   const bool frozen = gid && step > 0 && gopen[(size_t)(step - 1) * ng + g] == 0;
   __shared__ float sv[256];
   __shared__ int si[256];
-  if (!frozen) {
-    const float* row = logits + (size_t)b * ld_b;
-    float best = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int c = t; c < C; c += 256) {
-      const float v = row[c];
-      if (v > best) {  // strict: keeps the lowest index among equal values within a thread
-        best = v;
-        bi = c;
-      }
-    }
-    sv[t] = best;
-    si[t] = bi;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (t < o) {
-        const float v2 = sv[t + o];
-        const int i2 = si[t + o];
-        if (v2 > sv[t] || (v2 == sv[t] && i2 < si[t])) {  // torch.argmax returns the first maximal index
-          sv[t] = v2;
-          si[t] = i2;
-        }
-      }
-      __syncthreads();
-    }
+  if (!frozen) {  // block-uniform
+    float mx, unused;
+    int am;
+    row_reduce_256<false>(logits + (size_t)b * ld_b, C, sv, si, mx, am, unused);
   }
   if (t != 0) return;
   int* st = state + b * 4;
@@ -575,34 +625,12 @@ void refine_prep(hipStream_t s, const int* raw, int ld_tok, int S, int bos_id, i
 // raw[b][t] = argmax(logits[b][t][:]) for t < S (used between refinement iterations)
 __global__ __launch_bounds__(256) void k_row_argmax(const float* __restrict__ logits, int C, int* __restrict__ out) {
   const size_t rowi = blockIdx.x;
-  const int t = threadIdx.x;
-  const float* row = logits + rowi * C;
-  float best = -INFINITY;
-  int bi = 0x7fffffff;
-  for (int c = t; c < C; c += 256) {
-    const float v = row[c];
-    if (v > best) {
-      best = v;
-      bi = c;
-    }
-  }
   __shared__ float sv[256];
   __shared__ int si[256];
-  sv[t] = best;
-  si[t] = bi;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (t < o) {
-      const float v2 = sv[t + o];
-      const int i2 = si[t + o];
-      if (v2 > sv[t] || (v2 == sv[t] && i2 < si[t])) {
-        sv[t] = v2;
-        si[t] = i2;
-      }
-    }
-    __syncthreads();
-  }
-  if (t == 0) out[rowi] = si[0];
+  float mx, unused;
+  int am;
+  row_reduce_256<false>(logits + rowi * C, C, sv, si, mx, am, unused);
+  if (threadIdx.x == 0) out[rowi] = am;
 }
 void row_argmax(hipStream_t s, const float* logits, int rows, int C, int* out) {
   if (rows == 0) return;
@@ -628,47 +656,14 @@ void rep_cut(hipStream_t s, float* logits, long ld_b, int C, int S, const int* s
 __global__ __launch_bounds__(256) void k_row_maxprob(const float* __restrict__ logits, int C, int* __restrict__ ids,
                                                      float* __restrict__ probs) {
   const size_t rowi = blockIdx.x;
-  const int t = threadIdx.x;
-  const float* row = logits + rowi * C;
-  float best = -INFINITY;
-  int bi = 0x7fffffff;
-  for (int c = t; c < C; c += 256) {
-    const float v = row[c];
-    if (v > best) {
-      best = v;
-      bi = c;
-    }
-  }
   __shared__ float sv[256];
   __shared__ int si[256];
-  sv[t] = best;
-  si[t] = bi;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (t < o) {
-      const float v2 = sv[t + o];
-      const int i2 = si[t + o];
-      if (v2 > sv[t] || (v2 == sv[t] && i2 < si[t])) {
-        sv[t] = v2;
-        si[t] = i2;
-      }
-    }
-    __syncthreads();
-  }
-  const float mx = sv[0];
-  const int am = si[0];
-  __syncthreads();
-  float sum = 0.f;
-  for (int c = t; c < C; c += 256) sum += expf(row[c] - mx);
-  sv[t] = sum;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (t < o) sv[t] += sv[t + o];
-    __syncthreads();
-  }
-  if (t == 0) {
+  float mx, sum;
+  int am;
+  row_reduce_256<true>(logits + rowi * C, C, sv, si, mx, am, sum);
+  if (threadIdx.x == 0) {
     ids[rowi] = am;
-    probs[rowi] = 1.f / sv[0];
+    probs[rowi] = 1.f / sum;
   }
 }
 void row_maxprob(hipStream_t s, const float* logits, int rows, int C, int* ids, float* probs) {
