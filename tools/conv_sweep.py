@@ -33,7 +33,8 @@ SHAPES = [
     ("parseq proj 192->192 +res", 1, 1, 176496, 192, 192, 1, 1, 0, 1, 0, 1),
     ("parseq head 192->7119", 1, 1, 66155, 192, 7119, 1, 1, 0, 1, 0, 0),
 ]
-VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "0,1,2,3,4,5,6").split(",")]
+# "v" or "v/f": conv_variant v with conv_fast f (0: index divisions for 1x1 layers and no residual prefetch - the A/B baseline)
+VARIANTS = [v.strip() for v in os.environ.get("VARIANTS", "0,1,2,3,4,5,6").split(",")]
 if os.environ.get("ONLY"):  # substring filter on the shape names (PMC runs profile one or two shapes)
     SHAPES = [sh for sh in SHAPES if any(tok in sh[0] for tok in os.environ["ONLY"].split("|"))]
 REPS = int(os.environ.get("REPS", 5))
@@ -56,7 +57,9 @@ def run(shape, variant, reps=REPS):
     ow = (w + 2 * pad - dil * (k - 1) - 1) // stride + 1
     y = torch.empty(n, oh, ow, cout, device=dev)
     r = torch.randn(n, oh, ow, cout, generator=g).to(dev) if res else None
-    _lib.debug_option("conv_variant", variant)
+    vnum, _, fast = str(variant).partition("/")
+    _lib.debug_option("conv_variant", int(vnum))
+    _lib.debug_option("conv_fast", int(fast) if fast else 3)
     times = []
     for i in range(reps + 1):
         _lib.check(lib.ymk_prof_begin())
@@ -67,6 +70,7 @@ def run(shape, variant, reps=REPS):
         if i:
             times.append(ms.value)
     _lib.debug_option("conv_variant", 0)
+    _lib.debug_option("conv_fast", 3)
     t = float(np.median(times))
     return fl.value / (t * 1e-3) / 1e12, t * 1e3, float(y.flatten()[:4096].double().sum().item())
 

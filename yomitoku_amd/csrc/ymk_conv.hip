@@ -53,6 +53,7 @@ struct ConvK {
   int vec;      // 1: Cout, leading dims and pointers allow 16 B epilogue accesses
   const int* row_group;   // optional (ConvArgs): row m -> group id ...
   const int* group_open;  // ... and the per-group "still needed" word; M tiles without a needed row return at once
+  int fast;     // bit 0: pointwise index shortcut, bit 1: residual prefetch (both on; ymk_debug_option("conv_fast") for A/B runs)
 };
 
 // true when some row of the block's M tile [m0, m0 + BM) is still needed (or no row predicate was given); block-uniform
@@ -89,8 +90,29 @@ constexpr unsigned SPLITK_OOB_ROW = 0xC0000000u;  // conv_splitk: row base of a 
 
 // ---- epilogue over a block tile staged in LDS as Cs[BM][BN + 4]: scale/bias, residual (before or after
 // the activation), activation, plain or 2x2 pixel-shuffle store; NT threads, 16 B per lane, full rows coalesced.
+// rows a thread stores in epilogue_tile (row r0 + RPP * i, i < NR)
 template <int BM, int BN, int NT>
-__device__ __forceinline__ void epilogue_tile(const ConvK& p, const float* Cs, int m0, int n0, int t) {
+struct EpiRows {
+  static constexpr int TPR = BN / 4, RPP = NT / TPR, NR = (BM + RPP - 1) / RPP;
+};
+
+// the residual values of the thread's epilogue rows, fetched ahead of the last K tile's MFMAs (short-K layers: the
+// epilogue is a large share of the block's life, and its only long-latency operation is this read)
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void prefetch_residual(const ConvK& p, int m0, int n0, int t, float4* rr) {
+  using E = EpiRows<BM, BN, NT>;
+  const int c4 = t % E::TPR, r0 = t / E::TPR;
+  const int co = n0 + c4 * 4;
+#pragma unroll
+  for (int i = 0; i < E::NR; ++i) {
+    const int m = m0 + r0 + E::RPP * i;
+    rr[i] = (co < p.Cout && m < p.M && r0 + E::RPP * i < BM) ? *reinterpret_cast<const float4*>(p.res + (size_t)m * p.res_ld + co)
+                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+template <int BM, int BN, int NT, bool PRE = false>
+__device__ __forceinline__ void epilogue_tile(const ConvK& p, const float* Cs, int m0, int n0, int t, const float4* pre = nullptr) {
   constexpr int LDC = BN + 4;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   constexpr int TPR = BN / 4;        // threads per output row
@@ -109,10 +131,11 @@ __device__ __forceinline__ void epilogue_tile(const ConvK& p, const float* Cs, i
       ab = co / cq_n;
       cq = co - ab * cq_n;
     }
-#pragma unroll 4
-    for (int row = r0; row < BM; row += RPP) {
+#pragma unroll(PRE ? EpiRows<BM, BN, NT>::NR : 4)
+    for (int i = 0; i < EpiRows<BM, BN, NT>::NR; ++i) {
+      const int row = r0 + RPP * i;
       const int m = m0 + row;
-      if (m >= p.M) break;
+      if (row >= BM || m >= p.M) break;
       float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + c4 * 4);
       v.x = v.x * sc.x + bi.x;
       v.y = v.y * sc.y + bi.y;
@@ -122,7 +145,7 @@ __device__ __forceinline__ void epilogue_tile(const ConvK& p, const float* Cs, i
       float4 rr = zero4;
       if (p.epi == EPI_STORE) {
         if (p.res) {
-          rr = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.res_ld + co);
+          rr = PRE ? pre[i] : *reinterpret_cast<const float4*>(p.res + (size_t)m * p.res_ld + co);
           if (!p.res_post) {
             v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
           }
@@ -142,6 +165,7 @@ __device__ __forceinline__ void epilogue_tile(const ConvK& p, const float* Cs, i
         v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
       }
       *reinterpret_cast<float4*>(p.out + o) = v;
+      if (PRE) __builtin_amdgcn_sched_barrier(0);  // one row at a time: the 16-wave tiles have 64 registers per lane
     }
   } else {  // ragged Cout / unaligned rows: scalar stores (EPI_STORE only)
     for (int row = r0; row < BM; row += RPP) {
@@ -193,10 +217,16 @@ __global__ __launch_bounds__(64 * WM * WN, (2 * (BM + BN) * LDK * 4 <= 80 * 1024
   // ---- staging coordinates: thread loads 16 B (4 k) of row (t>>3)+32*i
   const int colq = t & 7, rowb = t >> 3;
   int pixb[APASS], ih0[APASS], iw0[APASS];
+  // 1x1, stride 1, no padding (every nn.Linear and most bottleneck convs): input pixel = output pixel = m, no divisions
+  const bool pointwise = (p.fast & 1) && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.stride_w == 1 && p.pad == 0;
 #pragma unroll
   for (int i = 0; i < APASS; ++i) {
     const int m = m0 + rowb + RPP * i;
-    if (m < p.M) {
+    if (m < p.M && pointwise) {
+      pixb[i] = m;
+      ih0[i] = 0;
+      iw0[i] = 0;
+    } else if (m < p.M) {
       const int ohw = p.OH * p.OW;
       const int n = m / ohw, rem = m - n * ohw;
       const int oh = rem / p.OW, ow = rem - oh * p.OW;
@@ -326,10 +356,15 @@ __global__ __launch_bounds__(64 * WM * WN, (2 * (BM + BN) * LDK * 4 <= 80 * 1024
   if (PF == 2 && ktiles > 1) load_tile(1, 1);
   __syncthreads();
 
+  using Epi = EpiRows<EROWS, BN, NT>;
+  constexpr bool CAN_PRE = PF == 1 && EROWS == BM && Epi::NR <= 8 && NT <= 512;  // the 16-wave tiles have no registers to spare
+  const bool pre_res = CAN_PRE && (p.fast & 2) && p.res != nullptr && p.vec && p.epi == EPI_STORE;  // block-uniform
+  float4 rpre[CAN_PRE ? Epi::NR : 1];
   if (PF == 1) {
     for (int kt = 0; kt < ktiles; ++kt) {
       const int buf = kt & 1;
       if (kt + 1 < ktiles) load_tile(kt + 1, 0);
+      if (CAN_PRE && kt + 1 == ktiles && pre_res) prefetch_residual<EROWS, BN, NT>(p, m0, n0, t, rpre);
       compute(buf);
       if (kt + 1 < ktiles) store_tile(buf ^ 1, 0);
       __syncthreads();
@@ -368,7 +403,8 @@ __global__ __launch_bounds__(64 * WM * WN, (2 * (BM + BN) * LDK * 4 <= 80 * 1024
           }
     }
     __syncthreads();
-    epilogue_tile<EROWS, BN, NT>(p, Cs, m0 + e0, n0, t);
+    if (CAN_PRE && pre_res) epilogue_tile<EROWS, BN, NT, true>(p, Cs, m0 + e0, n0, t, rpre);
+    else epilogue_tile<EROWS, BN, NT>(p, Cs, m0 + e0, n0, t);
   }
 }
 
@@ -402,10 +438,15 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk(ConvK p) {
   if (!tile_needed<BM, NT>(p, m0, t)) return;
 
   int pixb[TM], ih0[TM], iw0[TM];
+  const bool pointwise = (p.fast & 1) && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.stride_w == 1 && p.pad == 0;
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
     const int m = m0 + 32 * a + li;
-    if (m < p.M) {
+    if (m < p.M && pointwise) {
+      pixb[a] = m;
+      ih0[a] = 0;
+      iw0[a] = 0;
+    } else if (m < p.M) {
       const int ohw = p.OH * p.OW;
       const int n = m / ohw, rem = m - n * ohw;
       const int oh = rem / p.OW, ow = rem - oh * p.OW;
@@ -550,6 +591,7 @@ constexpr int SPLITK_MAX_GRID = 384;
 // test / measurement knobs (ymk_debug_option): process-wide, read per launch, never set on the product path
 static std::atomic<int> g_splitk_force{-1};  // >= 0: that split-K candidate for every eligible launch (kernel tests)
 static std::atomic<int> g_no_splitk{0};      // 1: every launch through conv_igemm (A/B profiling, kernel tests)
+static std::atomic<int> g_conv_fast{3};      // ConvK::fast
 static std::atomic<int> g_conv_variant{0};   // conv_igemm schedule selector for A/B runs, see launch_wide()
 static std::atomic<int> g_prof_dump{0};      // 1: ymk_prof_end prints one line per launch to stderr
 static int splitk_forced() { return g_splitk_force.load(std::memory_order_relaxed); }
@@ -558,6 +600,7 @@ bool conv_debug_option(const std::string& key, int value) {
   if (key == "splitk_force") g_splitk_force = value;
   else if (key == "no_splitk") g_no_splitk = value;
   else if (key == "conv_variant") g_conv_variant = value;
+  else if (key == "conv_fast") g_conv_fast = value;
   else if (key == "prof_dump") g_prof_dump = value;
   else return false;
   return true;
@@ -765,6 +808,7 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
             (!w.bias || al16(w.bias)) && (!a.res || (a.res->ld % 4 == 0 && al16(a.res->p)));
     if (a.epi == EPI_DECONV2X2) YMK_CHECK(k.vec, "deconv epilogue needs 16 B aligned channels");
   }
+  k.fast = g_conv_fast.load(std::memory_order_relaxed);
 
   // tile selection: wide tiles when there is enough work to fill 256 CUs x 2 blocks
   const long blocks128 = (long)((k.M + 127) / 128) * ((w.cout + 127) / 128);
