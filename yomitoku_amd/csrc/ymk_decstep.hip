@@ -297,11 +297,12 @@ __device__ void matvec_rows(const float* __restrict__ Wt, const float* __restric
 
 // LayerNorm of R LDS vectors, wave r takes row r (same arithmetic as block_ln)
 template <int R>
-__device__ void rows_ln(const float* x, const float* __restrict__ g, const float* __restrict__ b, float eps, float* y, int D) {
+__device__ void rows_ln(const float* x, const float* __restrict__ g, const float* __restrict__ b, float eps, float* y, int D,
+                        int rs /* floats between the rows of x and of y */) {
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (wv < R) {
-    const float* xr = x + wv * DMAX;
-    float* yr = y + wv * DMAX;
+    const float* xr = x + wv * rs;
+    float* yr = y + wv * rs;
     float v[4], s = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -329,7 +330,7 @@ __device__ void rows_ln(const float* x, const float* __restrict__ g, const float
 // n = key rows of THIS wave's row (0 for a row that takes no part); base = its K|V rows.
 template <int R>
 __device__ void attend_rows(float4 qv, const float* __restrict__ base, size_t stride, int n, int D, int H, float* sc_all,
-                            int lcap, float* red_all, float* pv_all, float* y_all) {
+                            int lcap, float* red_all, float* pv_all, float* y_all, int ys) {
   constexpr int WPR = NWV / R;  // waves per row
   constexpr int U = 8, U2 = 8 / R;
   const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
@@ -339,7 +340,6 @@ __device__ void attend_rows(float4 qv, const float* __restrict__ base, size_t st
   float* sc = sc_all + (size_t)r * H * lcap;
   float* red = red_all + r * HMAX;
   float* pv = pv_all + (size_t)r * NWV * D;
-  float* y = y_all + r * DMAX;
   const float* col = base + ln * 4;
   for (int j0 = wr; j0 < n; j0 += WPR * U) {
     float4 kk[U];
@@ -403,7 +403,7 @@ __device__ void attend_rows(float4 qv, const float* __restrict__ base, size_t st
     float a = 0.f;
 #pragma unroll
     for (int w = 0; w < NWV; ++w) a += pr[w * D + cc];
-    y_all[rr * DMAX + cc] = a * red_all[rr * HMAX + cc / hd];
+    y_all[rr * ys + cc] = a * red_all[rr * HMAX + cc / hd];
   }
   __syncthreads();
 }
@@ -419,12 +419,13 @@ __global__ __launch_bounds__(NT) void k_parseq_dec_step_rows(DecStepW W, const i
   if (prev_not_done && *prev_not_done == 0) return;
   constexpr int WPR = NWV / R;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xa = smem;                     // [R][DMAX]
-  float* xb = xa + R * DMAX;            // [R][DMAX]
-  float* q = xb + R * DMAX;             // [R][DMAX]
-  float* kvcur = q + R * DMAX;          // [R][2 * DMAX]
-  float* hid = kvcur + R * 2 * DMAX;    // [R][FMAX]
-  float* red = hid + R * FMAX;          // [R][HMAX]
+  const int DS = W.D, FS = W.F;         // row strides of the LDS vectors: the model's widths, not the kernel's maxima
+  float* xa = smem;                     // [R][D]
+  float* xb = xa + R * DS;              // [R][D]
+  float* q = xb + R * DS;               // [R][D]
+  float* kvcur = q + R * DS;            // [R][2 D]
+  float* hid = kvcur + R * 2 * DS;      // [R][F]
+  float* red = hid + R * FS;            // [R][HMAX]
   float* uni = red + R * HMAX;          // matvec: part [R][4 * NT]  |  attention: sc [R][H * lcap] + pv [R][NWV][D]
   __shared__ int live_s[R];
   const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
@@ -460,14 +461,14 @@ __global__ __launch_bounds__(NT) void k_parseq_dec_step_rows(DecStepW W, const i
         v = sq * W.emb[(size_t)token * D + cc];
         if (step > 0) v = W.posq[(size_t)(step - 1) * D + cc] + v;
       }
-      xa[r * DMAX + cc] = v;
+      xa[r * DS + cc] = v;
     }
     __syncthreads();
-    rows_ln<R>(xa, W.ncg, W.ncb, 1e-5f, xb, D);
-    matvec_rows<ACT_NONE, R>(W.Wkv_t, W.bkv, xb, DMAX, D, 2 * D, nullptr, 0, kvcur, 2 * DMAX, uni);
+    rows_ln<R>(xa, W.ncg, W.ncb, 1e-5f, xb, D, DS);
+    matvec_rows<ACT_NONE, R>(W.Wkv_t, W.bkv, xb, DS, D, 2 * D, nullptr, 0, kvcur, 2 * DS, uni);
     for (int c = t; c < 2 * D * R; c += NT) {
       const int r = c / (2 * D), cc = c - r * 2 * D;
-      if (live_s[r]) skv[((size_t)(b0 + r) * NS + step) * 2 * D + cc] = kvcur[r * 2 * DMAX + cc];
+      if (live_s[r]) skv[((size_t)(b0 + r) * NS + step) * 2 * D + cc] = kvcur[r * 2 * DS + cc];
     }
     __syncthreads();  // the new rows are read back from the caches below
   }
@@ -475,29 +476,29 @@ __global__ __launch_bounds__(NT) void k_parseq_dec_step_rows(DecStepW W, const i
   {
     float4 qv = *reinterpret_cast<const float4*>(W.qsa + (size_t)step * D + ln * 4);
     qv.x *= scale; qv.y *= scale; qv.z *= scale; qv.w *= scale;
-    attend_rows<R>(qv, skv + (size_t)my_b * NS * 2 * D, (size_t)2 * D, my_live ? step + 1 : 0, D, H, sc, lcap, red, pv, xa);
-    matvec_rows<ACT_NONE, R>(W.Wo1_t, W.bo1, xa, DMAX, D, D, W.posq + (size_t)step * D, 0, q, DMAX, uni);
+    attend_rows<R>(qv, skv + (size_t)my_b * NS * 2 * D, (size_t)2 * D, my_live ? step + 1 : 0, D, H, sc, lcap, red, pv, xa, DS);
+    matvec_rows<ACT_NONE, R>(W.Wo1_t, W.bo1, xa, DS, D, D, W.posq + (size_t)step * D, 0, q, DS, uni);
   }
   // ---- cross attention over the encoder memory
   {
-    rows_ln<R>(q, W.n1g, W.n1b, 1e-5f, xa, D);
-    matvec_rows<ACT_NONE, R>(W.Wq_t, W.bq, xa, DMAX, D, D, nullptr, 0, xb, DMAX, uni);
-    float4 qv = *reinterpret_cast<const float4*>(xb + my_r * DMAX + ln * 4);
+    rows_ln<R>(q, W.n1g, W.n1b, 1e-5f, xa, D, DS);
+    matvec_rows<ACT_NONE, R>(W.Wq_t, W.bq, xa, DS, D, D, nullptr, 0, xb, DS, uni);
+    float4 qv = *reinterpret_cast<const float4*>(xb + my_r * DS + ln * 4);
     qv.x *= scale; qv.y *= scale; qv.z *= scale; qv.w *= scale;
     const size_t mrow = mem_off ? (size_t)mem_off[my_b] : (size_t)my_b * L;
     const int mlen = mem_len ? mem_len[my_b] : L;
-    attend_rows<R>(qv, memkv + mrow * 2 * D, (size_t)2 * D, my_live ? mlen : 0, D, H, sc, lcap, red, pv, xa);
-    matvec_rows<ACT_NONE, R>(W.Wo2_t, W.bo2, xa, DMAX, D, D, q, DMAX, q, DMAX, uni);
+    attend_rows<R>(qv, memkv + mrow * 2 * D, (size_t)2 * D, my_live ? mlen : 0, D, H, sc, lcap, red, pv, xa, DS);
+    matvec_rows<ACT_NONE, R>(W.Wo2_t, W.bo2, xa, DS, D, D, q, DS, q, DS, uni);
   }
   // ---- feed forward
-  rows_ln<R>(q, W.n2g, W.n2b, 1e-5f, xa, D);
-  matvec_rows<ACT_GELU, R>(W.W1_t, W.b1, xa, DMAX, D, W.F, nullptr, 0, hid, FMAX, uni);
-  matvec_rows<ACT_NONE, R>(W.W2_t, W.b2, hid, FMAX, W.F, D, q, DMAX, q, DMAX, uni);
+  rows_ln<R>(q, W.n2g, W.n2b, 1e-5f, xa, D, DS);
+  matvec_rows<ACT_GELU, R>(W.W1_t, W.b1, xa, DS, D, W.F, nullptr, 0, hid, FS, uni);
+  matvec_rows<ACT_NONE, R>(W.W2_t, W.b2, hid, FS, W.F, D, q, DS, q, DS, uni);
   // ---- decoder.norm -> rows for the vocabulary head
-  rows_ln<R>(q, W.dng, W.dnb, 1e-5f, xa, D);
+  rows_ln<R>(q, W.dng, W.dnb, 1e-5f, xa, D, DS);
   for (int c = t; c < D * R; c += NT) {
     const int r = c / D, cc = c - r * D;
-    if (live_s[r]) out[(size_t)(b0 + r) * D + cc] = xa[r * DMAX + cc];
+    if (live_s[r]) out[(size_t)(b0 + r) * D + cc] = xa[r * DS + cc];
   }
 }
 
@@ -509,8 +510,8 @@ bool decstep_debug_option(const std::string& key, int value) {
 }
 
 template <int R>
-static size_t rows_smem_bytes(int D, int H, int lcap) {
-  const size_t fixed = (size_t)R * (3 * DMAX + 2 * DMAX + FMAX + HMAX);
+static size_t rows_smem_bytes(int D, int F, int H, int lcap) {
+  const size_t fixed = (size_t)R * (3 * D + 2 * D + F + HMAX);
   const size_t uni = std::max((size_t)R * 4 * NT, (size_t)R * ((size_t)H * lcap + (size_t)NWV * D));
   return (fixed + uni) * sizeof(float);
 }
@@ -520,7 +521,7 @@ static bool launch_rows(hipStream_t s, const DecStepW& W, const int* tok, int ld
                         const float* memkv, int L, const int* mem_off, const int* mem_len, float* out, const int* prev_not_done,
                         int B, const int* gid, const int* gopen, int ng) {
   const int lcap = (std::max(L, NS) + 63) / 64 * 64;
-  const size_t bytes = rows_smem_bytes<R>(W.D, W.H, lcap);
+  const size_t bytes = rows_smem_bytes<R>(W.D, W.F, W.H, lcap);
   if (bytes > 160 * 1024 - 64) return false;  // live_s + alignment slack
   static std::atomic<size_t> configured{0};
   if (configured.load(std::memory_order_acquire) < bytes) {
