@@ -250,6 +250,10 @@ def _helper_init(local_rank, sds, shares, workers, wave, model_set, index):
 
     sds = {k: {name: torch.from_numpy(a) for name, a in sd.items()} for k, sd in sds.items()}
     device = rank_device(local_rank)
+    if not DRY and os.environ.get("YMK_DEC_ROWS"):
+        from yomitoku_amd import _lib
+
+        _lib.debug_option("dec_rows", int(os.environ["YMK_DEC_ROWS"]))
     pages = make_pages(shares[index], device)
     waves = make_waves(pages, wave)
     pool = PageParallel(lambda i: build_analyzer(device, sds, model_set), n_workers=workers)
@@ -280,26 +284,34 @@ REC_PRESETS = {  # --rec-model: (synth.parseq_state_dict kwargs, oracle preset n
 }
 
 
-def conv_roofline(lib, run_once, units, unit_name, kernel_desc):
-    """HIP events around every implicit-GEMM launch of one serial pass (`run_once`) -> the roofline dict."""
+def conv_roofline(lib, run_once, units, unit_name, kernel_desc, reps=3):
+    """HIP events around every implicit-GEMM launch of one serial pass (`run_once`) -> the roofline dict.  The pass is
+    repeated `reps` times and the MEDIAN pass (by total event time) is reported, with the spread next to it."""
     from yomitoku_amd import _lib
 
-    _lib.check(lib.ymk_prof_begin())
-    run_once()
-    torch.cuda.synchronize()
-    ms, fl, ln = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-    _lib.check(lib.ymk_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(ln)))
-    alg = ctypes.c_double()
-    _lib.check(lib.ymk_prof_bytes(ctypes.byref(alg)))
-    if ms.value <= 0:
+    passes = []
+    for _ in range(max(1, reps)):
+        _lib.check(lib.ymk_prof_begin())
+        run_once()
+        torch.cuda.synchronize()
+        ms, fl, ln = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        _lib.check(lib.ymk_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(ln)))
+        alg = ctypes.c_double()
+        _lib.check(lib.ymk_prof_bytes(ctypes.byref(alg)))
+        if ms.value > 0:
+            passes.append((ms.value, fl.value, ln.value, alg.value))
+    if not passes:
         return None
-    ach = fl.value / (ms.value * 1e-3) / 1e12
+    passes.sort()
+    ms, fl, ln, alg = passes[len(passes) // 2]
+    ach = fl / (ms * 1e-3) / 1e12
     return {
         "bound": "mfma", "kernel": kernel_desc, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-        "algorithmic_bytes_per_launch": int(alg.value // max(1, ln.value)),
-        f"launches_per_{unit_name}": round(ln.value / units, 2), "avg_launch_us": round(ms.value * 1e3 / max(1, ln.value), 2),
-        f"kernel_ms_per_{unit_name}": round(ms.value / units, 4), f"gflop_per_{unit_name}": round(fl.value / units / 1e9, 2),
+        "algorithmic_bytes_per_launch": int(alg // max(1, ln)),
+        f"launches_per_{unit_name}": round(ln / units, 2), "avg_launch_us": round(ms * 1e3 / max(1, ln), 2),
+        f"kernel_ms_per_{unit_name}": round(ms / units, 4), f"gflop_per_{unit_name}": round(fl / units / 1e9, 2),
+        "serial_passes_tflops": [round(f / (m * 1e-3) / 1e12, 2) for m, f, _, _ in passes],
     }
 
 
@@ -444,6 +456,8 @@ def main():
     assert DRY or torch.cuda.is_available(), "bench.py needs a HIP device"
     device = rank_device(local_rank)
     lib = None if DRY else _lib.load()
+    if lib is not None and os.environ.get("YMK_DEC_ROWS"):  # A/B knob of the fused greedy step (rows per block)
+        _lib.debug_option("dec_rows", int(os.environ["YMK_DEC_ROWS"]))
     # Launch-latency-bound host threads: a worker returning from a 50 us library call must not wait 5 ms (CPython's
     # default switch interval) behind another worker's Python loop.  An application-level choice, made here.
     sys.setswitchinterval(float(os.environ.get("YMK_SWITCH_INTERVAL", 2e-4)))

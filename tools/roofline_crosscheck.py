@@ -4,8 +4,8 @@
     python tools/roofline_crosscheck.py line.json DIR out.json [FETCH_DIR WRITE_DIR traffic.json]
 
 `bench.py --roofline-only` runs, in this order: the serial pass once untimed (shapes seen once), the SAME serial pass
-with a HIP event pair around every conv launch (L launches: `launches_per_page` x pages of the pass), then one DBNet
-forward.  The conv dispatches of the kernel trace therefore END with [L warm][L timed][DBNet]; this script takes the
+with a HIP event pair around every conv launch (L launches: `launches_per_page` x pages of the pass; repeated, the
+median pass is reported), then the DBNet forward alone (same repetitions).  The conv dispatches of the kernel trace therefore END with [L warm][L timed][DBNet]; this script takes the
 timed block and compares its average duration with the live `avg_launch_us`.  With the two PMC directories (separate
 `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of the same command) it also writes the HBM bytes per launch of the same
 block, corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes (KB units; FETCH_SIZE doubled on gfx950).
@@ -31,8 +31,8 @@ def _timed_block(rows, launches, tail):
     """The conv dispatches of the timed serial pass: the `launches` before the last `tail` (the closing DBNet forward).
     Counted from the END of the trace, because model set-up (bias calibration forwards) also launches convs."""
     conv = [r for r in rows if _is_conv(r["Kernel_Name"])]
-    if len(conv) < 2 * launches + tail:
-        raise SystemExit(f"{len(conv)} conv dispatches in the trace, expected at least {2 * launches + tail}")
+    if len(conv) < launches + tail:
+        raise SystemExit(f"{len(conv)} conv dispatches in the trace, expected at least {launches + tail}")
     return conv[len(conv) - tail - launches: len(conv) - tail], len(conv)
 
 
@@ -51,8 +51,11 @@ def main(argv):
     if "launches_per_page" not in roof:
         raise SystemExit("not an analyzer/detector roofline line")
     launches = int(round(roof["launches_per_page"] * pages))
+    reps = len(roof.get("serial_passes_tflops", [0]))  # bench.py repeats the profiled pass and reports the median one
+    pages *= reps
+    launches *= reps
     db = roof.get("dbnet_conv")
-    tail = int(round(db["launches_per_page"] * db["batch"])) if db else 0
+    tail = int(round(db["launches_per_page"] * db["batch"])) * reps if db else 0
     rows = kernel_rows(kt_dir)
     block, total = _timed_block(rows, launches, tail)
     dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in block]

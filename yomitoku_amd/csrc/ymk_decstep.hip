@@ -237,7 +237,7 @@ __global__ __launch_bounds__(NT) void k_parseq_dec_step(DecStepW W, const int* _
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The same step for R samples per block (R = 2 or 4), for forwards with more rows than the chip has block slots
+// The same step for R samples per block (R = 2; 4 as an A/B option), for forwards with more rows than the chip has block slots
 // (a grouped forward over the pages of a wave: ~650 rows against 256 resident blocks of the kernel above, i.e. three
 // block generations per step).  A block streams the 1.9 MB of decoder matrices ONCE for its R rows (R accumulators per
 // thread), LayerNorms run one wave per row, and the 16 waves split into 16 / R waves per row for the two attentions.
@@ -540,9 +540,11 @@ void parseq_dec_step(hipStream_t s, const DecStepW& W, const int* tok, int ld_to
                      int B, const int* gid, const int* gopen, int ng) {
   YMK_CHECK(parseq_dec_step_supported(W.D, W.H, W.F, L, NS), "fused decoder step: unsupported geometry");
   // rows per block: one while every row gets its own resident block (256 CUs x 1 block of this register footprint),
-  // more when the rows would otherwise queue up behind each other; falls back when the LDS does not hold R rows' scores
+  // two when the rows would otherwise queue up behind each other.  Measured per step, serial, 655 rows / ~400 / a handful
+  // still open (profiles/README.md): 1 row 175 / 120 / 58 us, 2 rows 148 / 84 / 72 us, 4 rows 183 / 122 / 109 us - with
+  // four rows the block's own chain of phases is twice as long, so that variant stays a test / A-B option.
   int rows = g_dec_rows.load(std::memory_order_relaxed);
-  if (rows == 0) rows = B > 512 ? 4 : B > 288 ? 2 : 1;
+  if (rows == 0) rows = B > 288 ? 2 : 1;
   if (rows >= 4 && launch_rows<4>(s, W, tok, ld_tok, step, skv, NS, memkv, L, mem_off, mem_len, out, prev_not_done, B, gid, gopen, ng))
     return;
   if (rows >= 2 && launch_rows<2>(s, W, tok, ld_tok, step, skv, NS, memkv, L, mem_off, mem_len, out, prev_not_done, B, gid, gopen, ng))
