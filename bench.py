@@ -615,9 +615,12 @@ def main():
             roof["wall_implied"] = {"achieved": round(wall_tf, 2), "frac": round(wall_tf / FP32_MFMA_PEAK_TFLOPS, 4),
                                     "note": "gflop_per_page x pages/s per GPU: lower than `achieved` because the wall clock also holds "
                                             "the non-conv kernels, D2H copies and host gaps; kernel_ms_per_page x pages_per_step <= ms_per_step "
-                                            "is asserted below"}
+                                            "is checked below (`self_consistent`)"}
             roof["conv_share_of_wall"] = round(roof["kernel_ms_per_page"] * len(seeds) * args.steps / (dt * 1e3), 4)
-            assert roof["conv_share_of_wall"] <= 1.05, "serial conv time exceeds the wall clock of the timed region"
+            # serial conv time <= wall clock of the timed region, up to what concurrency buys (other waves' kernels fill the
+            # last, partly empty block generation of a launch; the serial pass leaves those CUs idle).  Reported, not
+            # asserted: a disturbed serial pass must not cost the run its JSON line.
+            roof["self_consistent"] = bool(roof["conv_share_of_wall"] <= 1.05)
         if args.workload == "analyzer" and roof is not None:
             # the north star quotes MFMA utilisation "on DBNet conv": the same measurement over the detector's launches alone
             det = solo.analyzer.text_detector
