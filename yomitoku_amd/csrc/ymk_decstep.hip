@@ -522,12 +522,16 @@ static bool launch_rows(hipStream_t s, const DecStepW& W, const int* tok, int ld
                         int B, const int* gid, const int* gopen, int ng) {
   const int lcap = (std::max(L, NS) + 63) / 64 * 64;
   const size_t bytes = rows_smem_bytes<R>(W.D, W.F, W.H, lcap);
-  if (bytes > 160 * 1024 - 64) return false;  // live_s + alignment slack
-  static std::atomic<size_t> configured{0};
-  if (configured.load(std::memory_order_acquire) < bytes) {
+  constexpr size_t LDS_MAX = 160 * 1024 - 64;  // the CU's 160 KB minus live_s and alignment slack
+  if (bytes > LDS_MAX) return false;
+  static std::atomic<bool> configured[64];  // per device: the attribute belongs to the function on one device
+  int dev = 0;
+  YMK_HIP(hipGetDevice(&dev));
+  YMK_CHECK(dev >= 0 && dev < 64, "fused decoder step: device index out of range");
+  if (!configured[dev].load(std::memory_order_acquire)) {  // idempotent: a race sets the same value twice
     YMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parseq_dec_step_rows<R>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    configured.store(160 * 1024, std::memory_order_release);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
+    configured[dev].store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL(k_parseq_dec_step_rows<R>, dim3((B + R - 1) / R), dim3(NT), bytes, s, W, tok, ld_tok, step, skv, NS, memkv,
                      L, mem_off, mem_len, out, prev_not_done, gid, gopen, ng, B, lcap);
