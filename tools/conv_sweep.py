@@ -32,6 +32,8 @@ SHAPES = [
     ("parseq fc2 768->192 +res", 1, 1, 176496, 768, 192, 1, 1, 0, 1, 0, 1),
     ("parseq proj 192->192 +res", 1, 1, 176496, 192, 192, 1, 1, 0, 1, 0, 1),
     ("parseq head 192->7119", 1, 1, 66155, 192, 7119, 1, 1, 0, 1, 0, 0),
+    ("parseq AR head 655 rows", 1, 1, 655, 192, 7119, 1, 1, 0, 1, 0, 0),
+    ("parseq AR head 200 rows", 1, 1, 200, 192, 7119, 1, 1, 0, 1, 0, 0),
 ]
 # "v" or "v/f": conv_variant v with conv_fast f (0: index divisions for 1x1 layers and no residual prefetch - the A/B baseline)
 VARIANTS = [v.strip() for v in os.environ.get("VARIANTS", "0,1,2,3,4,5,6").split(",")]
@@ -58,6 +60,10 @@ def run(shape, variant, reps=REPS):
     y = torch.empty(n, oh, ow, cout, device=dev)
     r = torch.randn(n, oh, ow, cout, generator=g).to(dev) if res else None
     vnum, _, fast = str(variant).partition("/")
+    force = -1
+    if vnum.startswith("s"):  # "s<i>": split-K candidate i (ymk_debug_option splitk_force)
+        force, vnum = int(vnum[1:]), "0"
+    _lib.debug_option("splitk_force", force)
     _lib.debug_option("conv_variant", int(vnum))
     _lib.debug_option("conv_fast", int(fast) if fast else 3)
     times = []
@@ -70,6 +76,7 @@ def run(shape, variant, reps=REPS):
         if i:
             times.append(ms.value)
     _lib.debug_option("conv_variant", 0)
+    _lib.debug_option("splitk_force", -1)
     _lib.debug_option("conv_fast", 3)
     t = float(np.median(times))
     return fl.value / (t * 1e-3) / 1e12, t * 1e3, float(y.flatten()[:4096].double().sum().item())
