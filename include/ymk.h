@@ -137,7 +137,9 @@ int ymk_prof_begin(void);
 /* Test / measurement knobs, process-wide (never touched by the product path; defaults in parentheses):
  *   "splitk_force" (-1)  >= 0: that split-K tile shape for every eligible launch      "no_splitk" (0)  1: conv_igemm only
  *   "conv_variant" (0)   alternative conv_igemm schedules for A/B runs (tools/conv_sweep.py)       "prof_dump" (0)  1: ymk_prof_end
- *   prints one line per launch      "parseq_unfused" (0)  1: per-op PARSeq decoder step at every width */
+ *   prints one line per launch      "parseq_unfused" (0)  1: per-op PARSeq decoder step at every width
+ *   "conv_fast" (3)      bit 0: index shortcut of 1x1 / stride-1 layers, bit 1: residual rows fetched ahead (0 = the A/B baseline)
+ *   "dec_rows" (0)       samples per block of the fused greedy step: 0 = by row count, 1 / 2 / 4 forced (bit-identical results) */
 int ymk_debug_option(const char* key, int value);
 int ymk_prof_end(double* conv_ms, double* conv_flop, int64_t* conv_launches);
 int ymk_prof_bytes(double* conv_bytes);
