@@ -2,21 +2,22 @@
 """Benchmark of the MI355X DocumentAnalyzer hot path (contract: task prompt / DESIGN.md §8).
 
     python bench.py --gpus N --steps K --warmup W [--workload analyzer|detector|recognizer] [--model-set lite|default]
-                    [--pages 64] [--wave 8] [--workers 2] [--procs 2]
+                    [--pages 64] [--wave 8] [--in-flight 3]
 
-One rank per GPU.  Under torchrun the rank comes from the environment; `python bench.py --gpus N` without one
-spawns its own N ranks (same protocol: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  A "step" is one pass of the hot
-path over one batch of synthetic 1600x1200 pages that are already resident in HBM (uint8 BGR, as `cv2.imread` would
-hand them over).  Rank 0 prints ONE JSON line: BASELINE.json's metric (pages/s, whole job), the roofline of the
+One rank = ONE process per GPU.  Under torchrun the rank comes from the environment; `python bench.py --gpus N` without
+one spawns its own N ranks (same protocol: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  A "step" is one pass of the hot
+path over one batch of synthetic 1600x1200 pages (uint8 BGR, as `cv2.imread` would hand them over); the analyzer
+workload starts from HOST pages - pinned staging and the H2D copies are inside the clock.  Rank 0 prints ONE JSON line: BASELINE.json's metric (pages/s, whole job), the roofline of the
 dominant kernel (live HIP-event timing of every implicit-GEMM convolution launch on its own stream, in a serial pass
 of the same program) and, at N=1, the CPU baseline (oracle restatement of the reference's PyTorch-CPU path).
 
 workload analyzer (default; BASELINE.json configs[3]): DBNet text detector, PARSeq recogniser, RT-DETRv2 layout
-  parser, RT-DETRv2 table-structure recogniser, host post-processing and aggregation, through
-  `DocumentAnalyzer.analyze_pages`: `--wave` pages share device batches (DBNet / RT-DETR forwards over the wave, one
-  grouped PARSeq forward with one greedy loop), `--workers` waves in flight per process (each on its own replica and
-  HIP streams), `--procs` processes per GPU.  Per-page results equal `DocumentAnalyzer.__call__` page by page
-  (tests/test_pipeline_gpu.py).  `--model-set lite` = the reference's `--lite` switches (cli/main.py:505-520:
+  parser, RT-DETRv2 table-structure recogniser, host post-processing and aggregation, through the product's multi-page
+  entry point `DocumentAnalyzer.serve(host_pages)` (yomitoku_amd/serving.py): `--wave` pages share device batches
+  (DBNet / RT-DETR forwards over the wave, one grouped PARSeq forward with one greedy loop), a stage pipeline keeps
+  `--in-flight` waves between upload and aggregation, and EVERY page's DocumentAnalyzerSchema comes back, in page
+  order, inside the clock.  Per-page results equal `DocumentAnalyzer.__call__` page by page (tests/test_serving_gpu.py,
+  tests/test_pipeline_gpu.py).  `--model-set lite` = the reference's `--lite` switches (cli/main.py:505-520:
   parseq-tiny-dynw-v4, dynamic_width, batch_bucketing, source_downscale); `--model-set default` = the constructor
   defaults (dbnetv2_1 + parseq-large-v4_1 at its fixed 800 px canvas).
   Weights are seeded random draws (no network) which detect noise, so the DISCRETE hand-overs between stages use the
@@ -41,6 +42,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # as `import yomitoku_amd` does; here too because torch is imported first
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -172,7 +174,8 @@ class Page:
 
 
 def build_analyzer(device, sds, model_set="lite"):
-    """One analyzer replica as a callable: run(wave of Page objects) -> list of DocumentAnalyzerSchema."""
+    """The analyzer of this rank: DocumentAnalyzer whose DISCRETE stage hand-overs use the pages' ground truth (module
+    doc).  `an.truth` is the list of Page objects the served pages come from (page id i -> truth[i % len(truth)])."""
     import logging
 
     from yomitoku_amd import document_analyzer as da
@@ -181,49 +184,40 @@ def build_analyzer(device, sds, model_set="lite"):
     logging.getLogger("yomitoku_amd.base").setLevel(logging.WARNING)
 
     class TruthDrivenAnalyzer(da.DocumentAnalyzer):
-        """DocumentAnalyzer whose stage hand-overs use the pages' ground truth (see module doc)."""
-
-        truth = None  # {device pointer of the page: Page}
+        truth = None
         stats = None
 
-        def _ocr_pages(self, pages):
-            truth = [self.truth[p.data_ptr()] for p in pages]
-            det = self.text_detector
-            maps = det.forward_pages(pages)  # pre-processing, DBNet forwards, maps back to the host: full cost
-            sizes = [tuple(int(v) for v in p.shape[:2]) for p in pages]
-            assert all(m.shape == t.truth_map.shape for m, t in zip(maps, truth))
-            boxes = det.extract_boxes([t.truth_map for t in truth], sizes)  # C++ box extraction on the rendered maps
-            dets = [TextDetectorSchema(points=t.quads, scores=[1.0] * len(t.quads)) for t in truth]
-            recs = self.text_recognizer.recognize_pages(pages, [d.points for d in dets])
+        def _truth(self, wave):
+            return [self.truth[i % len(self.truth)] for i in wave.ids]
+
+        # _stage_detect is the product's: pre-processing, DBNet forwards, maps back to the host - full cost
+        def _stage_boxes(self, wave):
+            truth = self._truth(wave)
+            assert all(m.shape == t.truth_map.shape for m, t in zip(wave.maps, truth))
+            boxes = self.text_detector.extract_boxes([t.truth_map for t in truth], wave.sizes)  # C++ extraction on rendered maps
+            wave.dets = [TextDetectorSchema(points=t.quads, scores=[1.0] * len(t.quads)) for t in truth]
             if self.stats is not None:
                 self.stats["det_boxes"].extend(len(b.points) for b in boxes)
-            return dets, recs
 
-        def _layout_pages(self, pages):
-            truth = [self.truth[p.data_ptr()] for p in pages]
-            noise = self.layout.layout_parser.parse_pages(pages)  # full layout stage, result not propagated
-            tables = self.layout.table_structure_recognizer.recognize_pages(pages, [t.tables for t in truth])
-            out = []
+        # _stage_recognize is the product's, on the true text-line quads
+        def _stage_layout(self, wave):
+            truth = self._truth(wave)
+            noise = self.layout.layout_parser.parse_pages(wave.pages)  # full layout stage, result not propagated
+            tables = self.layout.table_structure_recognizer.recognize_pages(wave.pages, [t.tables for t in truth])
+            wave.lays = []
             for t, tb in zip(truth, tables):
                 paragraphs = [Element(id=None, box=b, score=1.0, role=None, contents=None) for b in t.paragraphs]
-                out.append(LayoutAnalyzerSchema(paragraphs=paragraphs, tables=tb, figures=[]))
+                wave.lays.append(LayoutAnalyzerSchema(paragraphs=paragraphs, tables=tb, figures=[]))
             if self.stats is not None:
                 self.stats["layout_boxes"].extend(len(n.paragraphs) + len(n.tables) + len(n.figures) for n in noise)
                 self.stats["cells"].extend(sum(len(x.cells) for x in tb) for tb in tables)
-            return out
 
     an = TruthDrivenAnalyzer(configs=MODEL_SETS[model_set], device=str(device))
     an.text_detector.model.load_state_dict(sds["det"])
     an.text_recognizer.model.load_state_dict(sds["rec"])
     an.layout.layout_parser.model.load_state_dict(sds["lay"])
     an.layout.table_structure_recognizer.model.load_state_dict(sds["tab"])
-
-    def run(wave):
-        an.truth = {p.dev.data_ptr(): p for p in wave}
-        return [r[0] for r in an.analyze_pages([p.dev for p in wave], wave=len(wave))]
-
-    run.analyzer = an
-    return run
+    return an
 
 
 def cpu_analyzer_page(sds, page: Page, charset, model_set="lite"):
@@ -237,36 +231,6 @@ def cpu_analyzer_page(sds, page: Page, charset, model_set="lite"):
     op.recognize(sds["rec"], ocfg, page.img, page.quads, charset, **batching)
     op.layout(sds["lay"], page.img)
     op.tables(sds["tab"], page.img, page.tables)
-
-
-def make_waves(pages, wave):
-    return [pages[i : i + wave] for i in range(0, len(pages), wave)]
-
-
-def _helper_init(local_rank, sds, shares, workers, wave, model_set, index):
-    """One helper process of a rank (yomitoku_amd/parallel.py PageProcesses): same GPU, own HIP context and
-    analyzer replicas built from the rank's checkpoints (received as numpy arrays), own pages resident in HBM."""
-    from yomitoku_amd.parallel import PageParallel
-
-    sds = {k: {name: torch.from_numpy(a) for name, a in sd.items()} for k, sd in sds.items()}
-    device = rank_device(local_rank)
-    if not DRY and os.environ.get("YMK_DEC_ROWS"):
-        from yomitoku_amd import _lib
-
-        _lib.debug_option("dec_rows", int(os.environ["YMK_DEC_ROWS"]))
-    pages = make_pages(shares[index], device)
-    waves = make_waves(pages, wave)
-    pool = PageParallel(lambda i: build_analyzer(device, sds, model_set), n_workers=workers)
-    pool.map(waves[:workers])  # first-call allocations happen before the parent starts its clock
-    device_sync()
-
-    def run_steps(k):  # k steps back to back: the pool keeps `workers` waves in flight across the step boundaries
-        k = int(k or 1)
-        pool.map(waves * k)
-        device_sync()
-        return len(pages) * k
-
-    return run_steps
 
 
 def make_pages(seeds, device):
@@ -330,20 +294,32 @@ def cpu_timed(fn, n_warm, n_timed, budget_s):
     return times
 
 
-def recognizer_workload(args, rank, local_rank, world, device, lib):
-    """BASELINE.json configs[2]: TextRecognizer with dynamic_width + batch_bucketing on 2048 synthetic 32 x W text-line
-    crops per GPU per step (one sheet image + 2048 quads through TextRecognizer.__call__).  Unit: text lines."""
+def recognizer_setup(device, rec_model, lines, seed=1, sd=None):
+    """TextRecognizer (`rec_model` geometry, seeded weights) + one synthetic sheet of `lines` text lines resident in HBM."""
     from yomitoku_amd import imaging
-    from yomitoku_amd import distributed as ydist
     from yomitoku_amd.text_recognizer import TextRecognizer
     from yomitoku_amd.utils.synth import parseq_state_dict, synthetic_line_sheet
 
+    ckpt_kw, _, _ = REC_PRESETS[rec_model]
+    if sd is None:
+        sd = parseq_state_dict(**ckpt_kw)
+    sheet, quads = synthetic_line_sheet(seed=seed, n_lines=lines)
+    page = imaging.page_to_device(sheet, device)
+    rec = TextRecognizer(model_name=rec_model, from_pretrained=False, device=str(device), dynamic_width=True, batch_bucketing=True)
+    rec.model.load_state_dict(sd)
+    return rec, sd, sheet, page, quads
+
+
+def recognizer_workload(args, rank, local_rank, world, device, lib):
+    """BASELINE.json configs[2]: TextRecognizer with dynamic_width + batch_bucketing on 2048 synthetic 32 x W text-line
+    crops per GPU per step (one sheet image + 2048 quads through TextRecognizer.__call__).  Unit: text lines."""
+    from yomitoku_amd import distributed as ydist
+    from yomitoku_amd.utils.synth import parseq_state_dict
+
     ckpt_kw, preset, batching = REC_PRESETS[args.rec_model]
     sd = ydist.broadcast_state_dict(parseq_state_dict(**ckpt_kw) if rank == 0 else None, src=0, device=device)
-    sheet, quads = synthetic_line_sheet(seed=1 + rank, n_lines=args.lines)
-    page = imaging.page_to_device(sheet, device)
-    rec = TextRecognizer(model_name=args.rec_model, from_pretrained=False, device=str(device), dynamic_width=True, batch_bucketing=True)
-    rec.model.load_state_dict(sd)
+    rccl = ydist.replica_report({"rec": sd}, device)
+    rec, sd, sheet, page, quads = recognizer_setup(device, args.rec_model, args.lines, seed=1 + rank, sd=sd)
 
     def step():
         return rec(page, quads)[0]
@@ -396,8 +372,47 @@ def recognizer_workload(args, rank, local_rank, world, device, lib):
                    "parallelism": f"line sheets sharded x{world} GPU(s); the mini-batches of a call share grouped forwards of "
                                   f"<= {rec.MAX_LINES_PER_FORWARD} lines",
                    "checkpoints": "seeded synthetic (no network)", "last_forward_ar_steps": int(rec.model.last_ar_steps)},
-        "roofline": roof, "cpu_baseline": cpu,
+        "roofline": roof, "cpu_baseline": cpu, "rccl": rccl,
     }
+
+
+def secondary_metrics(args, device, sds, pages):
+    """The other numbers BASELINE.json's metric names, measured in this process AFTER the timed region (rank 0, N = 1) so
+    that the driver's one bench line carries them: PARSeq text-lines/sec (configs[2]) for the open-beta geometry and for
+    the --lite recogniser, and the analyzer with the reference's DEFAULT model set.  Short legs: 1 warm-up + 2 timed
+    steps of 2048 lines; 16 warm-up + 64 timed pages."""
+    out = {}
+    for rec_model in ("parseq", "parseq-tiny-dynw-v4"):
+        rec, _, _, page, quads = recognizer_setup(device, rec_model, 2048)
+        rec(page, quads)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            res = rec(page, quads)[0]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[f"lines_per_s_{rec_model}"] = {"value": round(2 * 2048 / dt, 1), "unit": "lines/s", "steps": 2, "lines_per_step": 2048,
+                                           "workload": "BASELINE.json configs[2]: one TextRecognizer call (dynamic_width, batch_bucketing) "
+                                                       "over 2048 synthetic 32 x W lines of one sheet resident in HBM",
+                                           "distinct_strings": len(set(res.contents))}
+        rec.model.close()
+        del rec
+    sds_def = dict(sds, rec=make_checkpoints("default")["rec"])
+    an = build_analyzer(device, sds_def, "default")
+    an.truth = pages
+    host = [p.img for p in pages]
+    an.serve(host[:16], wave=args.wave, in_flight=args.in_flight)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = an.serve(host, wave=args.wave, in_flight=args.in_flight)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["pages_per_s_default_model_set"] = {"value": round(len(host) / dt, 2), "unit": "pages/s", "steps": 1, "pages": len(host),
+                                            "failed_pages": sum(isinstance(r, BaseException) for r in res),
+                                            "workload": "the analyzer workload with the reference's constructor defaults: dbnetv2_1 + "
+                                                        "parseq-large-v4_1 (fixed 800 px canvas, batch 128) + RT-DETRv2 layout + table"}
+    an.close()
+    return out
 
 
 def self_spawn(argv, n):
@@ -436,9 +451,9 @@ def main():
     ap.add_argument("--pages", type=int, default=64, help="pages per step per GPU (BASELINE.json configs[3]: 64)")
     ap.add_argument("--total-pages", type=int, default=0, help="strong scaling (configs[4]: 512): pages per step over ALL GPUs")
     ap.add_argument("--wave", type=int, default=8, help="pages per device batch (analyzer workload)")
-    ap.add_argument("--workers", type=int, default=2, help="waves in flight per process (analyzer workload)")
-    ap.add_argument("--procs", type=int, default=2, help="processes per GPU (analyzer workload): each has its own interpreter/GIL")
+    ap.add_argument("--in-flight", type=int, default=3, help="waves between upload and aggregation (analyzer workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary metrics leg (recogniser lines/s, default model set)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="skip the timed region: only the serial roofline pass (the command profiles/ runs under rocprofv3)")
     args = ap.parse_args()
@@ -449,7 +464,6 @@ def main():
     from yomitoku_amd import _lib
     from yomitoku_amd import distributed as ydist
     from yomitoku_amd import imaging
-    from yomitoku_amd.parallel import PageParallel
 
     rank, local_rank, world = ydist.init("gloo" if DRY else None)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -458,11 +472,11 @@ def main():
     lib = None if DRY else _lib.load()
     if lib is not None and os.environ.get("YMK_DEC_ROWS"):  # A/B knob of the fused greedy step (rows per block)
         _lib.debug_option("dec_rows", int(os.environ["YMK_DEC_ROWS"]))
-    # Launch-latency-bound host threads: a worker returning from a 50 us library call must not wait 5 ms (CPython's
-    # default switch interval) behind another worker's Python loop.  An application-level choice, made here.
+    # Launch-latency-bound host threads: a stage thread returning from a 50 us library call must not wait 5 ms (CPython's
+    # default switch interval) behind another stage's Python loop.  An application-level choice, made here.
     sys.setswitchinterval(float(os.environ.get("YMK_SWITCH_INTERVAL", 2e-4)))
     if not DRY and hasattr(os, "sched_setaffinity") and world > 1:
-        # one slice of the host cores per rank, so 8 ranks' worker threads do not migrate over each other
+        # one slice of the host cores per rank, so 8 ranks' stage threads do not migrate over each other
         cores = sorted(os.sched_getaffinity(0))
         per = max(1, len(cores) // world)
         os.sched_setaffinity(0, set(cores[local_rank * per : (local_rank + 1) * per]))
@@ -476,14 +490,16 @@ def main():
             torch.distributed.destroy_process_group()
         return
 
-    # ---- weights: drawn once on rank 0, ONE flat RCCL broadcast per checkpoint over xGMI
+    # ---- weights: drawn once on rank 0, ONE flat RCCL broadcast per checkpoint over xGMI; every rank then reports the CRC
+    # of what it received, so the line shows how many ranks the collective saw and that they hold rank 0's bytes
     sds = make_checkpoints(args.model_set) if rank == 0 else {k: None for k in ("det", "rec", "lay", "tab")}
     if rank == 0 and args.workload == "analyzer":
         sds = calibrate_heads(sds, device, Page(0, device))
     for k in ("det", "rec", "lay", "tab"):
         sds[k] = ydist.broadcast_state_dict(sds[k], src=0, device=device)
+    rccl = ydist.replica_report(sds, device)
 
-    # ---- synthetic pages of this rank, resident in HBM before the clock starts
+    # ---- synthetic pages of this rank: HOST arrays for the analyzer (staging + H2D inside the clock)
     if args.workload == "detector":
         args.pages = min(args.pages, 8)
     scaling = "weak"
@@ -493,45 +509,33 @@ def main():
     else:
         seeds = [1000 * rank + i for i in range(args.pages)]
     pages_job = args.total_pages if args.total_pages else args.pages * world
-    n_procs = max(1, args.procs) if args.workload == "analyzer" else 1
-    shares = [seeds[i::n_procs] for i in range(n_procs)]  # pages of this rank, dealt to its processes
-    pages = make_pages(shares[0], device)
+    pages = make_pages(seeds, device)
     extra = {}
-    helpers = None
+    failed = 0
+    an = None
     if args.workload == "analyzer":
-        from yomitoku_amd.parallel import PageProcesses
-
-        if n_procs > 1:
-            # the rank's checkpoints go to its helpers by value, as numpy arrays through the spawn pipe (no /dev/shm)
-            wire = {k: {name: t.numpy() for name, t in sd.items()} for k, sd in sds.items()}
-            helpers = PageProcesses(_helper_init, (local_rank, wire, shares, args.workers, args.wave, args.model_set),
-                                    n_procs=n_procs - 1, first_index=1)
-        pool = PageParallel(lambda i: build_analyzer(device, sds, args.model_set), n_workers=args.workers)
-        waves = make_waves(pages, args.wave)
+        an = build_analyzer(device, sds, args.model_set)
+        an.truth = pages
+        host_pages = [p.img for p in pages]
 
         def run_steps(k):
-            """k steps (k passes over the rank's pages) as ONE streaming job: every process of the rank walks its share
-            k times and keeps `workers` waves in flight across the step boundaries (no drain between steps); returns
-            when all processes have finished all k passes."""
-            if helpers:
-                helpers.start([k] * len(helpers))
-            out = pool.map(waves * k)[-1]
-            device_sync()
-            if helpers:
-                assert sum(helpers.finish()) + len(pages) * k == len(seeds) * k
-            return out
-
-        def step():
-            return run_steps(1)
+            """k steps (k passes over the rank's pages) as ONE serve() job: host pages in, every page's result out, in
+            order; the pipeline keeps `in_flight` waves going across the step boundaries (no drain between steps)."""
+            nonlocal failed
+            res = an.serve(host_pages * int(k), wave=args.wave, in_flight=args.in_flight)
+            assert len(res) == len(host_pages) * int(k)
+            failed += sum(isinstance(r, BaseException) for r in res)
+            return res[-1]
 
         names = {"lite": "DBNet dbnetv2_1 + PARSeq parseq-tiny-dynw-v4 (dynamic_width, batch_bucketing, source_downscale)",
                  "default": "DBNet dbnetv2_1 + PARSeq parseq-large-v4_1 (fixed 800 px canvas, batch_size 128 per page)"}
         metric = f"pages/sec (DocumentAnalyzer @1600x1200, {args.model_set} model set)"
         workload = (f"Full DocumentAnalyzer (BASELINE.json configs[{4 if args.total_pages else 3}]): {names[args.model_set]} + RT-DETRv2 layout + "
-                    f"RT-DETRv2 table structure + host post-processing and aggregation, through DocumentAnalyzer.analyze_pages; "
-                    f"{len(seeds)} synthetic 1600x1200 pages per step on this GPU, in waves of {args.wave} pages (device batches "
-                    f"across the pages of a wave), {n_procs} process(es) x {args.workers} waves in flight, the K steps of the timed region "
-                    f"streamed back to back (waves of step k+1 start while the last waves of step k finish); stage hand-overs use ground "
+                    f"RT-DETRv2 table structure + host post-processing and aggregation, through DocumentAnalyzer.serve - ONE process per "
+                    f"GPU, HOST pages in (pinned staging + H2D inside the clock), every page's DocumentAnalyzerSchema returned in page "
+                    f"order; {len(seeds)} synthetic 1600x1200 pages per step on this GPU, in waves of {args.wave} pages (device batches "
+                    f"across the pages of a wave), stage pipeline with {args.in_flight} waves in flight, the K steps of the timed region "
+                    f"served as one job (waves of step k+1 start while the last waves of step k finish); stage hand-overs use ground "
                     f"truth ({np.mean([len(p.quads) for p in pages]):.0f} text lines, {np.mean([len(p.tables) for p in pages]):.1f} tables, "
                     f"{np.mean([len(p.paragraphs) for p in pages]):.0f} paragraphs per page) and the DB box extraction runs on a map "
                     f"rendered from the true lines, because seeded random weights detect noise")
@@ -555,16 +559,19 @@ def main():
 
     dt = None
     out = None
+    per_rank = None
     if not args.roofline_only:
         if args.warmup:
             run_steps(args.warmup)
+        failed = 0
         device_sync()
         if world > 1:
             torch.distributed.barrier()
         device_sync()
         t0 = time.perf_counter()
-        out = run_steps(args.steps)  # exactly K steps; the analyzer's follow each other without a drain (streaming job)
+        out = run_steps(args.steps)  # exactly K steps; the analyzer's follow each other without a drain (one serve() job)
         device_sync()
+        dt_local = time.perf_counter() - t0
         if world > 1:
             torch.distributed.barrier()
         device_sync()
@@ -574,34 +581,35 @@ def main():
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             dt = float(tt.item())
         assert out is not None
+        # every rank's own pages/s (its K steps over its own clock, before the closing barrier) and failed-page count
+        rows = ydist.all_gather_scalars([len(seeds) * args.steps / dt_local, failed], device)
+        per_rank = {"pages_per_s_min": round(min(r[0] for r in rows), 3), "pages_per_s_max": round(max(r[0] for r in rows), 3),
+                    "failed_pages": int(sum(r[1] for r in rows))}
 
-    if helpers:
-        helpers.close()
-
-    # ---- roofline leg: per-launch HIP events around the conv kernel, in a SERIAL pass of the same program: one analyzer,
+    # ---- roofline leg: per-launch HIP events around the conv kernel, in a SERIAL pass of the same program: the same analyzer,
     # one wave at a time, the two chains of a wave one after the other on one stream - so that a launch's event pair
     # brackets that kernel alone.  `python bench.py --roofline-only` under rocprofv3 is the same pass (profiles/).
     roof = None
     if rank == 0 and not DRY:
         kern = "conv_igemm / conv_splitk (fp32 MFMA implicit GEMM: every conv / linear layer of the four nets)"
         if args.workload == "analyzer":
-            solo = pool.workers[0]
-            solo.analyzer.concurrent_chains = False  # the two chains one after the other: an event pair brackets one kernel
-            solo.analyzer.stats = {"det_boxes": [], "layout_boxes": [], "cells": []}
-            prof_waves = waves[: max(1, 16 // args.wave)]
-            units = sum(len(w) for w in prof_waves)
-            for w in prof_waves:  # shapes of the serial pass seen once (workspace growth stays out of the events)
-                solo(w)
+            an.concurrent_chains = False  # the two chains one after the other: an event pair brackets one kernel
+            an.stats = {"det_boxes": [], "layout_boxes": [], "cells": []}
+            n_prof = min(len(pages), max(args.wave, 16 // args.wave * args.wave))
+            prof_pages = [p.dev for p in pages[:n_prof]]  # resident pages: page ids 0.. match an.truth
+            units = len(prof_pages)
+            an.analyze_pages(prof_pages, wave=args.wave)  # shapes of the serial pass seen once (workspace growth stays out)
             torch.cuda.synchronize()
-            solo.analyzer.stats = {"det_boxes": [], "layout_boxes": [], "cells": []}
+            an.stats = {"det_boxes": [], "layout_boxes": [], "cells": []}
 
             def prof_step():
-                for w in prof_waves:
-                    solo(w)
+                an.analyze_pages(prof_pages, wave=args.wave)
         else:
             prof_step, units = step, args.pages
         roof = conv_roofline(lib, prof_step, units, "page", kern)
-        pmc = os.path.join(ROOT, "profiles", f"r02_{args.workload}_pmc_conv_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", f"r03_{args.workload}_pmc_conv_traffic.json")
+        if not os.path.exists(pmc):
+            pmc = os.path.join(ROOT, "profiles", f"r02_{args.workload}_pmc_conv_traffic.json")
         if roof is not None and os.path.exists(pmc):
             # HBM bytes per conv launch from the PMC passes of this same serial pass (rocprofv3 cannot run inside bench.py:
             # profiles/README.md has the commands); compare with algorithmic_bytes_per_launch
@@ -614,7 +622,7 @@ def main():
             wall_tf = roof["gflop_per_page"] * 1e-3 * pages_job * args.steps / dt / max(1, world)
             roof["wall_implied"] = {"achieved": round(wall_tf, 2), "frac": round(wall_tf / FP32_MFMA_PEAK_TFLOPS, 4),
                                     "note": "gflop_per_page x pages/s per GPU: lower than `achieved` because the wall clock also holds "
-                                            "the non-conv kernels, D2H copies and host gaps; kernel_ms_per_page x pages_per_step <= ms_per_step "
+                                            "the non-conv kernels, copies and host gaps; kernel_ms_per_page x pages_per_step <= ms_per_step "
                                             "is checked below (`self_consistent`)"}
             roof["conv_share_of_wall"] = round(roof["kernel_ms_per_page"] * len(seeds) * args.steps / (dt * 1e3), 4)
             # serial conv time <= wall clock of the timed region, up to what concurrency buys (other waves' kernels fill the
@@ -623,23 +631,30 @@ def main():
             roof["self_consistent"] = bool(roof["conv_share_of_wall"] <= 1.05)
         if args.workload == "analyzer" and roof is not None:
             # the north star quotes MFMA utilisation "on DBNet conv": the same measurement over the detector's launches alone
-            det = solo.analyzer.text_detector
-            d_roof = conv_roofline(lib, lambda: det.forward_pages([p.dev for p in prof_waves[0]]), len(prof_waves[0]), "page", kern)
+            det = an.text_detector
+            d_roof = conv_roofline(lib, lambda: det.forward_pages(prof_pages[: args.wave]), len(prof_pages[: args.wave]), "page", kern)
             roof["dbnet_conv"] = {k: d_roof[k] for k in ("achieved", "frac", "launches_per_page", "kernel_ms_per_page", "gflop_per_page")}
-            roof["dbnet_conv"]["batch"] = len(prof_waves[0])
-            st = solo.analyzer.stats
+            roof["dbnet_conv"]["batch"] = len(prof_pages[: args.wave])
+            st = an.stats
             extra["measured_units_per_page"] = {
-                "ar_steps_last_forward": int(solo.analyzer.text_recognizer.model.last_ar_steps),
+                "ar_steps_last_forward": int(an.text_recognizer.model.last_ar_steps),
                 "db_boxes_extracted": float(np.mean(st["det_boxes"])),
                 "noise_layout_boxes": float(np.mean(st["layout_boxes"])),
                 "table_cells": float(np.mean(st["cells"])),
             }
+            an.concurrent_chains = True
+            an.stats = None
+
+    # ---- secondary metrics (rank 0, N=1): the recogniser's lines/s and the default model set, in this same process
+    secondary = None
+    if rank == 0 and world == 1 and args.workload == "analyzer" and not (DRY or args.roofline_only or args.no_secondary):
+        secondary = secondary_metrics(args, device, sds, pages)
 
     # ---- CPU baseline leg (rank 0, N=1): oracle chain on the host cores, bounded sample
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not DRY and not args.roofline_only:
         if args.workload == "analyzer":
-            charset = pool.workers[0].analyzer.text_recognizer.charset
+            charset = an.text_recognizer.charset
             times = cpu_timed(lambda i: cpu_analyzer_page(sds, pages[i % len(pages)], charset, args.model_set), 2, 3, 90.0)
             sample = (f"the same synthetic pages through the oracle restatement (PyTorch-CPU fp32) of the `-d cpu` chain with the "
                       f"{args.model_set} model set: detector + recogniser + layout + table nets with their pre/post-processing (PyTorch "
@@ -668,12 +683,16 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "pages_per_step_per_gpu": len(seeds) if args.total_pages else args.pages,
-                       "parallelism": (f"page-sharded x{world} GPU(s), waves of {args.wave} pages, {n_procs} process(es) x {args.workers} "
-                                       f"waves in flight per GPU"
+                       "parallelism": (f"page-sharded x{world} GPU(s), one process per GPU: DocumentAnalyzer.serve, waves of {args.wave} "
+                                       f"pages, {args.in_flight} waves in flight"
                                        if args.workload == "analyzer" else f"page-sharded x{world} GPU(s), one batch of {args.pages} per forward"),
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "checkpoints": "seeded synthetic (no network)", **extra},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "rccl": rccl,
+            "per_rank": per_rank,
+            "secondary": secondary,
         }
         if args.total_pages:
             line["config"]["total_pages_per_step"] = args.total_pages
@@ -681,6 +700,8 @@ def main():
             line["dry_run"] = True
             line["metric"] = "DRY RUN - orchestration rehearsal with stub page workers, not a measurement"
         print(json.dumps(line), flush=True)
+    if an is not None:
+        an.close()
     if world > 1:
         torch.distributed.barrier()  # rank 0 is still in its roofline leg: the others wait here, not in teardown
         torch.distributed.destroy_process_group()

@@ -72,6 +72,11 @@ int ymk_parseq_forward(ymk_model* m, const float* x_dev, int b, int w, float* lo
  * group order.  out_len[g] / ar_steps[g] are what group g's own ymk_parseq_forward call would have returned. */
 int ymk_parseq_forward_groups(ymk_model* m, const float* const* x_dev, const int* b, const int* w, int n_groups,
                               float* logits_dev, int* out_len, int* ar_steps, void* stream);
+/* Size the model's workspace once for the largest forward the caller will issue: max_lines rows (over all groups of a
+ * call), each at most max_width pixels wide.  After it, forwards within those bounds never allocate or free device
+ * memory, whatever their shape (the mini-batches of text_recognizer.py:158-203 differ in size and width on every
+ * page) - which is what the "allocates nothing on the per-call path" rule above needs for ragged calls. */
+int ymk_parseq_reserve(ymk_model* m, int max_lines, int max_width, void* stream);
 /* what ParseqTokenizer.decode needs from softmax(logits) (parseq_tokenizer.py:79-87) without
  * materialising it: per row the arg-max class id and max probability. rows = b * out_len. */
 int ymk_parseq_token_stats(const float* logits_dev, int rows, int num_classes, int* ids_dev, float* probs_dev,

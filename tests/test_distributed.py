@@ -39,6 +39,14 @@ def _worker(rank, world, port, q):
     # half-precision tensors are not truncated to integers, doubles are not narrowed to fp32 on the way
     ok = ok and got["h.bf16"].dtype == torch.bfloat16 and torch.equal(got["h.bf16"], torch.tensor([0.3359375, -2.5, 1e-3], dtype=torch.bfloat16))
     ok = ok and got["h.f64"].dtype == torch.float64 and torch.equal(got["h.f64"], torch.tensor([1.0 + 2.0 ** -40, -3.0], dtype=torch.float64))
+    # every rank holds rank 0's bytes, and the report counts the ranks the collective saw
+    rep = yd.replica_report({"ck": got}, device=torch.device("cpu"))
+    ok = ok and rep["ranks"] == world and rep["backend"] == "gloo" and rep["weights_crc_equal"] is True
+    bad = dict(got)
+    if rank == 1:
+        bad["a.bias"] = got["a.bias"] + 1
+    ok = ok and yd.replica_report({"ck": bad}, device=torch.device("cpu"))["weights_crc_equal"] is False
+    ok = ok and yd.all_gather_scalars([rank + 0.5], torch.device("cpu")) == [[0.5], [1.5]]
     n_items = 7
     mine = yd.shard_indices(n_items, rank, world)
     merged = yd.gather_in_order([f"page{i}" for i in mine], n_items, rank, world)

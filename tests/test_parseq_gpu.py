@@ -135,6 +135,38 @@ def test_grouped_forward_matches_oracle_and_single_calls(dev, shapes):
     assert torch.equal(again.cpu(), lg), "grouped forward must be bit-identical on repeat"
 
 
+def test_grouped_forward_with_a_repetition_stopped_row_in_a_short_group(dev):
+    """A row stopped by the repetition detector keeps an ARG-MAX, not <eos>, at its last position.  When its mini-batch is
+    the short one of a grouped forward, the shared greedy loop runs on for the other groups; the refinement must still
+    see exactly the context the row's own forward builds (models/parseq.py:264-278: tgt_in from logits[:, :-1] of ITS
+    loop) - positions beyond the group's own step count are masked.  Checked against the oracle and the single call."""
+    from oracle.parseq import parseq_forward
+    from yomitoku_amd.utils.synth import parseq_state_dict, synthetic_line_batch
+
+    z = np.load(os.path.join(GOLD, "parseq_ref_rep.npz"))
+    sd = parseq_state_dict(**ast.literal_eval(str(z["ckpt"])))
+    ocfg, net = _net(dev, sd)
+    rows = [torch.from_numpy(z["x"][i : i + 1]) for i in range(z["x"].shape[0])]
+    rows += [synthetic_line_batch(40 + i, 1, w) for i, w in enumerate((96, 240, 480, 800))]
+    steps = []
+    for r in rows:
+        net(r.to(dev))
+        steps.append(net.last_ar_steps)
+    short, long_ = int(np.argmin(steps)), int(np.argmax(steps))
+    assert steps[short] < steps[long_] < 101, steps  # the short group is cut by the detector well before the loop ends
+    xs = [rows[short], rows[long_]]
+    logits, out_lens, got_steps = net.forward_groups([x.to(dev) for x in xs])
+    assert list(got_steps) == [steps[short], steps[long_]]
+    lg = logits.cpu()
+    for k, x in enumerate(xs):
+        ref, ref_steps = parseq_forward(sd, ocfg, x, return_steps=True)
+        got = lg[k : k + 1, : out_lens[k]]
+        assert ref_steps == got_steps[k] and got.shape == ref.shape
+        assert torch.equal(got.argmax(-1), ref.argmax(-1)) and (got - ref).abs().max().item() < LOGIT_TOL
+        one = net(x.to(dev)).cpu()
+        assert (one - got).abs().max().item() < 1e-4
+
+
 def test_grouped_forward_open_beta_no_refine(dev):
     """Per-op decoder path (D = 512) with ragged encoder memory, refine_iters = 0: each group returns the AR logits of
     the steps ITS loop would have run, although the shared loop runs until the slowest group is done."""

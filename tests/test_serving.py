@@ -1,0 +1,118 @@
+"""Orchestration of DocumentAnalyzer.serve (yomitoku_amd/serving.py) with stub stages on the host: page order, waves,
+back-pressure, per-page failure isolation (cli/main.py:555-564: a failing page is reported, the job goes on).  The
+numerics of the real stages are tests/test_serving_gpu.py's."""
+import threading
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from yomitoku_amd.serving import PagePipeline
+
+
+class StubAnalyzer:
+    """Stages that only move page ids along; a page whose first pixel is 255 poisons the stage named in its second."""
+
+    STAGES = {1: "detect", 2: "boxes", 3: "recognize", 4: "layout", 5: "finish"}
+
+    def __init__(self, split=False, delay=0.0):
+        self.text_detector = SimpleNamespace(device="cpu")
+        self.split_text_across_cells = split
+        self.delay = delay
+        self.log = []
+        self.in_flight_seen = 0
+        self._live = set()
+        self._lock = threading.Lock()
+
+    def _poison(self, wave, stage):
+        for img in wave.imgs:
+            if img[0, 0, 0] == 255 and self.STAGES[int(img[0, 0, 1])] == stage:
+                raise RuntimeError(f"poisoned page in {stage}")
+
+    def _stage_detect(self, wave):
+        with self._lock:
+            self._live.add(wave.seq)
+            self.in_flight_seen = max(self.in_flight_seen, len(self._live))
+        time.sleep(self.delay)
+        self._poison(wave, "detect")
+        wave.maps = [int(img[0, 0, 2]) for img in wave.imgs]
+
+    def _stage_boxes(self, wave):
+        self._poison(wave, "boxes")
+        wave.dets = [m + 1000 for m in wave.maps]
+
+    def _stage_split(self, wave):
+        assert wave.lays is not None  # the layout chain of this wave has finished
+        wave.dets = [d + 5000 for d in wave.dets]
+
+    def _stage_recognize(self, wave):
+        time.sleep(self.delay)
+        self._poison(wave, "recognize")
+        wave.recs = [d * 2 for d in wave.dets]
+
+    def _stage_layout(self, wave):
+        time.sleep(self.delay)
+        self._poison(wave, "layout")
+        wave.lays = [len(wave)] * len(wave)
+
+    def _stage_finish(self, wave, k):
+        if wave.imgs[k][0, 0, 0] == 255 and self.STAGES[int(wave.imgs[k][0, 0, 1])] == "finish":
+            raise ValueError("poisoned page in finish")
+        with self._lock:
+            self._live.discard(wave.seq)
+        self.log.append((wave.seq, tuple(wave.ids)))
+        return (wave.ids[k], wave.recs[k], wave.lays[k])
+
+
+def page(tag, poison_stage=0):
+    img = np.zeros((4, 4, 3), dtype=np.uint8)
+    img[0, 0] = (255 if poison_stage else 0, poison_stage, tag)
+    return img
+
+
+def test_results_in_page_order_and_waves_of_the_asked_size():
+    an = StubAnalyzer(delay=0.002)
+    pipe = PagePipeline(an, wave=4, in_flight=3)
+    out = pipe.serve([page(i) for i in range(18)])
+    assert [o[0] for o in out] == list(range(18))
+    assert [o[1] for o in out] == [(i + 1000) * 2 for i in range(18)]
+    assert [o[2] for o in out] == [4] * 16 + [2] * 2  # 4 full waves and a last wave of 2
+    assert pipe.last_job == {"pages": 18, "waves": 5, "retried_pages": 0}
+    assert 1 <= an.in_flight_seen <= 3
+    assert pipe.serve([]) == []
+    pipe.close()
+
+
+@pytest.mark.parametrize("stage", [1, 2, 3, 4, 5])
+def test_a_poisoned_page_fails_alone(stage):
+    an = StubAnalyzer()
+    pipe = PagePipeline(an, wave=4, in_flight=2)
+    pages = [page(i) for i in range(10)]
+    pages[5] = page(5, poison_stage=stage)
+    out = pipe.serve(pages)
+    assert isinstance(out[5], (RuntimeError, ValueError)) and "poisoned" in str(out[5])
+    good = [i for i in range(10) if i != 5]
+    assert [out[i][0] for i in good] == good and [out[i][1] for i in good] == [(i + 1000) * 2 for i in good]
+    if stage != 5:  # the wave {4..7} was re-run page by page; aggregation failures need no re-run
+        assert pipe.last_job["retried_pages"] == 4 and pipe.last_job["waves"] == 3 + 4
+        assert [out[i][2] for i in (4, 6, 7)] == [1, 1, 1]
+    # the pipeline is still usable
+    assert [o[0] for o in pipe.serve([page(i) for i in range(3)])] == [0, 1, 2]
+    pipe.close()
+
+
+def test_bad_inputs_are_per_page_failures(tmp_path):
+    an = StubAnalyzer()
+    pipe = PagePipeline(an, wave=2, in_flight=2)
+    out = pipe.serve([page(0), str(tmp_path / "missing.png"), page(2)])
+    assert out[0][0] == 0 and out[2][0] == 2 and isinstance(out[1], Exception)
+    pipe.close()
+
+
+def test_split_text_across_cells_waits_for_the_layout_chain():
+    an = StubAnalyzer(split=True, delay=0.002)
+    pipe = PagePipeline(an, wave=3, in_flight=2)
+    out = pipe.serve([page(i) for i in range(7)])
+    assert [o[1] for o in out] == [(i + 1000 + 5000) * 2 for i in range(7)]
+    pipe.close()

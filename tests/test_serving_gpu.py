@@ -1,0 +1,112 @@
+"""DocumentAnalyzer.serve on the device: the multi-page entry point (host pages / file paths in, every result out, in
+order) must give each page what `__call__` gives it alone, keep going past a page that fails, and hold its host and
+device buffers steady (reference: the page loop and per-file error handling of cli/main.py:105-137, 555-564)."""
+import numpy as np
+import pytest
+
+from tests.test_pipeline_gpu import _assert_same_schema
+
+pytestmark = pytest.mark.gpu
+
+LITE = {
+    "ocr": {
+        "text_detector": {"from_pretrained": False},
+        "text_recognizer": {"model_name": "parseq-tiny-dynw-v4", "from_pretrained": False, "dynamic_width": True,
+                            "batch_bucketing": True, "source_downscale": True},
+    },
+    "layout_analyzer": {"layout_parser": {"from_pretrained": False}, "table_structure_recognizer": {"from_pretrained": False}},
+}
+
+
+def _analyzer(**kw):
+    from yomitoku_amd import DocumentAnalyzer
+    from yomitoku_amd.utils.synth import dbnet_state_dict, parseq_state_dict
+    from yomitoku_amd.utils.synth_rtdetr import rtdetr_state_dict
+
+    an = DocumentAnalyzer(configs=LITE, device="cuda:0", **kw)
+    an.text_detector.model.load_state_dict(dbnet_state_dict(1234, out_bias=-2.0))
+    an.text_recognizer.model.load_state_dict(parseq_state_dict(1235, eos_bias=6.0))
+    an.layout.layout_parser.model.load_state_dict(rtdetr_state_dict(1240, num_classes=6, score_bias=-2.0))
+    an.layout.table_structure_recognizer.model.load_state_dict(rtdetr_state_dict(1241, num_classes=3, score_bias=-1.0))
+    return an
+
+
+@pytest.fixture(scope="module")
+def imgs():
+    from yomitoku_amd.utils.synth import synthetic_page_with_truth
+
+    shapes = [(1000, 1400), (1400, 1000), (1000, 1400), (1200, 1600), (1000, 1400), (1400, 1000), (1000, 1400)]
+    return [synthetic_page_with_truth(3 + i, h, w)[0] for i, (h, w) in enumerate(shapes)]
+
+
+def test_serve_equals_per_page_calls_and_isolates_a_poisoned_page(dev, imgs, tmp_path):
+    from PIL import Image
+
+    an = _analyzer()
+    singles = [an(img)[0].model_dump() for img in imgs]
+    assert sum(len(s["words"]) for s in singles) > 0
+    # host arrays, a file path, a page the detector cannot take (2-D array), a file that does not exist
+    path = str(tmp_path / "page.png")
+    Image.fromarray(imgs[1][:, :, ::-1]).save(path)  # load_image returns BGR
+    sources = [imgs[0], path, imgs[2], np.zeros((50, 60), dtype=np.uint8), imgs[3], str(tmp_path / "nope.png"), imgs[4], imgs[5], imgs[6]]
+    expect = [singles[0], singles[1], singles[2], None, singles[3], None, singles[4], singles[5], singles[6]]
+    for wave, in_flight in ((4, 2), (3, 3), (8, 1)):
+        out = an.serve(sources, wave=wave, in_flight=in_flight)
+        assert len(out) == len(sources)
+        for want, got in zip(expect, out):
+            if want is None:
+                assert isinstance(got, Exception), got
+            else:
+                _assert_same_schema(want, got.model_dump())
+    assert an.serve([]) == []
+    an.close()
+
+
+def test_a_stage_failure_inside_a_wave_costs_only_its_page(dev, imgs):
+    """A page that blows up INSIDE a device stage (here: the recogniser, on the third page of the wave) fails the wave's
+    shared forward; the wave's pages are re-run one by one and only the culprit comes back as an exception."""
+    an = _analyzer()
+    singles = [an(img)[0].model_dump() for img in imgs[:5]]
+    rec = an.text_recognizer
+    inner = rec.recognize_pages
+    culprit = imgs[2].shape
+
+    def touchy(pages, points_list):
+        if any(tuple(p.shape) == culprit and int(p[0, 0, 0]) == 7 for p in pages):
+            raise RuntimeError("recogniser choked on this page")
+        return inner(pages, points_list)
+
+    rec.recognize_pages = touchy
+    bad = imgs[2].copy()
+    bad[0, 0, 0] = 7
+    out = an.serve([imgs[0], imgs[1], bad, imgs[3], imgs[4]], wave=4, in_flight=2)
+    assert isinstance(out[2], RuntimeError) and "choked" in str(out[2])
+    for i in (0, 1, 3, 4):
+        _assert_same_schema(singles[i], out[i].model_dump())
+    assert an._pipeline.last_job["retried_pages"] == 4
+    an.close()
+
+
+def test_split_text_across_cells_through_the_pipeline(dev, imgs):
+    an = _analyzer(split_text_across_cells=True)
+    singles = [an(img)[0].model_dump() for img in imgs[:4]]
+    out = an.serve(imgs[:4], wave=3, in_flight=2)
+    for want, got in zip(singles, out):
+        _assert_same_schema(want, got.model_dump())
+    an.close()
+
+
+def test_buffers_stay_put_across_jobs(dev, imgs):
+    """Ragged waves (page sizes, line counts and table counts differ from wave to wave) must not keep growing pinned host
+    memory or reallocate the models' workspaces once the largest shapes have been seen."""
+    an = _analyzer()
+    an.serve(imgs + imgs[::-1], wave=4, in_flight=2)
+    nets = (an.text_detector.model, an.text_recognizer.model, an.layout.layout_parser.model, an.layout.table_structure_recognizer.model)
+    ws = [n.workspace_bytes for n in nets]
+    pinned = sum(t.numel() for t in an.text_detector.post_processor._pinned.values())
+    for _ in range(3):
+        out = an.serve(imgs[::-1] + imgs, wave=4, in_flight=2)
+        assert not any(isinstance(o, Exception) for o in out)
+    assert [n.workspace_bytes for n in nets] == ws
+    assert sum(t.numel() for t in an.text_detector.post_processor._pinned.values()) == pinned
+    an.close()

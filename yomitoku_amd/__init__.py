@@ -8,6 +8,13 @@ Importing the package does not load the HIP library; the first module constructi
 (`yomitoku_amd._lib.load()` raises if libymk_hip.so has not been built - there is no CPU fallback).
 """
 
+import os as _os
+
+# DocumentAnalyzer.serve keeps three compute streams, a copy stream and the default stream busy at once; the HIP runtime maps
+# streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise.  The runtime reads the
+# variable when it initialises (the process's first HIP call), so it is set at import time - unless the user already chose.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 __version__ = "0.1.0"
 
 __all__ = ["DocumentAnalyzer", "OCR", "LayoutAnalyzer", "TextDetector", "TextRecognizer", "LayoutParser",

@@ -30,6 +30,7 @@ SIGNATURES = {
     "ymk_parseq_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, POINTER(c_int), POINTER(c_int), c_void_p]),
     "ymk_parseq_forward_groups": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int), POINTER(c_int), c_int, c_void_p, POINTER(c_int),
                                           POINTER(c_int), c_void_p]),
+    "ymk_parseq_reserve": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "ymk_parseq_token_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ymk_rtdetr_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ymk_det_preprocess": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

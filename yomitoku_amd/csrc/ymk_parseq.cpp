@@ -218,6 +218,37 @@ class ParseqModel : public Model {
     run(groups, ng, logits, out_len, ar_steps, s);
   }
 
+  // Size the workspace once for the largest forward the caller will ever issue (max_lines rows, each max_w wide; every
+  // buffer of run() is monotone in the row count, the token-row count and the largest group's pixels), so that
+  // ragged forwards - whose shape changes on every call - never reach hipMalloc / hipFree on the serving path.
+  void reserve(int max_lines, int max_w, hipStream_t s) {
+    YMK_CHECK(finalized, "model not finalized");
+    YMK_CHECK(max_lines > 0 && max_w >= pw_ && max_w <= img_w_, "parseq reserve: bad bounds");
+    max_w -= max_w % pw_;
+    // one group holding every line: the largest input staging buffer; the per-group tables of up to max_lines groups on top
+    const PGroup g{reinterpret_cast<const float*>(uintptr_t(4096)), max_lines, max_w};
+    arena.dry_run = true;
+    arena.reset();
+    run(&g, 1, nullptr, nullptr, nullptr, s);
+    arena.dry_run = false;
+    const size_t need = arena.used() + (size_t)nsteps_ * max_lines * sizeof(int) + 512;
+    arena.reset();
+    if (need > arena.capacity()) {
+      YMK_HIP(hipStreamSynchronize(s));
+      arena.reserve(need);
+    }
+    const size_t want = (size_t)3 * max_lines + (size_t)nsteps_ * max_lines + max_lines;
+    if (want > stage_cap_) {
+      YMK_HIP(hipStreamSynchronize(s));
+      if (stage_) YMK_HIP(hipHostFree(stage_));
+      stage_ = nullptr;
+      stage_cap_ = 0;
+      YMK_HIP(hipHostMalloc((void**)&stage_, want * sizeof(int), hipHostMallocDefault));
+      stage_cap_ = want;
+    }
+    shape_key_ = 0;
+  }
+
  private:
   void ln(hipStream_t s, const float* x, const float* g, const float* b, float eps, float* y, int M, int D) {
     layernorm(s, x, D, 0, g, b, eps, y, D, M, D);
@@ -295,7 +326,7 @@ class ParseqModel : public Model {
     if (ragged) {
       // the tables travel through a pinned staging buffer owned by the model: a forward returns only after its
       // greedy loop has been observed to finish, so the previous call's copy has long left the buffer
-      const size_t want = (size_t)3 * B + (size_t)NS * ng;  // tables out | per-step group counters back
+      const size_t want = (size_t)3 * B + (size_t)NS * ng + ng;  // tables out | per-step group counters back | group step counts out
       if (want > stage_cap_) {
         if (stage_) YMK_HIP(hipHostFree(stage_));
         stage_ = nullptr;
@@ -437,6 +468,11 @@ class ParseqModel : public Model {
           }
         ar_steps[g] = sg;
       }
+      // the refinement masks every row's context beyond ITS mini-batch's step count: the counts go back to the device
+      // (into the head of the group-counter buffer, which has been read out)
+      int* gs = back + (size_t)NS * ng;
+      for (int g = 0; g < ng; ++g) gs[g] = ar_steps[g];
+      YMK_HIP(hipMemcpyAsync(gopen, gs, (size_t)ng * sizeof(int), hipMemcpyHostToDevice, s));
     } else {
       ar_steps[0] = steps;
     }
@@ -450,7 +486,7 @@ class ParseqModel : public Model {
           row_argmax(s, logits, MR, C, raw);
           S_in = NS;
         }
-        refine_prep(s, prev_raw, NS, S_in, bos_, eos_, tok2, kpm, B);
+        refine_prep(s, prev_raw, NS, S_in, bos_, eos_, tok2, kpm, B, (it == 0 && ng > 1) ? gid : nullptr, gopen);
         ctx_embed_ln(s, tok2, NS, 0, S_in, emb_, posq_, ncg_, ncb_, 1e-5f, cn, NS, D, B);
         // project every row of the [B][NS] context buffer; rows >= S_in are stale but never attended (Lk = S_in)
         gemm(s, cn, MR, D, D, sa_kv_, ACT_NONE, nullptr, 0, skv, 2 * D);
@@ -505,6 +541,11 @@ void parseq_forward_groups(Model* m, const float* const* x, const int* b, const 
   std::vector<PGroup> g((size_t)ng);
   for (int i = 0; i < ng; ++i) g[i] = PGroup{x[i], b[i], w[i]};
   p->forward_groups(g.data(), ng, logits, out_len, ar_steps, s);
+}
+void parseq_reserve(Model* m, int max_lines, int max_w, hipStream_t s) {
+  auto* p = dynamic_cast<ParseqModel*>(m);
+  YMK_CHECK(p != nullptr, "model is not a parseq");
+  p->reserve(max_lines, max_w, s);
 }
 void parseq_dims(Model* m, int* num_steps, int* num_classes) {
   auto* p = dynamic_cast<ParseqModel*>(m);

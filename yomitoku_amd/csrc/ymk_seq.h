@@ -34,7 +34,7 @@ void greedy_step(hipStream_t s, const float* logits, long ld_b, int C, int step,
                  int* not_done, const int* prev_not_done, int* arrived, int* host_flag, int B, const int* gid = nullptr,
                  int* gopen = nullptr, int ng = 1);
 void refine_prep(hipStream_t s, const int* raw, int ld_tok, int S, int bos_id, int eos_id, int* tok2, unsigned char* kpm,
-                 int B);
+                 int B, const int* gid = nullptr, const int* gsteps = nullptr);
 void row_argmax(hipStream_t s, const float* logits, int rows, int C, int* out);
 void rep_cut(hipStream_t s, float* logits, long ld_b, int C, int S, const int* state, int eos_id, int B);
 void row_maxprob(hipStream_t s, const float* logits, int rows, int C, int* ids, float* probs);

@@ -604,21 +604,28 @@ void greedy_step(hipStream_t s, const float* logits, long ld_b, int C, int step,
 }
 
 // refinement inputs (models/parseq.py:286-292): tok2 = [bos, raw[0..S-2]]; kpm = cumsum(tok2 == eos) > 0
+// gid / gsteps (grouped forward): row b belongs to mini-batch gid[b], whose own greedy loop ran gsteps[gid[b]] <= S steps; its
+// own forward hands the refinement a context of exactly that many tokens (models/parseq.py:264-278: tgt_in is built from
+// logits[:, :-1] of ITS loop), so context positions beyond it are masked for the row - they hold what later steps of OTHER
+// mini-batches left in the shared token buffer (for a row stopped by the repetition detector that is an arg-max, not <eos>).
 __global__ void k_refine_prep(const int* __restrict__ raw, int ld_tok, int S, int bos_id, int eos_id, int* __restrict__ tok2,
-                              unsigned char* __restrict__ kpm, int B) {
+                              unsigned char* __restrict__ kpm, int B, const int* __restrict__ gid,
+                              const int* __restrict__ gsteps) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
+  const int own = gid ? gsteps[gid[b]] : S;
   bool seen = false;
   for (int t = 0; t < S; ++t) {
     const int v = t == 0 ? bos_id : raw[(size_t)b * ld_tok + t - 1];
     tok2[(size_t)b * ld_tok + t] = v;
-    seen = seen || (v == eos_id);
+    seen = seen || (v == eos_id) || t >= own;
     kpm[(size_t)b * ld_tok + t] = seen ? 1 : 0;
   }
 }
 void refine_prep(hipStream_t s, const int* raw, int ld_tok, int S, int bos_id, int eos_id, int* tok2, unsigned char* kpm,
-                 int B) {
-  hipLaunchKernelGGL(k_refine_prep, dim3((B + 63) / 64), dim3(64), 0, s, raw, ld_tok, S, bos_id, eos_id, tok2, kpm, B);
+                 int B, const int* gid, const int* gsteps) {
+  hipLaunchKernelGGL(k_refine_prep, dim3((B + 63) / 64), dim3(64), 0, s, raw, ld_tok, S, bos_id, eos_id, tok2, kpm, B, gid,
+                     gsteps);
   YMK_HIP(hipGetLastError());
 }
 

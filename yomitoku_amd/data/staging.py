@@ -26,8 +26,11 @@ class PageStager:
         self._next = 0
         self._lock = threading.Lock()
 
-    def upload(self, img: np.ndarray) -> torch.Tensor:
-        if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
+    def upload(self, img: np.ndarray, wait: bool = True) -> torch.Tensor:
+        """wait=True: the caller's current stream waits for the copy (event) before anything queued after this call.
+        wait=False: the caller orders its consumer streams itself (against an event recorded on `self.stream`) and keeps
+        the tensor alive until they are done with it (yomitoku_amd.serving does both per wave)."""
+        if not isinstance(img, np.ndarray) or img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
             raise ValueError("page must be a uint8 H x W x 3 BGR array")
         n = int(img.size)
         with self._lock:
@@ -39,15 +42,35 @@ class PageStager:
                 slot["buf"] = torch.empty(max(n, 1 << 23), dtype=torch.uint8, pin_memory=True)
             host = slot["buf"][:n].view(img.shape)
             np.copyto(host.numpy(), img)  # also makes a strided BGR view (img[:, :, ::-1]) contiguous
-            out = torch.empty(img.shape, dtype=torch.uint8, device=self.device)
             with torch.cuda.stream(self.stream):
+                # allocated on the COPY stream's pool: a block the caching allocator hands back here was freed in this
+                # stream's order (or is held back until the streams recorded on it are done), so the DMA can never
+                # overwrite data that kernels queued on the caller's stream still read
+                out = torch.empty(img.shape, dtype=torch.uint8, device=self.device)
                 out.copy_(host, non_blocking=True)
                 event = torch.cuda.Event()
                 event.record(self.stream)
             slot["event"] = event
-        torch.cuda.current_stream(self.device).wait_event(event)
-        out.record_stream(torch.cuda.current_stream(self.device))
+        if wait:
+            current = torch.cuda.current_stream(self.device)
+            current.wait_event(event)
+            out.record_stream(current)
         return out
+
+
+_default_stagers = {}
+_default_lock = threading.Lock()
+
+
+def default_stager(device) -> PageStager:
+    """The process-wide stager of a device (what imaging.page_to_device, i.e. every module's `__call__`, goes through)."""
+    device = torch.device(device)
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    with _default_lock:
+        stager = _default_stagers.get(index)
+        if stager is None:
+            stager = _default_stagers[index] = PageStager(torch.device("cuda", index), slots=4)
+    return stager
 
 
 def stream_pages(paths: Iterable[str], device, prefetch: int = 4) -> Iterator[Tuple[str, int, np.ndarray, torch.Tensor]]:

@@ -101,3 +101,42 @@ def broadcast_state_dict(sd: Mapping[str, torch.Tensor] | None, src: int = 0, de
         out[k] = host[c][off[c] : off[c] + n].reshape(s).to(getattr(torch, d)).clone()
         off[c] += n
     return out
+
+
+def state_dict_crc(sd: Mapping[str, torch.Tensor]) -> int:
+    """CRC-32 over the bytes of every tensor in key order - of what this rank actually HOLDS after the broadcast."""
+    import zlib
+
+    crc = 0
+    for k, v in sd.items():
+        crc = zlib.crc32(k.encode(), crc)
+        t = v.detach().cpu().contiguous()
+        if t.dtype == torch.bfloat16:  # numpy has no bfloat16: hash its bit pattern
+            t = t.view(torch.int16)
+        crc = zlib.crc32(t.numpy().tobytes(), crc)
+    return crc
+
+
+def all_gather_scalars(values: Sequence[float], device=None) -> List[List[float]]:
+    """Every rank's `values` on every rank (one tiny all-gather; world size 1: [[values]]).  float64 on the wire, so
+    32-bit CRCs and counters travel exactly."""
+    vals = [float(v) for v in values]
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [vals]
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    mine = torch.tensor(vals, dtype=torch.float64, device=device)
+    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    return [p.cpu().tolist() for p in parts]
+
+
+def replica_report(sds: Mapping[str, Mapping[str, torch.Tensor]], device=None) -> dict:
+    """Proof that the collective saw every rank and that every rank holds rank 0's weights: world size and backend as
+    torch.distributed reports them, and whether the per-checkpoint CRCs of all ranks agree."""
+    names = sorted(sds)
+    crcs = all_gather_scalars([state_dict_crc(sds[k]) for k in names], device)
+    world = len(crcs)
+    return {"ranks": world, "backend": dist.get_backend() if dist.is_initialized() else None,
+            "weights_crc_equal": all(c == crcs[0] for c in crcs),
+            "weights_crc": {k: f"{int(v):08x}" for k, v in zip(names, crcs[0])}}

@@ -344,7 +344,11 @@ class DocumentAnalyzer:
         self.chain_priority = _chain_priorities()
 
     # ---- aggregation (:487-601)
-    def aggregate(self, ocr_res, layout_res):
+    def aggregate(self, ocr_res, layout_res, img=None):
+        """`img` (the page, for its size): defaults to `self.img` as in the reference; the multi-page paths pass it so
+        that no page's aggregation depends on shared state."""
+        if img is None:
+            img = self.img
         paragraphs = []
         cells = [cell for table in layout_res.tables for cell in table.cells]
         word_boxes = [quad_to_xyxy(word.points) for word in ocr_res.words]
@@ -379,7 +383,7 @@ class DocumentAnalyzer:
             order = "right2left" if page_direction == "vertical" else "top2bottom"
         else:
             order = self.reading_order
-        prediction_reading_order(elements, order, self.img)
+        prediction_reading_order(elements, order, img)
         for element in elements:
             element.order += len(headers)
         for footer in footers:
@@ -439,47 +443,91 @@ class DocumentAnalyzer:
         return DocumentAnalyzerSchema(**outputs), ocr, layout
 
     # ---- several pages per call: device batches across pages (the per-page path above leaves an MI355X mostly idle:
-    # batch-1 RT-DETR / PARSeq launches are grid-starved and every page pays its own greedy-decode loop)
-    def _ocr_pages(self, pages):
-        """det -> rec chain of a wave of pages: DBNet forwards over same-size pages, one grouped PARSeq forward."""
-        dets = self.text_detector.detect_pages(pages)
-        recs = self.text_recognizer.recognize_pages(pages, [d.points for d in dets])
-        return dets, recs
+    # batch-1 RT-DETR / PARSeq launches are grid-starved and every page pays its own greedy-decode loop).  The stages of
+    # a wave (yomitoku_amd.serving.Wave) are separate methods: `analyze_pages` runs them as two concurrent chains,
+    # `serve` as a pipeline with one thread and HIP stream per stage.
+    def _stage_detect(self, wave):
+        """DBNet forwards over same-size pages of the wave; the maps come back into the wave slot's pinned buffers."""
+        wave.maps = self.text_detector.forward_pages(wave.pages, ring=wave.ring)
 
-    def _layout_pages(self, pages):
-        """layout -> table chain of a wave: one RT-DETRv2 forward over the pages, one over all their table crops."""
-        lays = self.layout.layout_parser.parse_pages(pages)
-        tables = self.layout.table_structure_recognizer.recognize_pages(pages, [[t.box for t in l.tables] for l in lays])
-        return [LayoutAnalyzerSchema(paragraphs=l.paragraphs, tables=t, figures=l.figures) for l, t in zip(lays, tables)]
+    def _stage_boxes(self, wave):
+        """DB box extraction (C++, GIL released), the pages of the wave concurrently."""
+        wave.dets = self.text_detector.extract_boxes(wave.maps, wave.sizes)
+
+    def _stage_split(self, wave):
+        wave.dets = [_split_text_across_cells(d, l) for d, l in zip(wave.dets, wave.lays)]
+
+    def _stage_recognize(self, wave):
+        """One grouped PARSeq forward over the mini-batches of all pages of the wave."""
+        wave.recs = self.text_recognizer.recognize_pages(wave.pages, [d.points for d in wave.dets])
+
+    def _stage_layout(self, wave):
+        """One RT-DETRv2 forward over the pages, one over all their table crops."""
+        lays = self.layout.layout_parser.parse_pages(wave.pages)
+        tables = self.layout.table_structure_recognizer.recognize_pages(wave.pages, [[t.box for t in l.tables] for l in lays])
+        wave.lays = [LayoutAnalyzerSchema(paragraphs=l.paragraphs, tables=t, figures=l.figures) for l, t in zip(lays, tables)]
+
+    def _stage_finish(self, wave, k):
+        """Aggregation of page k of the wave -> DocumentAnalyzerSchema."""
+        results_ocr = OCRSchema(words=ocr_aggregate(wave.dets[k], wave.recs[k]))
+        return DocumentAnalyzerSchema(**self.aggregate(results_ocr, wave.lays[k], img=wave.imgs[k]))
+
+    def _ocr_wave(self, wave):
+        self._stage_detect(wave)
+        self._stage_boxes(wave)
+        if not self.split_text_across_cells:
+            self._stage_recognize(wave)
 
     def analyze_pages(self, imgs, wave: int = 8):
         """`__call__` over a list of pages, `wave` pages at a time on the device.  Every page's result is what
         `__call__(img)` returns for it (pages never interact: batches are per-image independent, recogniser
         mini-batches are formed per page); what changes is how the launches are shared.  The two chains of a wave
-        run concurrently on their own HIP streams, as in `run`.  Returns [(DocumentAnalyzerSchema, None, None), ...]."""
+        run concurrently on their own HIP streams, as in `run`.  Returns [(DocumentAnalyzerSchema, None, None), ...].
+        One wave at a time: `serve` is the throughput path (several waves in flight, failures isolated per page)."""
+        from .serving import Wave
+
         if self.visualize:
             raise NotImplementedError("visualisation is out of scope of the MI355X path (visualize=False only)")
         dev = self.text_detector.device
         out = []
-        for start in range(0, len(imgs), max(1, int(wave))):
-            chunk = imgs[start : start + max(1, int(wave))]
+        size = max(1, int(wave))
+        for start in range(0, len(imgs), size):
+            chunk = imgs[start : start + size]
             pages = [img if isinstance(img, torch.Tensor) else imaging.page_to_device(img, dev) for img in chunk]
+            w = Wave(start // size, range(start, start + len(chunk)), chunk, pages)
+            f_ocr = self._submit("ocr", self._ocr_wave, w)
+            f_lay = self._submit("layout", self._stage_layout, w)
+            f_ocr.result()
+            f_lay.result()
             if self.split_text_across_cells:
-                f_det = self._submit("ocr", self.text_detector.detect_pages, pages)
-                f_lay = self._submit("layout", self._layout_pages, pages)
-                dets, lays = f_det.result(), f_lay.result()
-                dets = [_split_text_across_cells(d, l) for d, l in zip(dets, lays)]
-                recs = self._submit("ocr", self.text_recognizer.recognize_pages, pages, [d.points for d in dets]).result()
-            else:
-                f_ocr = self._submit("ocr", self._ocr_pages, pages)
-                f_lay = self._submit("layout", self._layout_pages, pages)
-                dets, recs = f_ocr.result()
-                lays = f_lay.result()
-            for img, det, rec, lay in zip(chunk, dets, recs, lays):
-                self.img = img
-                results_ocr = OCRSchema(words=ocr_aggregate(det, rec))
-                out.append((DocumentAnalyzerSchema(**self.aggregate(results_ocr, lay)), None, None))
+                self._stage_split(w)
+                self._submit("ocr", self._stage_recognize, w).result()
+            out.extend((self._stage_finish(w, k), None, None) for k in range(len(chunk)))
         return out
+
+    def serve(self, sources, wave: int = 8, in_flight: int = 3):
+        """The multi-page entry point: host pages (uint8 H x W x 3 BGR arrays) and / or image file paths in, one result
+        per page out, in page order - the page loop of cli/main.py:105-137 as a stage pipeline on one GPU from one
+        process (yomitoku_amd/serving.py): pinned staging + H2D on a copy stream, `wave` pages per device batch, up to
+        `in_flight` waves between upload and aggregation.  A page's entry is its DocumentAnalyzerSchema - equal to
+        `__call__(img)[0]` - or, when the page (or its file) failed, the exception object; the other pages are not
+        affected (cli/main.py:555-564)."""
+        from .serving import PagePipeline
+
+        if self.visualize:
+            raise NotImplementedError("visualisation is out of scope of the MI355X path (visualize=False only)")
+        pipe = getattr(self, "_pipeline", None)
+        if pipe is None or (pipe.wave, pipe.in_flight) != (max(1, int(wave)), max(1, int(in_flight))):
+            if pipe is not None:
+                pipe.close()
+            pipe = self._pipeline = PagePipeline(self, wave=wave, in_flight=in_flight)
+        return pipe.serve(sources)
+
+    def close(self):
+        pipe = getattr(self, "_pipeline", None)
+        if pipe is not None:
+            pipe.close()
+            self._pipeline = None
 
     def __call__(self, img):
         self.img = img

@@ -33,11 +33,12 @@ def resize_shortest_edge_dims(h: int, w: int, shortest_edge_length: int, max_len
 
 
 def page_to_device(img: np.ndarray, device) -> torch.Tensor:
-    """uint8 H x W x 3 BGR page -> contiguous device tensor (one H2D copy per page, from pageable memory: the
-    synchronous form.  yomitoku_amd.data.PageStager is the pinned, asynchronous one for streams of pages)."""
-    if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
-        raise ValueError("page must be a uint8 H x W x 3 BGR array")
-    return torch.from_numpy(np.ascontiguousarray(img)).to(device, non_blocking=True)
+    """uint8 H x W x 3 BGR page -> contiguous device tensor: one H2D copy per page through the device's pinned staging
+    ring on the copy stream (yomitoku_amd.data.PageStager); the caller's current stream waits on the copy's event, the
+    host does not."""
+    from .data.staging import default_stager
+
+    return default_stager(device).upload(img)
 
 
 def detector_tensor(page_dev: torch.Tensor, shortest: int, limit: int, out: torch.Tensor = None) -> torch.Tensor:

@@ -1,0 +1,268 @@
+"""Multi-page serving on ONE GPU from ONE process: host pages in, every page's result out, in page order.
+
+The reference's unit of use is "file in -> all page results out" (cli/main.py:105-137): the page loop calls the
+analyzer once per page and a failing file is logged and skipped (cli/main.py:555-564).  On an MI355X one page at a time
+leaves the device mostly idle, so `DocumentAnalyzer.serve` runs the page loop as a STAGE PIPELINE over waves of pages:
+
+    caller thread   decode (paths) -> pinned staging ring -> H2D on the copy stream              (PageStager)
+    detect          DBNet forwards over the wave, maps back in one DMA per forward               HIP stream 1
+    boxes           DB box extraction, C++, GIL released                                         host
+    recognize       crop kernels + ONE grouped PARSeq forward with one greedy loop per wave      HIP stream 2
+    layout          RT-DETRv2 layout forward over the wave + table-structure forward over crops  HIP stream 3
+    finish          word -> cell / paragraph aggregation and reading order, per page             host
+
+Every network exists ONCE (no replicas): a model handle is only ever used by its own stage thread, which is what
+include/ymk.h asks for, and the three compute streams plus the copy stream fit the HIP runtime's hardware queues.
+Wave k + 1 is in the detector while wave k decodes text and its tables are parsed; up to `in_flight` waves are between
+upload and aggregation (a ring of pinned map buffers per wave slot), which bounds host and device memory.
+
+Failure isolation: a stage that raises marks its wave failed; the pages of a failed wave are re-run as single-page
+waves through the same pipeline, and a page that fails alone gets the exception object as its result - the job goes
+on (the reference's per-file `except: log, continue`).  Results equal `DocumentAnalyzer.__call__` page by page
+(tests/test_serving_gpu.py)."""
+
+from __future__ import annotations
+
+import logging
+import queue
+import threading
+from collections import deque
+from typing import Iterable, List, Optional
+
+import numpy as np
+import torch
+
+from .data.staging import PageStager
+
+logger = logging.getLogger(__name__)
+
+_STOP = object()
+
+
+class Wave:
+    """The pages that share device batches, and what the stages have produced for them so far."""
+
+    __slots__ = ("seq", "ids", "imgs", "pages", "ring", "uploaded", "maps", "sizes", "dets", "recs", "lays", "error",
+                 "failed_stage", "layout_done", "joined", "retry")
+
+    def __init__(self, seq=0, ids=(), imgs=(), pages=(), ring=0, uploaded=None, retry=False):
+        self.seq, self.ids, self.imgs, self.pages, self.ring, self.uploaded = seq, list(ids), list(imgs), list(pages), ring, uploaded
+        self.sizes = [tuple(int(v) for v in p.shape[:2]) for p in self.pages]
+        self.maps = self.dets = self.recs = self.lays = None
+        self.error: Optional[BaseException] = None
+        self.failed_stage = None
+        self.layout_done = threading.Event()
+        self.joined = 0
+        self.retry = retry
+
+    def __len__(self):
+        return len(self.ids)
+
+    def fail(self, stage, exc):
+        if self.error is None:
+            self.error, self.failed_stage = exc, stage
+
+
+class _Job:
+    """One serve() call: where results go and how many waves are still out."""
+
+    def __init__(self, n_hint=0):
+        self.results = {}
+        self.cond = threading.Condition()
+        self.outstanding = 0
+        self.retries: "deque" = deque()  # (page id, host page) to re-run alone
+        self.waves = 0
+        self.retried_pages = 0
+
+
+class PagePipeline:
+    def __init__(self, analyzer, wave: int = 8, in_flight: int = 3):
+        self.analyzer = analyzer
+        self.wave = max(1, int(wave))
+        self.in_flight = max(1, int(in_flight))
+        self.device = torch.device(analyzer.text_detector.device)
+        # a HIP device always, for DocumentAnalyzer (BaseModule refuses anything else); the host-only form exists so that
+        # the orchestration (ordering, back-pressure, retries) can be tested with stub stages on a box without a GPU
+        self._gpu = self.device.type == "cuda"
+        self.stager = PageStager(self.device, slots=self.wave * (self.in_flight + 1)) if self._gpu else None
+        self._rings: "queue.Queue" = queue.Queue()
+        for r in range(self.in_flight):
+            self._rings.put(r)
+        self._q = {name: queue.Queue() for name in ("detect", "boxes", "recognize", "layout", "finish")}
+        self._job: Optional[_Job] = None
+        self._seq = 0
+        self._serve_lock = threading.Lock()
+        a = analyzer
+        plan = (("detect", a._stage_detect, True, ("boxes",)), ("boxes", self._boxes, False, ("recognize",)),
+                ("recognize", a._stage_recognize, True, ("finish",)), ("layout", self._layout, True, ("finish",)),
+                ("finish", self._finish, False, ()))
+        self._threads = [threading.Thread(target=self._loop, args=spec, name=f"ymk-{spec[0]}", daemon=True) for spec in plan]
+        for t in self._threads:
+            t.start()
+
+    # ------------------------------------------------------------------ stage threads
+    def _loop(self, name, fn, on_gpu, outs):
+        stream = None
+        if on_gpu and self._gpu:
+            torch.cuda.set_device(self.device)
+            stream = torch.cuda.Stream(device=self.device)
+        q_in = self._q[name]
+        while True:
+            wave = q_in.get()
+            if wave is _STOP:
+                return
+            if name == "finish":
+                wave.joined += 1
+                if wave.joined < 2:  # arrives once from the recognise chain and once from the layout chain
+                    continue
+            if wave.error is None or name == "finish":
+                try:
+                    if stream is not None:
+                        with torch.cuda.stream(stream):
+                            stream.wait_event(wave.uploaded)
+                            fn(wave)
+                            stream.synchronize()
+                    else:
+                        fn(wave)
+                except BaseException as exc:  # noqa: BLE001 - delivered to the page's result slot
+                    wave.fail(name, exc)
+                    if name == "finish":  # cannot happen short of a bug in _finish itself: never lose a page or a slot
+                        for idx in wave.ids:
+                            self._job.results.setdefault(idx, exc)
+                        if wave.pages is not None:
+                            self._release(wave)
+            if name == "layout":
+                wave.layout_done.set()
+            for out in outs:
+                self._q[out].put(wave)
+
+    def _boxes(self, wave):
+        a = self.analyzer
+        a._stage_boxes(wave)
+        if a.split_text_across_cells:
+            wave.layout_done.wait()
+            if wave.error is None:
+                a._stage_split(wave)
+
+    def _layout(self, wave):
+        self.analyzer._stage_layout(wave)
+
+    def _release(self, wave):
+        job = self._job
+        wave.pages = wave.maps = None  # the device pages and the pinned map views go back
+        self._rings.put(wave.ring)
+        with job.cond:
+            job.outstanding -= 1
+            job.cond.notify_all()
+
+    def _finish(self, wave):
+        job = self._job
+        if wave.error is not None:
+            if len(wave) > 1:
+                logger.warning("wave of %d pages failed in stage %s (%s: %s); re-running its pages one by one", len(wave),
+                               wave.failed_stage, type(wave.error).__name__, wave.error)
+                with job.cond:
+                    job.retries.extend(zip(wave.ids, wave.imgs))
+            else:
+                logger.error("page %d failed in stage %s: %s: %s", wave.ids[0], wave.failed_stage, type(wave.error).__name__,
+                             wave.error)
+                job.results[wave.ids[0]] = wave.error
+        else:
+            for k, idx in enumerate(wave.ids):
+                try:
+                    job.results[idx] = self.analyzer._stage_finish(wave, k)
+                except Exception as exc:  # noqa: BLE001 - aggregation is per page: only this page fails
+                    logger.error("page %d failed in aggregation: %s: %s", idx, type(exc).__name__, exc)
+                    job.results[idx] = exc
+        self._release(wave)
+
+    # ------------------------------------------------------------------ caller side
+    def _launch(self, job, ids, imgs, retry=False):
+        ring = self._rings.get()  # blocks while `in_flight` waves are out: back-pressure on decoding and staging
+        try:
+            if self._gpu:
+                pages = [self.stager.upload(img, wait=False) for img in imgs]
+                uploaded = torch.cuda.Event()
+                uploaded.record(self.stager.stream)
+            else:
+                pages, uploaded = list(imgs), None
+        except BaseException:
+            self._rings.put(ring)
+            raise
+        self._seq += 1
+        wave = Wave(self._seq, ids, imgs, pages, ring, uploaded, retry)
+        with job.cond:
+            job.outstanding += 1
+            job.waves += 1
+        self._q["detect"].put(wave)
+        self._q["layout"].put(wave)
+
+    def serve(self, sources: Iterable) -> List:
+        """sources: uint8 H x W x 3 BGR arrays and / or image file paths (a multi-frame file contributes one entry per
+        frame).  Returns one entry per page, in order: the DocumentAnalyzerSchema, or the exception that page (or
+        file) raised."""
+        from .data.functions import load_image
+
+        with self._serve_lock:
+            job = self._job = _Job()
+            n = 0
+            pend_ids, pend_imgs = [], []
+
+            def flush():
+                nonlocal pend_ids, pend_imgs
+                if pend_ids:
+                    ids, imgs, pend_ids, pend_imgs = pend_ids, pend_imgs, [], []
+                    try:
+                        self._launch(job, ids, imgs)
+                    except Exception as exc:  # noqa: BLE001 - e.g. a page that is not uint8 H x W x 3
+                        if len(ids) == 1:
+                            job.results[ids[0]] = exc
+                        else:
+                            with job.cond:
+                                job.retries.extend(zip(ids, imgs))
+
+            def drain_retries():
+                while True:
+                    with job.cond:
+                        if not job.retries:
+                            return
+                        idx, img = job.retries.popleft()
+                        job.retried_pages += 1
+                    try:
+                        self._launch(job, [idx], [img], retry=True)
+                    except Exception as exc:  # noqa: BLE001
+                        job.results[idx] = exc
+
+            for src in sources:
+                if isinstance(src, np.ndarray):
+                    frames = [src]
+                else:
+                    try:
+                        frames = list(load_image(src))
+                    except Exception as exc:  # noqa: BLE001 - cli/main.py:555-564: log, go on with the next file
+                        logger.error("cannot load %s: %s: %s", src, type(exc).__name__, exc)
+                        job.results[n] = exc
+                        n += 1
+                        continue
+                for frame in frames:
+                    pend_ids.append(n)
+                    pend_imgs.append(frame)
+                    n += 1
+                    if len(pend_ids) == self.wave:
+                        drain_retries()
+                        flush()
+            flush()
+            while True:
+                drain_retries()
+                with job.cond:
+                    if job.outstanding == 0 and not job.retries:
+                        break
+                    job.cond.wait(timeout=0.05)
+            self.last_job = {"pages": n, "waves": job.waves, "retried_pages": job.retried_pages}
+            return [job.results[i] for i in range(n)]
+
+    def close(self):
+        for q in self._q.values():
+            q.put(_STOP)
+        for t in self._threads:
+            t.join(timeout=10)

@@ -5,6 +5,7 @@ DBNet forward run on the MI355X; the DB box extraction runs in the C++ host code
 from __future__ import annotations
 
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -35,13 +36,20 @@ class DBnetPostProcessor:
         self.unclip_ratio = unclip_ratio
         self._pinned = {}
 
-    def maps_to_host(self, maps: torch.Tensor, slot: int = 0) -> np.ndarray:
+    def _pinned_floats(self, key, count):
+        """Growable flat pinned buffer named `key`: one per (wave slot, forward of the wave) or per single-page caller -
+        never one per map SHAPE, so arbitrary scan sizes do not accumulate pinned host memory."""
+        host = self._pinned.get(key)
+        if host is None or host.numel() < count:
+            host = self._pinned[key] = torch.empty(max(int(count), 1 << 20), dtype=torch.float32, pin_memory=True)
+        return host[:count]
+
+    def maps_to_host(self, maps: torch.Tensor, slot=0) -> np.ndarray:
         """n x 1 x H x W device maps -> one pinned host array n x H x W (one DMA for the whole batch).  `slot` names the
-        pinned buffer: forwards of one call whose maps must stay valid together use different slots."""
+        pinned buffer: forwards whose maps must stay valid together (the forwards of one wave, the waves in flight of
+        DocumentAnalyzer.serve) use different slots."""
         shape = (maps.shape[0], maps.shape[2], maps.shape[3])
-        host = self._pinned.get((slot,) + shape)
-        if host is None:
-            host = self._pinned[(slot,) + shape] = torch.empty(shape, dtype=torch.float32, pin_memory=True)
+        host = self._pinned_floats(("maps", slot), shape[0] * shape[1] * shape[2]).view(shape)
         host.copy_(maps.detach().to(torch.float32).reshape(shape), non_blocking=True)
         torch.cuda.current_stream(maps.device).synchronize()
         return host.numpy()
@@ -52,11 +60,9 @@ class DBnetPostProcessor:
             pred = pred[0, 0]
         if isinstance(pred, torch.Tensor):
             if pred.is_cuda:
-                # one DMA into a pinned buffer kept per map shape (a pageable destination is copied in ~32 KB
-                # staging chunks: ~250 copy kernels and 2.7 ms for the 7.6 MB map)
-                host = self._pinned.get(tuple(pred.shape))
-                if host is None:
-                    host = self._pinned[tuple(pred.shape)] = torch.empty(pred.shape, dtype=torch.float32, pin_memory=True)
+                # one DMA into a pinned buffer (a pageable destination is copied in ~32 KB staging chunks: ~250 copy
+                # kernels and 2.7 ms for the 7.6 MB map)
+                host = self._pinned_floats(("page", threading.get_ident()), pred.numel()).view(pred.shape)
                 host.copy_(pred.detach().to(torch.float32), non_blocking=True)
                 torch.cuda.current_stream(pred.device).synchronize()
                 pred = host.numpy()
@@ -104,11 +110,11 @@ class TextDetector(BaseModule):
 
     MAX_PAGES_PER_FORWARD = 8  # bounds the activation workspace (a 1600 x 1184 page holds ~2 GB of fp32 maps)
 
-    def forward_pages(self, imgs):
+    def forward_pages(self, imgs, ring=0):
         """Pre-processing + DBNet forward for several pages: pages whose network input has the same size share forwards
         of up to MAX_PAGES_PER_FORWARD images (images of a batch are independent); the probability maps of a forward
         come back in one DMA.  Returns one host map (H' x W' float32, a view of a pinned buffer that the next
-        forward_pages call of this module reuses) per page, in input order."""
+        forward_pages call of this module WITH THE SAME `ring` reuses) per page, in input order."""
         pages = [img if isinstance(img, torch.Tensor) else imaging.page_to_device(img, self.device) for img in imgs]
         cfg = self._cfg.data
         by_size = {}
@@ -123,7 +129,7 @@ class TextDetector(BaseModule):
                 x = torch.empty((len(idx), 3, oh, ow), dtype=torch.float32, device=pages[idx[0]].device)
                 for k, i in enumerate(idx):
                     imaging.detector_tensor(pages[i], cfg.shortest_size, cfg.limit_size, out=x[k])
-                host = self.post_processor.maps_to_host(self.model(x)["binary"], slot)
+                host = self.post_processor.maps_to_host(self.model(x)["binary"], (ring, slot))
                 slot += 1
                 for k, i in enumerate(idx):
                     maps[i] = host[k]

@@ -267,6 +267,11 @@ class TextRecognizer(BaseModule):
         `__call__` (bucketing, width budget, padding), then ALL of them go through shared PARSeq forwards
         (`_infer_groups`).  Returns one TextRecognizerSchema per page; a page's result does not depend on its
         neighbours (mini-batches never mix pages)."""
+        if not getattr(self, "_workspace_reserved", False):
+            # multi-page serving: size the PARSeq workspace once for the largest grouped forward, so that no wave - however
+            # its lines fall into mini-batches - reaches hipMalloc / hipFree (tiny: ~12 GB, large-v4_1: ~23 GB of 288 GB)
+            self.model.reserve(self.MAX_LINES_PER_FORWARD, int(self._cfg.data.img_size[1]), self.device)
+            self._workspace_reserved = True
         preps = [self.preprocess(img, pts) for img, pts in zip(imgs, points_list)]
         jobs, spans = [], []
         for batches, _, dataset, _ in preps:
