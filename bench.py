@@ -199,17 +199,25 @@ def build_analyzer(device, sds, model_set="lite"):
             if self.stats is not None:
                 self.stats["det_boxes"].extend(len(b.points) for b in boxes)
 
-        # _stage_recognize is the product's, on the true text-line quads
-        def _stage_layout(self, wave):
+        # _stage_crops / _stage_recognize / _stage_decode are the product's, on the true text-line quads;
+        # _stage_layout (layout forward over the wave) is the product's too
+        def _stage_tables(self, wave):
             truth = self._truth(wave)
-            noise = self.layout.layout_parser.parse_pages(wave.pages)  # full layout stage, result not propagated
-            tables = self.layout.table_structure_recognizer.recognize_pages(wave.pages, [t.tables for t in truth])
+            noise = self.layout.layout_parser.pages_from_raw(wave.lay_raw)  # full layout post-processing, result not propagated
+            wave.lay_raw = None
+            wave.tab_raw = self.layout.table_structure_recognizer.forward_tables(wave.pages, [t.tables for t in truth])
+            if self.stats is not None:
+                self.stats["layout_boxes"].extend(len(n.paragraphs) + len(n.tables) + len(n.figures) for n in noise)
+
+        def _stage_cells(self, wave):
+            truth = self._truth(wave)
+            tables = self.layout.table_structure_recognizer.tables_from_raw(wave.tab_raw, len(wave.pages))
+            wave.tab_raw = None
             wave.lays = []
             for t, tb in zip(truth, tables):
                 paragraphs = [Element(id=None, box=b, score=1.0, role=None, contents=None) for b in t.paragraphs]
                 wave.lays.append(LayoutAnalyzerSchema(paragraphs=paragraphs, tables=tb, figures=[]))
             if self.stats is not None:
-                self.stats["layout_boxes"].extend(len(n.paragraphs) + len(n.tables) + len(n.figures) for n in noise)
                 self.stats["cells"].extend(sum(len(x.cells) for x in tb) for tb in tables)
 
     an = TruthDrivenAnalyzer(configs=MODEL_SETS[model_set], device=str(device))

@@ -43,6 +43,12 @@ void ymk_model_destroy(ymk_model* m);
 int ymk_model_set_param(ymk_model* m, const char* key, double value);
 int ymk_model_set_tensor(ymk_model* m, const char* name, const float* host_data, int ndim, const int64_t* dims);
 int ymk_model_finalize(ymk_model* m);
+/* Size the model's workspace once for the largest forward the caller will issue, so that forwards within the bound
+ * never allocate or free device memory whatever their shape ("allocates nothing on the per-call path" also for calls
+ * whose shape changes every time: the pages of a wave differ in size, the mini-batches of text_recognizer.py:158-203
+ * differ in rows and width).  dbnet: n images of h x w (either orientation); rtdetr: n images of h x w; parseq: n
+ * text lines over all groups of a call, each at most w pixels wide (h ignored). */
+int ymk_model_reserve(ymk_model* m, int n, int h, int w, void* stream);
 /* bytes of HBM held by the model's weights / workspace */
 int64_t ymk_model_weight_bytes(const ymk_model* m);
 int64_t ymk_model_workspace_bytes(const ymk_model* m);
@@ -72,11 +78,6 @@ int ymk_parseq_forward(ymk_model* m, const float* x_dev, int b, int w, float* lo
  * group order.  out_len[g] / ar_steps[g] are what group g's own ymk_parseq_forward call would have returned. */
 int ymk_parseq_forward_groups(ymk_model* m, const float* const* x_dev, const int* b, const int* w, int n_groups,
                               float* logits_dev, int* out_len, int* ar_steps, void* stream);
-/* Size the model's workspace once for the largest forward the caller will issue: max_lines rows (over all groups of a
- * call), each at most max_width pixels wide.  After it, forwards within those bounds never allocate or free device
- * memory, whatever their shape (the mini-batches of text_recognizer.py:158-203 differ in size and width on every
- * page) - which is what the "allocates nothing on the per-call path" rule above needs for ragged calls. */
-int ymk_parseq_reserve(ymk_model* m, int max_lines, int max_width, void* stream);
 /* what ParseqTokenizer.decode needs from softmax(logits) (parseq_tokenizer.py:79-87) without
  * materialising it: per row the arg-max class id and max probability. rows = b * out_len. */
 int ymk_parseq_token_stats(const float* logits_dev, int rows, int num_classes, int* ids_dev, float* probs_dev,

@@ -289,3 +289,32 @@ def test_nested_configs_reach_the_modules(dev, tmp_path):
     assert an.layout.table_structure_recognizer.thresh_score == 0.8
     ocr = OCR(configs=configs["ocr"], device="cuda:0")
     assert ocr.detector.post_processor.thresh == 0.4 and ocr.recognizer.model.refine_iters == 0
+
+
+def test_degenerate_quad_gets_a_placeholder_and_the_outputs_stay_aligned(dev, page, caplog):
+    """A quad that passes validate_quads but whose first edge is shorter than one pixel cannot be cropped (the reference
+    hands OpenCV an empty dsize).  It is reported as an empty string with score 0 - loudly - so that contents / scores /
+    directions keep lining up with `points` and the page's other lines are what they are without it."""
+    import logging
+
+    from yomitoku_amd.text_recognizer import TextRecognizer
+    from yomitoku_amd.utils.synth import parseq_state_dict
+
+    img, quads, _ = page
+    quads = [list(map(list, q)) for q in quads[:9]]
+    rec = TextRecognizer(model_name="parseq-tiny-dynw-v4", from_pretrained=False, device="cuda:0", dynamic_width=True,
+                         batch_bucketing=True)
+    rec.model.load_state_dict(parseq_state_dict(1235, eos_bias=6.0))
+    rec.batch_bucketing = False  # the call with a dropped quad below runs un-bucketed too (text_recognizer.py:139)
+    clean, _ = rec(img, quads)
+    rec.batch_bucketing = True
+    bad = [[50, 60], [50, 60], [50, 200], [50, 200]]  # zero-length first edge, tall: "vertical"
+    with caplog.at_level(logging.WARNING, logger="yomitoku_amd.text_recognizer"):
+        mixed, _ = rec(img, quads[:4] + [bad] + quads[4:])
+    assert "shorter" in caplog.text
+    assert len(mixed.contents) == len(mixed.scores) == len(mixed.directions) == len(mixed.points) == 10
+    assert (mixed.contents[4], mixed.scores[4], mixed.directions[4]) == ("", 0.0, "vertical")
+    # the other lines went through the same mini-batches in the same order: same strings
+    assert mixed.contents[:4] + mixed.contents[5:] == clean.contents
+    many = rec.recognize_pages([img], [quads[:4] + [bad] + quads[4:]])[0]
+    assert many.contents == mixed.contents and many.directions == mixed.directions

@@ -14,7 +14,7 @@ from yomitoku_amd.serving import PagePipeline
 class StubAnalyzer:
     """Stages that only move page ids along; a page whose first pixel is 255 poisons the stage named in its second."""
 
-    STAGES = {1: "detect", 2: "boxes", 3: "recognize", 4: "layout", 5: "finish"}
+    STAGES = {1: "detect", 2: "boxes", 3: "recognize", 4: "layout", 5: "finish", 6: "crops", 7: "decode", 8: "tables", 9: "cells"}
 
     def __init__(self, split=False, delay=0.0):
         self.text_detector = SimpleNamespace(device="cpu")
@@ -46,15 +46,31 @@ class StubAnalyzer:
         assert wave.lays is not None  # the layout chain of this wave has finished
         wave.dets = [d + 5000 for d in wave.dets]
 
+    def _stage_crops(self, wave):
+        self._poison(wave, "crops")
+        wave.rec_plan = list(wave.dets)
+
     def _stage_recognize(self, wave):
         time.sleep(self.delay)
         self._poison(wave, "recognize")
-        wave.recs = [d * 2 for d in wave.dets]
+        wave.rec_plan = [d * 2 for d in wave.rec_plan]
+
+    def _stage_decode(self, wave):
+        self._poison(wave, "decode")
+        wave.recs = wave.rec_plan
 
     def _stage_layout(self, wave):
         time.sleep(self.delay)
         self._poison(wave, "layout")
-        wave.lays = [len(wave)] * len(wave)
+        wave.lay_raw = len(wave)
+
+    def _stage_tables(self, wave):
+        self._poison(wave, "tables")
+        wave.tab_raw = wave.lay_raw
+
+    def _stage_cells(self, wave):
+        self._poison(wave, "cells")
+        wave.lays = [wave.tab_raw] * len(wave)
 
     def _stage_finish(self, wave, k):
         if wave.imgs[k][0, 0, 0] == 255 and self.STAGES[int(wave.imgs[k][0, 0, 1])] == "finish":
@@ -84,7 +100,7 @@ def test_results_in_page_order_and_waves_of_the_asked_size():
     pipe.close()
 
 
-@pytest.mark.parametrize("stage", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("stage", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_a_poisoned_page_fails_alone(stage):
     an = StubAnalyzer()
     pipe = PagePipeline(an, wave=4, in_flight=2)
@@ -115,4 +131,28 @@ def test_split_text_across_cells_waits_for_the_layout_chain():
     pipe = PagePipeline(an, wave=3, in_flight=2)
     out = pipe.serve([page(i) for i in range(7)])
     assert [o[1] for o in out] == [(i + 1000 + 5000) * 2 for i in range(7)]
+    pipe.close()
+
+
+def test_full_collections_are_deferred_during_a_job_and_restored_after():
+    """A generation-2 pass of the cyclic collector holds the GIL while it walks every live container (100+ ms with a
+    few hundred page results alive): serve() postpones it for the duration of the job and puts the thresholds back."""
+    import gc
+
+    before = gc.get_threshold()
+    seen = []
+
+    class Spy(StubAnalyzer):
+        def _stage_detect(self, wave):
+            seen.append(gc.get_threshold())
+            super()._stage_detect(wave)
+
+    pipe = PagePipeline(Spy(), wave=2, in_flight=2)
+    pipe.serve([page(i) for i in range(4)])
+    assert all(t[:2] == before[:2] and t[2] >= 1 << 30 for t in seen) and len(seen) == 2
+    assert gc.get_threshold() == before
+    pipe.defer_full_gc = False
+    seen.clear()
+    pipe.serve([page(i) for i in range(2)])
+    assert seen == [before]
     pipe.close()

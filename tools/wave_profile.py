@@ -19,12 +19,17 @@ SET = os.environ.get("SET", "lite")
 sds = bench.make_checkpoints(SET)
 pages = bench.make_pages(range(1000, 1000 + 2 * W), dev)
 sds = bench.calibrate_heads(sds, dev, bench.Page(0, dev))
-run = bench.build_analyzer(dev, sds, SET)
-an = run.analyzer
+an = bench.build_analyzer(dev, sds, SET)
+an.truth = pages
 an.concurrent_chains = False
 wave = pages[:W]
+
+
+def run(ws):
+    return an.analyze_pages([p.dev for p in ws], wave=len(ws))  # page ids 0.. line up with an.truth for the first wave
+
+
 run(wave)
-run(pages[W:])
 torch.cuda.synchronize()
 
 
@@ -39,7 +44,6 @@ def T(label, f, *a):
     return r
 
 
-an.truth = {p.dev.data_ptr(): p for p in wave}
 devs = [p.dev for p in wave]
 det, rec = an.text_detector, an.text_recognizer
 maps = T("det.forward_pages (+D2H)", det.forward_pages, devs)
@@ -64,8 +68,10 @@ preds = T("  tables: forward", ts.model, xb)
 lg, bx = T("  tables: D2H", lambda: (preds["pred_logits"].cpu().numpy(), preds["pred_boxes"].cpu().numpy()))
 T("  tables: postprocess", lambda: [ts.postprocess({"pred_logits": lg[k:k+1], "pred_boxes": bx[k:k+1]}, {"size": m[0], "offset": m[1]}) for k, m in enumerate(metas)])
 print("tables in wave", sum(len(p.tables) for p in wave))
-T("_ocr_pages", an._ocr_pages, devs)
-lays = T("_layout_pages", an._layout_pages, devs)
+from yomitoku_amd.serving import Wave
+
+T("_ocr_wave", an._ocr_wave, Wave(0, range(W), devs, devs))
+T("_layout_wave", an._layout_wave, Wave(0, range(W), devs, devs))
 T("wave total (serial chains)", run, wave)
 an.concurrent_chains = True
 T("wave total (2 streams)", run, wave)

@@ -23,6 +23,7 @@ SIGNATURES = {
     "ymk_model_set_param": (c_int, [c_void_p, c_char_p, c_double]),
     "ymk_model_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, c_int, POINTER(c_int64)]),
     "ymk_model_finalize": (c_int, [c_void_p]),
+    "ymk_model_reserve": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "ymk_model_weight_bytes": (c_int64, [c_void_p]),
     "ymk_model_workspace_bytes": (c_int64, [c_void_p]),
     "ymk_dbnet_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -30,7 +31,6 @@ SIGNATURES = {
     "ymk_parseq_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, POINTER(c_int), POINTER(c_int), c_void_p]),
     "ymk_parseq_forward_groups": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int), POINTER(c_int), c_int, c_void_p, POINTER(c_int),
                                           POINTER(c_int), c_void_p]),
-    "ymk_parseq_reserve": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "ymk_parseq_token_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ymk_rtdetr_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ymk_det_preprocess": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

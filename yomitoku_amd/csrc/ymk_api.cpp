@@ -10,7 +10,6 @@ void parseq_forward(Model* m, const float* x, int B, int W, float* logits, int* 
 void parseq_forward_groups(Model* m, const float* const* x, const int* b, const int* w, int ng, float* logits, int* out_len,
                            int* ar_steps, hipStream_t s);
 void parseq_dims(Model* m, int* num_steps, int* num_classes);
-void parseq_reserve(Model* m, int max_lines, int max_w, hipStream_t s);
 Model* create_parseq();
 Model* create_rtdetr();
 void rtdetr_forward(Model* m, const float* x, int B, int H, int W, float* logits, float* boxes, hipStream_t s);
@@ -103,6 +102,14 @@ int ymk_model_finalize(ymk_model* m) {
   YMK_API_END
 }
 
+int ymk_model_reserve(ymk_model* m, int n, int h, int w, void* stream) {
+  YMK_API_BEGIN
+  YMK_CHECK(m && m->impl, "null argument");
+  YMK_HIP(hipSetDevice(m->device));
+  m->impl->reserve(n, h, w, (hipStream_t)stream);
+  YMK_API_END
+}
+
 int64_t ymk_model_weight_bytes(const ymk_model* m) { return m ? (int64_t)m->impl->pool.bytes() : -1; }
 int64_t ymk_model_workspace_bytes(const ymk_model* m) { return m ? (int64_t)m->impl->arena.capacity() : -1; }
 
@@ -136,14 +143,6 @@ int ymk_parseq_forward_groups(ymk_model* m, const float* const* x_dev, const int
   YMK_CHECK(m && x_dev && b && w && logits_dev && out_len && ar_steps, "null argument");
   YMK_HIP(hipSetDevice(m->device));
   ymk::parseq_forward_groups(m->impl, x_dev, b, w, n_groups, logits_dev, out_len, ar_steps, (hipStream_t)stream);
-  YMK_API_END
-}
-
-int ymk_parseq_reserve(ymk_model* m, int max_lines, int max_width, void* stream) {
-  YMK_API_BEGIN
-  YMK_CHECK(m, "null argument");
-  YMK_HIP(hipSetDevice(m->device));
-  ymk::parseq_reserve(m->impl, max_lines, max_width, (hipStream_t)stream);
   YMK_API_END
 }
 

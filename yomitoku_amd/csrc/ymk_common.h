@@ -184,6 +184,8 @@ class Model {
   virtual ~Model() {}
   virtual const char* kind() const = 0;
   virtual void finalize() = 0;
+  // size the workspace once for the largest forward the caller will issue (see ymk_model_reserve in include/ymk.h)
+  virtual void reserve(int n, int h, int w, hipStream_t s) = 0;
   WeightStore ws;
   std::map<std::string, double> params;
   double param(const std::string& k, double dflt) const {

@@ -118,6 +118,25 @@ class DBNetModel : public Model {
     run(x_nchw, n, h, w, prob, s);
   }
 
+  void reserve(int n, int h, int w, hipStream_t s) override {
+    YMK_CHECK(finalized, "model not finalized");
+    YMK_CHECK(n > 0 && h % 32 == 0 && w % 32 == 0 && h >= 32 && w >= 32, "dbnet reserve: sizes must be multiples of 32");
+    size_t need = 0;
+    for (int turn = 0; turn < 2; ++turn) {  // either orientation of the page
+      arena.dry_run = true;
+      arena.reset();
+      run(nullptr, n, turn ? w : h, turn ? h : w, nullptr, s);
+      arena.dry_run = false;
+      need = std::max(need, arena.used());
+      arena.reset();
+    }
+    if (need > arena.capacity()) {
+      YMK_HIP(hipStreamSynchronize(s));
+      arena.reserve(need);
+    }
+    shape_key_ = 0;
+  }
+
  private:
   Tensor conv(hipStream_t s, const Tensor& in, const ConvW& w, int stride, int pad, int dil, int act,
               const Tensor* res = nullptr, const Tensor* into = nullptr) {

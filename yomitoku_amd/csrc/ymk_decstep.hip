@@ -522,17 +522,24 @@ static bool launch_rows(hipStream_t s, const DecStepW& W, const int* tok, int ld
                         int B, const int* gid, const int* gopen, int ng) {
   const int lcap = (std::max(L, NS) + 63) / 64 * 64;
   const size_t bytes = rows_smem_bytes<R>(W.D, W.F, W.H, lcap);
-  constexpr size_t LDS_MAX = 160 * 1024 - 64;  // the CU's 160 KB minus live_s and alignment slack
-  if (bytes > LDS_MAX) return false;
-  static std::atomic<bool> configured[64];  // per device: the attribute belongs to the function on one device
+  // per device: the LDS a workgroup may declare (gfx950: 160 KB; asked of the device, not assumed) minus live_s and
+  // alignment slack; 0 = not asked yet, -1 = the attribute could not be raised -> the one-row kernel serves the forward
+  static std::atomic<long> lds_max[64];
   int dev = 0;
   YMK_HIP(hipGetDevice(&dev));
   YMK_CHECK(dev >= 0 && dev < 64, "fused decoder step: device index out of range");
-  if (!configured[dev].load(std::memory_order_acquire)) {  // idempotent: a race sets the same value twice
-    YMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parseq_dec_step_rows<R>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
-    configured[dev].store(true, std::memory_order_release);
+  long cap = lds_max[dev].load(std::memory_order_acquire);
+  if (cap == 0) {  // idempotent: a race asks twice and stores the same value
+    int per_block = 0;
+    cap = -1;
+    if (hipDeviceGetAttribute(&per_block, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && per_block > 4096 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parseq_dec_step_rows<R>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            per_block - 64) == hipSuccess)
+      cap = per_block - 64;
+    (void)hipGetLastError();  // a refused attribute is a routing decision, not an error of this forward
+    lds_max[dev].store(cap, std::memory_order_release);
   }
+  if (cap < 0 || bytes > (size_t)cap) return false;
   hipLaunchKernelGGL(k_parseq_dec_step_rows<R>, dim3((B + R - 1) / R), dim3(NT), bytes, s, W, tok, ld_tok, step, skv, NS, memkv,
                      L, mem_off, mem_len, out, prev_not_done, gid, gopen, ng, B, lcap);
   YMK_HIP(hipGetLastError());

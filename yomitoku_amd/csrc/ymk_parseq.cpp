@@ -221,7 +221,7 @@ class ParseqModel : public Model {
   // Size the workspace once for the largest forward the caller will ever issue (max_lines rows, each max_w wide; every
   // buffer of run() is monotone in the row count, the token-row count and the largest group's pixels), so that
   // ragged forwards - whose shape changes on every call - never reach hipMalloc / hipFree on the serving path.
-  void reserve(int max_lines, int max_w, hipStream_t s) {
+  void reserve(int max_lines, int /*h*/, int max_w, hipStream_t s) override {
     YMK_CHECK(finalized, "model not finalized");
     YMK_CHECK(max_lines > 0 && max_w >= pw_ && max_w <= img_w_, "parseq reserve: bad bounds");
     max_w -= max_w % pw_;
@@ -541,11 +541,6 @@ void parseq_forward_groups(Model* m, const float* const* x, const int* b, const 
   std::vector<PGroup> g((size_t)ng);
   for (int i = 0; i < ng; ++i) g[i] = PGroup{x[i], b[i], w[i]};
   p->forward_groups(g.data(), ng, logits, out_len, ar_steps, s);
-}
-void parseq_reserve(Model* m, int max_lines, int max_w, hipStream_t s) {
-  auto* p = dynamic_cast<ParseqModel*>(m);
-  YMK_CHECK(p != nullptr, "model is not a parseq");
-  p->reserve(max_lines, max_w, s);
 }
 void parseq_dims(Model* m, int* num_steps, int* num_classes) {
   auto* p = dynamic_cast<ParseqModel*>(m);

@@ -209,6 +209,22 @@ class RtdetrModel : public Model {
     run(x, B, H, W, logits, boxes, s);
   }
 
+  void reserve(int n, int h, int w, hipStream_t s) override {
+    YMK_CHECK(finalized, "model not finalized");
+    YMK_CHECK(n > 0 && h % 32 == 0 && w % 32 == 0, "rtdetr reserve: sizes must be multiples of 32");
+    arena.dry_run = true;
+    arena.reset();
+    run(nullptr, n, h, w, nullptr, nullptr, s);
+    arena.dry_run = false;
+    const size_t need = arena.used();
+    arena.reset();
+    if (need > arena.capacity()) {
+      YMK_HIP(hipStreamSynchronize(s));
+      arena.reserve(need);
+    }
+    shape_key_ = 0;
+  }
+
  private:
   bool dry() const { return arena.dry_run; }
 

@@ -457,26 +457,60 @@ class DocumentAnalyzer:
     def _stage_split(self, wave):
         wave.dets = [_split_text_across_cells(d, l) for d, l in zip(wave.dets, wave.lays)]
 
+    def _stage_crops(self, wave):
+        """Per-page mini-batches (bucketing, width budget) and the crop kernels that build their tensors."""
+        wave.rec_plan = self.text_recognizer.plan_pages(wave.pages, [d.points for d in wave.dets])
+
     def _stage_recognize(self, wave):
-        """One grouped PARSeq forward over the mini-batches of all pages of the wave."""
-        wave.recs = self.text_recognizer.recognize_pages(wave.pages, [d.points for d in wave.dets])
+        """One grouped PARSeq forward over the mini-batches of all pages of the wave (owns the recogniser's model; with
+        `rec_orientation_fallback` the decode happens here too, because the retry runs further forwards)."""
+        self.text_recognizer.forward_plan(wave.rec_plan)
+        if self.text_recognizer.rec_orientation_fallback:
+            self._stage_decode(wave)
+
+    def _stage_decode(self, wave):
+        """Token decode and un-permutation on the host."""
+        if wave.recs is None:
+            wave.recs = self.text_recognizer.finish_plan(wave.rec_plan)
+            wave.rec_plan = None
 
     def _stage_layout(self, wave):
-        """One RT-DETRv2 forward over the pages, one over all their table crops."""
-        lays = self.layout.layout_parser.parse_pages(wave.pages)
-        tables = self.layout.table_structure_recognizer.recognize_pages(wave.pages, [[t.box for t in l.tables] for l in lays])
-        wave.lays = [LayoutAnalyzerSchema(paragraphs=l.paragraphs, tables=t, figures=l.figures) for l, t in zip(lays, tables)]
+        """One RT-DETRv2 layout forward over the pages (device half)."""
+        wave.lay_raw = self.layout.layout_parser.forward_pages(wave.pages)
+
+    def _stage_tables(self, wave):
+        """Layout boxes on the host, then one table-structure forward over all table crops of the wave."""
+        wave.lay_parsed = self.layout.layout_parser.pages_from_raw(wave.lay_raw)
+        wave.lay_raw = None
+        boxes = [[t.box for t in l.tables] for l in wave.lay_parsed]
+        wave.tab_raw = self.layout.table_structure_recognizer.forward_tables(wave.pages, boxes)
+
+    def _stage_cells(self, wave):
+        """Row / column / span filters and the cell grids on the host."""
+        tables = self.layout.table_structure_recognizer.tables_from_raw(wave.tab_raw, len(wave.pages))
+        wave.tab_raw = None
+        wave.lays = [LayoutAnalyzerSchema(paragraphs=l.paragraphs, tables=t, figures=l.figures) for l, t in zip(wave.lay_parsed, tables)]
 
     def _stage_finish(self, wave, k):
         """Aggregation of page k of the wave -> DocumentAnalyzerSchema."""
         results_ocr = OCRSchema(words=ocr_aggregate(wave.dets[k], wave.recs[k]))
         return DocumentAnalyzerSchema(**self.aggregate(results_ocr, wave.lays[k], img=wave.imgs[k]))
 
+    def _recognize_wave(self, wave):
+        self._stage_crops(wave)
+        self._stage_recognize(wave)
+        self._stage_decode(wave)
+
+    def _layout_wave(self, wave):
+        self._stage_layout(wave)
+        self._stage_tables(wave)
+        self._stage_cells(wave)
+
     def _ocr_wave(self, wave):
         self._stage_detect(wave)
         self._stage_boxes(wave)
         if not self.split_text_across_cells:
-            self._stage_recognize(wave)
+            self._recognize_wave(wave)
 
     def analyze_pages(self, imgs, wave: int = 8):
         """`__call__` over a list of pages, `wave` pages at a time on the device.  Every page's result is what
@@ -496,22 +530,23 @@ class DocumentAnalyzer:
             pages = [img if isinstance(img, torch.Tensor) else imaging.page_to_device(img, dev) for img in chunk]
             w = Wave(start // size, range(start, start + len(chunk)), chunk, pages)
             f_ocr = self._submit("ocr", self._ocr_wave, w)
-            f_lay = self._submit("layout", self._stage_layout, w)
+            f_lay = self._submit("layout", self._layout_wave, w)
             f_ocr.result()
             f_lay.result()
             if self.split_text_across_cells:
                 self._stage_split(w)
-                self._submit("ocr", self._stage_recognize, w).result()
+                self._submit("ocr", self._recognize_wave, w).result()
             out.extend((self._stage_finish(w, k), None, None) for k in range(len(chunk)))
         return out
 
-    def serve(self, sources, wave: int = 8, in_flight: int = 3):
+    def serve(self, sources, wave: int = 8, in_flight: int = 3, defer_full_gc: bool = True):
         """The multi-page entry point: host pages (uint8 H x W x 3 BGR arrays) and / or image file paths in, one result
         per page out, in page order - the page loop of cli/main.py:105-137 as a stage pipeline on one GPU from one
         process (yomitoku_amd/serving.py): pinned staging + H2D on a copy stream, `wave` pages per device batch, up to
         `in_flight` waves between upload and aggregation.  A page's entry is its DocumentAnalyzerSchema - equal to
         `__call__(img)[0]` - or, when the page (or its file) failed, the exception object; the other pages are not
-        affected (cli/main.py:555-564)."""
+        affected (cli/main.py:555-564).  `defer_full_gc`: postpone CPython's generation-2 garbage collections until
+        the job is done (a full pass holds the GIL for 100+ ms with a few hundred results alive and stalls every stage)."""
         from .serving import PagePipeline
 
         if self.visualize:
@@ -521,6 +556,7 @@ class DocumentAnalyzer:
             if pipe is not None:
                 pipe.close()
             pipe = self._pipeline = PagePipeline(self, wave=wave, in_flight=in_flight)
+        pipe.defer_full_gc = bool(defer_full_gc)
         return pipe.serve(sources)
 
     def close(self):

@@ -187,12 +187,16 @@ class LayoutParser(BaseModule):
 
     MAX_PAGES_PER_FORWARD = 16
 
-    def parse_pages(self, imgs):
-        """`__call__` for several pages through shared RT-DETRv2 forwards (images of a batch are independent,
-        tests/test_rtdetr_gpu.py::test_batch_of_pages_matches_oracle).  One LayoutParserSchema per page."""
+    def forward_pages(self, imgs):
+        """The device half of `parse_pages`: pre-processing + shared RT-DETRv2 forwards (images of a batch are independent,
+        tests/test_rtdetr_gpu.py::test_batch_of_pages_matches_oracle).  Returns per page (logits 1 x Q x C, boxes
+        1 x Q x 4, (h, w)) as host arrays - what `pages_from_raw` turns into LayoutParserSchemas on the host."""
         pages = [img if isinstance(img, torch.Tensor) else imaging.page_to_device(img, self.device) for img in imgs]
         oh, ow = (int(v) for v in self._cfg.data.img_size)
-        results = []
+        if not getattr(self, "_workspace_reserved", False):
+            self.model.reserve(self.MAX_PAGES_PER_FORWARD, oh, ow, self.device)  # any wave size: no reallocation later
+            self._workspace_reserved = True
+        raw = []
         for start in range(0, len(pages), self.MAX_PAGES_PER_FORWARD):
             chunk = pages[start : start + self.MAX_PAGES_PER_FORWARD]
             x = torch.empty((len(chunk), 3, oh, ow), dtype=torch.float32, device=chunk[0].device)
@@ -202,10 +206,20 @@ class LayoutParser(BaseModule):
             logits = preds["pred_logits"].cpu().numpy()
             boxes = preds["pred_boxes"].cpu().numpy()
             for k, page in enumerate(chunk):
-                h, w = (int(v) for v in page.shape[:2])
-                one = self.postprocessor({"pred_logits": logits[k : k + 1], "pred_boxes": boxes[k : k + 1]}, (w, h), self.thresh_score)
-                results.append(LayoutParserSchema(**self.filtering_elements(one[0])))
+                raw.append((logits[k : k + 1], boxes[k : k + 1], (int(page.shape[0]), int(page.shape[1]))))
+        return raw
+
+    def pages_from_raw(self, raw):
+        """The host half: RTDETRPostProcessor + containment filters per page -> LayoutParserSchema."""
+        results = []
+        for logits, boxes, (h, w) in raw:
+            one = self.postprocessor({"pred_logits": logits, "pred_boxes": boxes}, (w, h), self.thresh_score)
+            results.append(LayoutParserSchema(**self.filtering_elements(one[0])))
         return results
+
+    def parse_pages(self, imgs):
+        """`__call__` for several pages through shared RT-DETRv2 forwards.  One LayoutParserSchema per page."""
+        return self.pages_from_raw(self.forward_pages(imgs))
 
     def __call__(self, img):
         ori_h, ori_w = img.shape[:2]

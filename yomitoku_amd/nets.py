@@ -125,6 +125,14 @@ class HipNet:
         except Exception:
             pass
 
+    def reserve(self, n: int, h: int, w: int, device=None):
+        """Size the workspace for the largest forward (ymk_model_reserve): forwards within the bound never reallocate.
+        DBNet / RTDETRv2: n images of h x w; PARSeq: n lines of width <= w."""
+        if self._h is None:
+            self.to(device if device is not None else "cuda")
+        with torch.cuda.device(self._device_index):
+            _lib.check(_lib.load().ymk_model_reserve(self._h, int(n), int(h), int(w), _lib.current_stream_ptr()), "ymk_model_reserve")
+
     @property
     def weight_bytes(self) -> int:
         return int(_lib.load().ymk_model_weight_bytes(self._h)) if self._h else 0
@@ -219,14 +227,6 @@ class PARSeq(HipNet):
             )
         self.last_ar_steps = ar.value
         return logits[:, : out_len.value]
-
-    def reserve(self, max_lines: int, max_width: int, device=None):
-        """Size the workspace for the largest grouped forward (ymk_parseq_reserve): ragged forwards never reallocate after it."""
-        if self._h is None:
-            self.to(device if device is not None else "cuda")
-        with torch.cuda.device(self._device_index):
-            _lib.check(_lib.load().ymk_parseq_reserve(self._h, int(max_lines), int(max_width), _lib.current_stream_ptr()),
-                       "ymk_parseq_reserve")
 
     def forward_groups(self, batches):
         """Several mini-batches in ONE forward (ymk_parseq_forward_groups): `batches` is a list of fp32 B_g x 3 x 32 x W_g

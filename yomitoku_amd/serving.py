@@ -5,16 +5,31 @@ analyzer once per page and a failing file is logged and skipped (cli/main.py:555
 leaves the device mostly idle, so `DocumentAnalyzer.serve` runs the page loop as a STAGE PIPELINE over waves of pages:
 
     caller thread   decode (paths) -> pinned staging ring -> H2D on the copy stream              (PageStager)
-    detect          DBNet forwards over the wave, maps back in one DMA per forward               HIP stream 1
+    detect          DBNet forwards over the wave, maps back in one DMA per forward               HIP stream
     boxes           DB box extraction, C++, GIL released                                         host
-    recognize       crop kernels + ONE grouped PARSeq forward with one greedy loop per wave      HIP stream 2
-    layout          RT-DETRv2 layout forward over the wave + table-structure forward over crops  HIP stream 3
+    crops           per-page mini-batches (bucketing, width budget) + the crop kernels           HIP stream
+    recognize       ONE grouped PARSeq forward with one greedy loop per wave                     HIP stream
+    decode          token decode, un-permutation                                                 host
+    layout          RT-DETRv2 layout forward over the wave                                       HIP stream
+    tables          layout boxes (host), table-structure forward over all table crops            HIP stream
+    cells           row / column / span filters, cell grids                                      host
     finish          word -> cell / paragraph aggregation and reading order, per page             host
 
+The host halves are their own stages on purpose: a thread that owns a network only ever launches - it never sits in box
+logic or string decoding while its stream runs dry (measured: with crop planning / decode inside the recognise stage
+and the table grid logic inside the layout stage the GPU was idle 16 % of a job, in 10-20 ms holes).
 Every network exists ONCE (no replicas): a model handle is only ever used by its own stage thread, which is what
-include/ymk.h asks for, and the three compute streams plus the copy stream fit the HIP runtime's hardware queues.
-Wave k + 1 is in the detector while wave k decodes text and its tables are parsed; up to `in_flight` waves are between
-upload and aggregation (a ring of pinned map buffers per wave slot), which bounds host and device memory.
+include/ymk.h asks for; five compute streams plus the copy stream fit the eight hardware queues the package asks the
+HIP runtime for.  Wave k + 1 is in the detector while wave k decodes text and its tables are parsed; up to `in_flight`
+waves are between upload and aggregation (a ring of pinned map buffers per wave slot), which bounds host and device
+memory.
+
+Garbage collection: a full (generation-2) pass of CPython's cyclic collector walks every live container object of the
+process while holding the GIL - measured 100-180 ms with the results of a few hundred pages alive, six times in a
+4 s job - and every stage thread that needs the interpreter to issue its next launch stalls behind it (the GPU idles;
+this, not the launch rate, is what held one process at 48 pages/s where two reached 66).  `serve` therefore defers
+generation-2 collections for the duration of a job (`defer_full_gc=True`: the young generations keep running, the
+previous thresholds come back when the job ends).
 
 Failure isolation: a stage that raises marks its wave failed; the pages of a failed wave are re-run as single-page
 waves through the same pipeline, and a page that fails alone gets the exception object as its result - the job goes
@@ -23,9 +38,13 @@ on (the reference's per-file `except: log, continue`).  Results equal `DocumentA
 
 from __future__ import annotations
 
+import contextlib
+import gc
 import logging
+import os
 import queue
 import threading
+import time
 from collections import deque
 from typing import Iterable, List, Optional
 
@@ -42,13 +61,13 @@ _STOP = object()
 class Wave:
     """The pages that share device batches, and what the stages have produced for them so far."""
 
-    __slots__ = ("seq", "ids", "imgs", "pages", "ring", "uploaded", "maps", "sizes", "dets", "recs", "lays", "error",
-                 "failed_stage", "layout_done", "joined", "retry")
+    __slots__ = ("seq", "ids", "imgs", "pages", "ring", "uploaded", "maps", "sizes", "dets", "rec_plan", "recs", "lay_raw",
+                 "lay_parsed", "tab_raw", "lays", "error", "failed_stage", "layout_done", "joined", "retry")
 
     def __init__(self, seq=0, ids=(), imgs=(), pages=(), ring=0, uploaded=None, retry=False):
         self.seq, self.ids, self.imgs, self.pages, self.ring, self.uploaded = seq, list(ids), list(imgs), list(pages), ring, uploaded
         self.sizes = [tuple(int(v) for v in p.shape[:2]) for p in self.pages]
-        self.maps = self.dets = self.recs = self.lays = None
+        self.maps = self.dets = self.rec_plan = self.recs = self.lay_raw = self.lay_parsed = self.tab_raw = self.lays = None
         self.error: Optional[BaseException] = None
         self.failed_stage = None
         self.layout_done = threading.Event()
@@ -75,9 +94,30 @@ class _Job:
         self.retried_pages = 0
 
 
+@contextlib.contextmanager
+def _full_gc_deferred(on: bool):
+    """Generation-2 collections of the cyclic collector postponed while the block runs (module doc)."""
+    if not on or not gc.isenabled():
+        yield
+        return
+    t0, t1, t2 = gc.get_threshold()
+    gc.set_threshold(t0, t1, 1 << 30)
+    try:
+        yield
+    finally:
+        gc.set_threshold(t0, t1, t2)
+
+
 class PagePipeline:
-    def __init__(self, analyzer, wave: int = 8, in_flight: int = 3):
+    def __init__(self, analyzer, wave: int = 8, in_flight: int = 3, defer_full_gc: bool = True, stage_priority=None):
+        """stage_priority: {"detect" | "recognize" | "layout": HIP stream priority (0 default, -1 high)}; also read from
+        YMK_STAGE_PRIORITY="recognize:-1,..." (measurement knob)."""
         self.analyzer = analyzer
+        self.defer_full_gc = bool(defer_full_gc)
+        self.stage_priority = dict(stage_priority or {})
+        for item in filter(None, os.environ.get("YMK_STAGE_PRIORITY", "").split(",")):
+            name, _, value = item.partition(":")
+            self.stage_priority.setdefault(name.strip(), int(value))
         self.wave = max(1, int(wave))
         self.in_flight = max(1, int(in_flight))
         self.device = torch.device(analyzer.text_detector.device)
@@ -88,14 +128,19 @@ class PagePipeline:
         self._rings: "queue.Queue" = queue.Queue()
         for r in range(self.in_flight):
             self._rings.put(r)
-        self._q = {name: queue.Queue() for name in ("detect", "boxes", "recognize", "layout", "finish")}
+        names = ("detect", "boxes", "crops", "recognize", "decode", "layout", "tables", "cells", "finish")
+        self._q = {name: queue.Queue() for name in names}
         self._job: Optional[_Job] = None
         self._seq = 0
+        self.trace = None  # a list: every stage appends (stage, wave seq, pages, t_start, t_end) - tools/serve_trace.py
         self._serve_lock = threading.Lock()
         a = analyzer
-        plan = (("detect", a._stage_detect, True, ("boxes",)), ("boxes", self._boxes, False, ("recognize",)),
-                ("recognize", a._stage_recognize, True, ("finish",)), ("layout", self._layout, True, ("finish",)),
-                ("finish", self._finish, False, ()))
+        # (stage, function, launches on the GPU?, next stages); the recognise chain and the layout chain join in `finish`
+        plan = (("detect", a._stage_detect, True, ("boxes",)), ("boxes", self._boxes, False, ("crops",)),
+                ("crops", a._stage_crops, True, ("recognize",)), ("recognize", a._stage_recognize, True, ("decode",)),
+                ("decode", a._stage_decode, False, ("finish",)),
+                ("layout", a._stage_layout, True, ("tables",)), ("tables", a._stage_tables, True, ("cells",)),
+                ("cells", a._stage_cells, False, ("finish",)), ("finish", self._finish, False, ()))
         self._threads = [threading.Thread(target=self._loop, args=spec, name=f"ymk-{spec[0]}", daemon=True) for spec in plan]
         for t in self._threads:
             t.start()
@@ -105,7 +150,7 @@ class PagePipeline:
         stream = None
         if on_gpu and self._gpu:
             torch.cuda.set_device(self.device)
-            stream = torch.cuda.Stream(device=self.device)
+            stream = torch.cuda.Stream(device=self.device, priority=self.stage_priority.get(name, 0))
         q_in = self._q[name]
         while True:
             wave = q_in.get()
@@ -116,6 +161,7 @@ class PagePipeline:
                 if wave.joined < 2:  # arrives once from the recognise chain and once from the layout chain
                     continue
             if wave.error is None or name == "finish":
+                t_start = time.perf_counter()
                 try:
                     if stream is not None:
                         with torch.cuda.stream(stream):
@@ -131,7 +177,9 @@ class PagePipeline:
                             self._job.results.setdefault(idx, exc)
                         if wave.pages is not None:
                             self._release(wave)
-            if name == "layout":
+                if self.trace is not None:
+                    self.trace.append((name, wave.seq, len(wave), t_start, time.perf_counter()))
+            if name == "cells":
                 wave.layout_done.set()
             for out in outs:
                 self._q[out].put(wave)
@@ -144,12 +192,9 @@ class PagePipeline:
             if wave.error is None:
                 a._stage_split(wave)
 
-    def _layout(self, wave):
-        self.analyzer._stage_layout(wave)
-
     def _release(self, wave):
         job = self._job
-        wave.pages = wave.maps = None  # the device pages and the pinned map views go back
+        wave.pages = wave.maps = wave.rec_plan = None  # the device pages, the pinned map views and the crop tensors go back
         self._rings.put(wave.ring)
         with job.cond:
             job.outstanding -= 1
@@ -178,7 +223,9 @@ class PagePipeline:
 
     # ------------------------------------------------------------------ caller side
     def _launch(self, job, ids, imgs, retry=False):
+        t_start = time.perf_counter()
         ring = self._rings.get()  # blocks while `in_flight` waves are out: back-pressure on decoding and staging
+        t_ring = time.perf_counter()
         try:
             if self._gpu:
                 pages = [self.stager.upload(img, wait=False) for img in imgs]
@@ -190,6 +237,9 @@ class PagePipeline:
             self._rings.put(ring)
             raise
         self._seq += 1
+        if self.trace is not None:
+            self.trace.append(("wait_slot", self._seq, len(ids), t_start, t_ring))
+            self.trace.append(("stage_h2d", self._seq, len(ids), t_ring, time.perf_counter()))
         wave = Wave(self._seq, ids, imgs, pages, ring, uploaded, retry)
         with job.cond:
             job.outstanding += 1
@@ -203,7 +253,7 @@ class PagePipeline:
         file) raised."""
         from .data.functions import load_image
 
-        with self._serve_lock:
+        with self._serve_lock, _full_gc_deferred(self.defer_full_gc):
             job = self._job = _Job()
             n = 0
             pend_ids, pend_imgs = [], []

@@ -132,13 +132,17 @@ class TableStructureRecognizer(BaseModule):
         spans = sorted(elements["span"], key=lambda e: e["box"][1])
         return cells, rows, cols, spans
 
-    def recognize_pages(self, imgs, boxes_list):
-        """`__call__` for several pages: the table crops of ALL pages fill shared forwards of MAX_TABLES_PER_FORWARD
-        crops.  Returns per page the list `__call__` returns (tables without rows or columns dropped)."""
+    def forward_tables(self, imgs, boxes_list):
+        """The device half of `recognize_pages`: the table crops of ALL pages fill shared forwards of
+        MAX_TABLES_PER_FORWARD crops.  Returns [(page index, logits 1 x Q x C, boxes 1 x Q x 4, meta)] per table, host
+        arrays, in page / box order - what `tables_from_raw` turns into TableStructureRecognizerSchemas on the host."""
         pages = [img if isinstance(img, torch.Tensor) else imaging.page_to_device(img, self.device) for img in imgs]
         oh, ow = self._cfg.data.img_size
+        if not getattr(self, "_workspace_reserved", False):
+            self.model.reserve(self.MAX_TABLES_PER_FORWARD, int(oh), int(ow), self.device)  # any table count: no reallocation later
+            self._workspace_reserved = True
         flat = [(p, box) for p, boxes in enumerate(boxes_list) for box in boxes]
-        outputs = [[] for _ in pages]
+        raw = []
         for start in range(0, len(flat), self.MAX_TABLES_PER_FORWARD):
             chunk = flat[start : start + self.MAX_TABLES_PER_FORWARD]
             batch = torch.empty((len(chunk), 3, oh, ow), dtype=torch.float32, device=pages[chunk[0][0]].device)
@@ -150,10 +154,22 @@ class TableStructureRecognizer(BaseModule):
             logits = preds["pred_logits"].cpu().numpy()
             bxs = preds["pred_boxes"].cpu().numpy()
             for k, ((p, _), data) in enumerate(zip(chunk, metas)):
-                table = self.postprocess({"pred_logits": logits[k : k + 1], "pred_boxes": bxs[k : k + 1]}, data)
-                if table.n_row > 0 and table.n_col > 0:
-                    outputs[p].append(table)
+                raw.append((p, logits[k : k + 1], bxs[k : k + 1], data))
+        return raw
+
+    def tables_from_raw(self, raw, n_pages):
+        """The host half: post-processor, row / column / span filters and the cell grid per table; per page the list
+        `__call__` returns (tables without rows or columns dropped)."""
+        outputs = [[] for _ in range(n_pages)]
+        for p, logits, bxs, data in raw:
+            table = self.postprocess({"pred_logits": logits, "pred_boxes": bxs}, data)
+            if table.n_row > 0 and table.n_col > 0:
+                outputs[p].append(table)
         return outputs
+
+    def recognize_pages(self, imgs, boxes_list):
+        """`__call__` for several pages: shared forwards over the table crops of all pages, then the host grid logic."""
+        return self.tables_from_raw(self.forward_tables(imgs, boxes_list), len(imgs))
 
     def __call__(self, img, table_boxes, vis=None):
         outputs = []

@@ -8,6 +8,7 @@ the PARSeq forward, and the softmax -> (arg-max, max-prob) reduction the tokeniz
 
 from __future__ import annotations
 
+import logging
 import unicodedata
 from typing import List, Optional
 
@@ -26,6 +27,9 @@ from .configs import (
 )
 from .nets import PARSeq
 from .schemas import TextRecognizerSchema
+
+
+logger = logging.getLogger(__name__)
 
 
 def load_charset(charset_path):
@@ -90,6 +94,17 @@ class CropSet:
         self.plans = [p for p in plans if p is not None]
         self.content_widths = [p.content_width for p in self.plans]
         self.valid_quads = [q for q, p in zip(quads, plans) if p is not None]
+        # quads without a plan: "invalid" fails validate_quads (the reference drops those from the dataset but not from
+        # `points`, data/dataset.py:91-95 - kept as is); "degenerate" passes it but has an edge shorter than one pixel
+        # (the reference hands OpenCV an empty dsize there) - those get a placeholder result so that contents / scores /
+        # directions stay aligned with `points`
+        self.slots = ["ok" if p is not None else ("degenerate" if imaging.validate_quad(page_dev.shape[:2], q) else "invalid")
+                      for q, p in zip(quads, plans)]
+        self.n_degenerate = self.slots.count("degenerate")
+        if len(self.plans) != len(plans):
+            logger.warning("text recogniser: %d of %d quads dropped (%d outside the page or malformed, %d with an edge shorter "
+                           "than one pixel - the latter are reported as empty strings with score 0)", len(plans) - len(self.plans),
+                           len(plans), self.slots.count("invalid"), self.n_degenerate)
 
     def __len__(self):
         return len(self.plans)
@@ -196,34 +211,49 @@ class TextRecognizer(BaseModule):
         directions = np.where(h > w * 2, "vertical", "horizontal").tolist()
         return pred, score, directions
 
-    def _infer_groups(self, jobs, flip=False, fixed_width=False):
-        """jobs: (dataset, plans) mini-batches - of one page or of many - through ONE PARSeq forward per
-        MAX_LINES_PER_FORWARD lines (nets.PARSeq.forward_groups): every mini-batch keeps its own padded width and
-        its own early-stop step count, the launches are shared.  Returns per job (ids, probs) as numpy B x S."""
-        out = [None] * len(jobs)
-        start = 0
+    def _forward_chunks(self, jobs):
+        """jobs -> [(first job, one past the last)]: consecutive mini-batches that share a forward (<= MAX_LINES_PER_FORWARD)."""
+        chunks, start = [], 0
         while start < len(jobs):
             stop, lines = start, 0
             while stop < len(jobs) and (stop == start or lines + len(jobs[stop][1]) <= self.MAX_LINES_PER_FORWARD):
                 lines += len(jobs[stop][1])
                 stop += 1
-            tensors = []
-            for dataset, plans in jobs[start:stop]:
-                if fixed_width:
-                    h, w = (int(v) for v in self._cfg.data.img_size)
-                    tensors.append(imaging.build_crop_batch(dataset.page, plans, out_h=h, batch_w=w, flip=flip))
-                else:
-                    tensors.append(self._collate(dataset, plans))
-            logits, out_lens, _ = self.model.forward_groups(tensors)
+            chunks.append((start, stop))
+            start = stop
+        return chunks
+
+    def _collate_jobs(self, jobs, flip=False, fixed_width=False):
+        """The crop kernels of every mini-batch: one padded B x 3 x 32 x W device tensor per job."""
+        tensors = []
+        for dataset, plans in jobs:
+            if fixed_width:
+                h, w = (int(v) for v in self._cfg.data.img_size)
+                tensors.append(imaging.build_crop_batch(dataset.page, plans, out_h=h, batch_w=w, flip=flip))
+            else:
+                tensors.append(self._collate(dataset, plans))
+        return tensors
+
+    def _forward_jobs(self, tensors, chunks):
+        """One PARSeq forward per chunk (nets.PARSeq.forward_groups): every mini-batch keeps its own padded width and its
+        own early-stop step count, the launches are shared.  Returns per job (ids, probs) as numpy B x S."""
+        out = [None] * len(tensors)
+        for start, stop in chunks:
+            part = tensors[start:stop]
+            logits, out_lens, _ = self.model.forward_groups(part)
             ids, probs = self.model.token_stats(logits)
             ids, probs = ids.cpu().numpy(), probs.cpu().numpy()
             row = 0
-            for k, (t, n) in enumerate(zip(tensors, out_lens)):
+            for k, (t, n) in enumerate(zip(part, out_lens)):
                 b = int(t.shape[0])
                 out[start + k] = (ids[row : row + b, :n], probs[row : row + b, :n])
                 row += b
-            start = stop
         return out
+
+    def _infer_groups(self, jobs, flip=False, fixed_width=False):
+        """jobs: (dataset, plans) mini-batches - of one page or of many - through ONE PARSeq forward per
+        MAX_LINES_PER_FORWARD lines.  Returns per job (ids, probs) as numpy B x S."""
+        return self._forward_jobs(self._collate_jobs(jobs, flip, fixed_width), self._forward_chunks(jobs)) if jobs else []
 
     def _run_batch_inference(self, dataset, batches, points):
         preds, scores, directions = [], [], []
@@ -262,24 +292,53 @@ class TextRecognizer(BaseModule):
             if r_scores[j] > scores[idx] and r_scores[j] >= self.rec_orientation_fallback_thresh:
                 preds[idx], scores[idx], directions[idx] = r_preds[j], r_scores[j], r_dirs[j]
 
-    def recognize_pages(self, imgs, points_list):
-        """`__call__` for several pages at once: the mini-batches of every page are formed per page exactly as in
-        `__call__` (bucketing, width budget, padding), then ALL of them go through shared PARSeq forwards
-        (`_infer_groups`).  Returns one TextRecognizerSchema per page; a page's result does not depend on its
-        neighbours (mini-batches never mix pages)."""
+    @staticmethod
+    def _with_placeholders(dataset, points, preds, scores, directions):
+        """Results of the planned crops -> results aligned with `points` up to the quads the reference itself drops: a
+        degenerate quad (CropSet.slots) gets ("", 0.0, its direction)."""
+        if not dataset.n_degenerate:
+            return preds, scores, directions
+        out_p, out_s, out_d, k = [], [], [], 0
+        for slot, quad in zip(dataset.slots, points):
+            if slot == "ok":
+                out_p.append(preds[k]), out_s.append(scores[k]), out_d.append(directions[k])
+                k += 1
+            elif slot == "degenerate":
+                q = np.asarray(quad).reshape(4, 2)
+                w, h = np.linalg.norm(q[0] - q[1]), np.linalg.norm(q[1] - q[2])
+                out_p.append(""), out_s.append(0.0), out_d.append("vertical" if h > w * 2 else "horizontal")
+        return out_p, out_s, out_d
+
+    # ---- `__call__` for several pages at once, in three steps so that a pipeline can run them on different threads:
+    # plan_pages (host geometry + crop kernels), forward_plan (PARSeq, owns the model), finish_plan (host decode)
+    def plan_pages(self, imgs, points_list):
+        """The mini-batches of every page are formed per page exactly as in `__call__` (bucketing, width budget, padding)
+        and their crop tensors built; a page's result never depends on its neighbours (mini-batches never mix pages)."""
         if not getattr(self, "_workspace_reserved", False):
             # multi-page serving: size the PARSeq workspace once for the largest grouped forward, so that no wave - however
             # its lines fall into mini-batches - reaches hipMalloc / hipFree (tiny: ~12 GB, large-v4_1: ~23 GB of 288 GB)
-            self.model.reserve(self.MAX_LINES_PER_FORWARD, int(self._cfg.data.img_size[1]), self.device)
+            self.model.reserve(self.MAX_LINES_PER_FORWARD, int(self._cfg.data.img_size[0]), int(self._cfg.data.img_size[1]), self.device)
             self._workspace_reserved = True
         preps = [self.preprocess(img, pts) for img, pts in zip(imgs, points_list)]
         jobs, spans = [], []
         for batches, _, dataset, _ in preps:
             spans.append((len(jobs), len(jobs) + len(batches)))
             jobs.extend((dataset, plans) for plans in batches)
-        stats = self._infer_groups(jobs) if jobs else []
+        return {"preps": preps, "jobs": jobs, "spans": spans, "chunks": self._forward_chunks(jobs), "tensors": self._collate_jobs(jobs),
+                "stats": None}
+
+    def forward_plan(self, plan):
+        """ALL mini-batches of all pages through shared PARSeq forwards; fills plan["stats"]."""
+        plan["stats"] = self._forward_jobs(plan["tensors"], plan["chunks"]) if plan["jobs"] else []
+        plan["tensors"] = None
+        return plan
+
+    def finish_plan(self, plan):
+        """Token decode, un-permutation, optional 180-degree retry (which runs further forwards: call it from the thread
+        that owns the model when `rec_orientation_fallback` is on).  One TextRecognizerSchema per page."""
+        stats = plan["stats"]
         results = []
-        for (batches, points, dataset, order), (lo, hi) in zip(preps, spans):
+        for (batches, points, dataset, order), (lo, hi) in zip(plan["preps"], plan["spans"]):
             walk = [points[i] for i in order] if order is not None else points
             preds, scores, directions = [], [], []
             offset = 0
@@ -296,8 +355,13 @@ class TextRecognizer(BaseModule):
                 directions = [directions[i] for i in inverse]
             if self.rec_orientation_fallback:
                 self._apply_orientation_fallback(dataset, points, preds, scores, directions)
+            preds, scores, directions = self._with_placeholders(dataset, points, preds, scores, directions)
             results.append(TextRecognizerSchema(contents=preds, scores=scores, points=points, directions=directions))
         return results
+
+    def recognize_pages(self, imgs, points_list):
+        """`__call__` for several pages at once; one TextRecognizerSchema per page."""
+        return self.finish_plan(self.forward_plan(self.plan_pages(imgs, points_list)))
 
     def __call__(self, img, points=None, vis=None):
         batches, points, dataset, order = self.preprocess(img, points)
@@ -312,6 +376,7 @@ class TextRecognizer(BaseModule):
             preds, scores, directions = self._run_batch_inference(dataset, batches, points)
         if self.rec_orientation_fallback:
             self._apply_orientation_fallback(dataset, points, preds, scores, directions)
+        preds, scores, directions = self._with_placeholders(dataset, points, preds, scores, directions)
         results = TextRecognizerSchema(contents=preds, scores=scores, points=points, directions=directions)
         if self.visualize:
             raise NotImplementedError("visualisation is out of scope of the MI355X path (visualize=False only)")
