@@ -423,6 +423,32 @@ def secondary_metrics(args, device, sds, pages):
     return out
 
 
+SPLIT_DTYPE = ("DBNet and RT-DETRv2 convolutions with fp32 operands cut into 2 bf16 planes (hi + lo), 3 v_mfma_f32_32x32x16_bf16 per "
+               "product tile, fp32 accumulation; PARSeq, attention and every grid-starved launch exact fp32")
+
+
+def split_metrics(args, an, host_pages):
+    """The SAME analyzer and pages with the opt-in bf16-split convolutions (ymk_conv_bf16.hip) on the detector and the two
+    RT-DETRv2 nets - the configuration profiles/r03_split_eval.json shows 20-34 x inside the 1e-3 tolerance with every
+    discrete output unchanged; the recogniser (6 x) stays exact.  One warm-up pass of 16 pages, one timed step."""
+    nets = (an.text_detector.model, an.layout.layout_parser.model, an.layout.table_structure_recognizer.model)
+    for n in nets:
+        n.set_conv_split(2)
+    try:
+        an.serve(host_pages[:16], wave=args.wave, in_flight=args.in_flight)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = an.serve(host_pages, wave=args.wave, in_flight=args.in_flight)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        for n in nets:
+            n.set_conv_split(0)
+    return {"value": round(len(host_pages) / dt, 2), "unit": "pages/s", "steps": 1, "pages": len(host_pages), "dtype": SPLIT_DTYPE,
+            "failed_pages": sum(isinstance(r, BaseException) for r in res),
+            "evidence": "profiles/r03_split_eval.json (errors vs the oracle / goldens / fp32 kernels), profiles/r03_conv_sweep_bf16_split.txt"}
+
+
 def self_spawn(argv, n):
     """`python bench.py --gpus N` outside torchrun: start the N ranks ourselves (same env protocol), pass rank 0's line
     through, fail if any rank fails."""
@@ -459,7 +485,7 @@ def main():
     ap.add_argument("--pages", type=int, default=64, help="pages per step per GPU (BASELINE.json configs[3]: 64)")
     ap.add_argument("--total-pages", type=int, default=0, help="strong scaling (configs[4]: 512): pages per step over ALL GPUs")
     ap.add_argument("--wave", type=int, default=8, help="pages per device batch (analyzer workload)")
-    ap.add_argument("--in-flight", type=int, default=3, help="waves between upload and aggregation (analyzer workload)")
+    ap.add_argument("--in-flight", type=int, default=4, help="waves between upload and aggregation (analyzer workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary metrics leg (recogniser lines/s, default model set)")
     ap.add_argument("--roofline-only", action="store_true",
@@ -656,7 +682,8 @@ def main():
     # ---- secondary metrics (rank 0, N=1): the recogniser's lines/s and the default model set, in this same process
     secondary = None
     if rank == 0 and world == 1 and args.workload == "analyzer" and not (DRY or args.roofline_only or args.no_secondary):
-        secondary = secondary_metrics(args, device, sds, pages)
+        secondary = {"pages_per_s_bf16x2_split_det_layout_table": split_metrics(args, an, host_pages)}
+        secondary.update(secondary_metrics(args, device, sds, pages))
 
     # ---- CPU baseline leg (rank 0, N=1): oracle chain on the host cores, bounded sample
     cpu = None

@@ -40,6 +40,9 @@ int ymk_device_count(void);
  * then ymk_model_finalize() folds BatchNorm, repacks panels and uploads to `device`. */
 ymk_model* ymk_model_create(const char* kind, int device);
 void ymk_model_destroy(ymk_model* m);
+/* One parameter may also be set on a finalized model: "conv_split" = 0 (exact fp32 MFMA, the default), 2 or 3 (this
+ * model's convolutions / linear layers that fill the chip run with their fp32 operands cut into 2 / 3 bf16 planes, fp32
+ * accumulation: ymk_conv_bf16.hip), -1 (follow the process-wide ymk_debug_option). */
 int ymk_model_set_param(ymk_model* m, const char* key, double value);
 int ymk_model_set_tensor(ymk_model* m, const char* name, const float* host_data, int ndim, const int64_t* dims);
 int ymk_model_finalize(ymk_model* m);
@@ -145,7 +148,12 @@ int ymk_prof_begin(void);
  *   "conv_variant" (0)   alternative conv_igemm schedules for A/B runs (tools/conv_sweep.py)       "prof_dump" (0)  1: ymk_prof_end
  *   prints one line per launch      "parseq_unfused" (0)  1: per-op PARSeq decoder step at every width
  *   "conv_fast" (3)      bit 0: index shortcut of 1x1 / stride-1 layers, bit 1: residual rows fetched ahead (0 = the A/B baseline)
- *   "dec_rows" (0)       samples per block of the fused greedy step: 0 = by row count, 1 / 2 / 4 forced (bit-identical results) */
+ *   "dec_rows" (0)       samples per block of the fused greedy step: 0 = by row count, 1 / 2 / 4 forced (bit-identical results)
+ *   "conv_split" (0)     2 / 3: convolutions that fill the chip run with their fp32 operands cut into 2 / 3 bf16 planes and
+ *                        3 / 6 v_mfma_f32_32x32x16_bf16 per product tile, fp32 accumulation (ymk_conv_bf16.hip); 0 = exact fp32 MFMA.
+ *                        Also set for a whole process by the environment variable YMK_CONV_SPLIT (yomitoku_amd/_lib.py).
+ *   "conv_split_tile" (0) tile shape of that path for A/B runs: 0 = by plane count, 1 = 128 x 64, 2 = 256 x 128 (16 waves),
+ *                        3 = 128 x 128 (16 waves), 4 = 128 x 128 (8 waves) */
 int ymk_debug_option(const char* key, int value);
 int ymk_prof_end(double* conv_ms, double* conv_flop, int64_t* conv_launches);
 int ymk_prof_bytes(double* conv_bytes);

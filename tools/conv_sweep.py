@@ -61,6 +61,12 @@ def run(shape, variant, reps=REPS):
     r = torch.randn(n, oh, ow, cout, generator=g).to(dev) if res else None
     vnum, _, fast = str(variant).partition("/")
     force = -1
+    split, split_tile = 0, 0
+    if vnum.startswith("b"):  # "b<ns>[t<tile>]": bf16-split operands (ymk_conv_bf16.hip), ns planes, tile shape selector
+        body, _, tl = vnum[1:].partition("t")
+        split, split_tile, vnum = int(body), int(tl or 0), "0"
+    _lib.debug_option("conv_split", split)
+    _lib.debug_option("conv_split_tile", split_tile)
     if vnum.startswith("s"):  # "s<i>": split-K candidate i (ymk_debug_option splitk_force)
         force, vnum = int(vnum[1:]), "0"
     _lib.debug_option("splitk_force", force)
@@ -76,18 +82,24 @@ def run(shape, variant, reps=REPS):
         if i:
             times.append(ms.value)
     _lib.debug_option("conv_variant", 0)
+    _lib.debug_option("conv_split", 0)
+    _lib.debug_option("conv_split_tile", 0)
     _lib.debug_option("splitk_force", -1)
     _lib.debug_option("conv_fast", 3)
     t = float(np.median(times))
-    return fl.value / (t * 1e-3) / 1e12, t * 1e3, float(y.flatten()[:4096].double().sum().item())
+    return fl.value / (t * 1e-3) / 1e12, t * 1e3, float(y.flatten()[:4096].double().sum().item()), y
 
 
-print(f"{'shape':34s} " + " ".join(f"{'v' + str(v):>14s}" for v in VARIANTS))
+print(f"{'shape':34s} " + " ".join(f"{'v' + str(v):>14s}" + (" " * 10 if str(v).startswith("b") else "") for v in VARIANTS))
 for shape in SHAPES:
     cells = []
-    ref = None
+    ref = y_ref = None
     for v in VARIANTS:
-        tf, us, chk = run(shape, v)
-        ref = chk if ref is None else ref
-        cells.append(f"{tf:6.1f}TF{us:6.0f}us" + ("" if abs(chk - ref) <= 1e-3 * max(1.0, abs(ref)) else "!"))
+        tf, us, chk, y = run(shape, v)
+        if ref is None:
+            ref, y_ref = chk, y
+        cell = f"{tf:6.1f}TF{us:6.0f}us" + ("" if abs(chk - ref) <= 1e-3 * max(1.0, abs(ref)) else "!")
+        if str(v).startswith("b"):  # bf16-split: error against the first variant's (fp32) output, relative to its largest value
+            cell += f" e={float((y - y_ref).abs().max() / y_ref.abs().max()):.1e}"
+        cells.append(cell)
     print(f"{shape[0]:34s} " + " ".join(cells), flush=True)

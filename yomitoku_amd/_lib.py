@@ -101,6 +101,10 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    split = os.environ.get("YMK_CONV_SPLIT")
+    if split:  # evaluation switch: bf16-split conv operands for the whole process (ymk.h: ymk_debug_option "conv_split")
+        if lib.ymk_debug_option(b"conv_split", int(split)) != 0:
+            raise YmkError("YMK_CONV_SPLIT: " + lib.ymk_last_error().decode("utf-8", "replace"))
     return lib
 
 

@@ -82,6 +82,9 @@ struct ConvW {
   float* w = nullptr;      // [cout][kpad] device
   float* scale = nullptr;  // [cout] or null (folded BN gamma/sqrt(var+eps))
   float* bias = nullptr;   // [cout] or null
+  // the same panel split into bf16 planes, [cout^128][kpad / 32][planes][32] (ymk_conv_bf16.hip): 2 planes (hi, lo), 3 planes
+  const unsigned short* w2 = nullptr;
+  const unsigned short* w3 = nullptr;
   int cout = 0, cin = 0, kh = 1, kw = 1;
   int kpad = 0, ctiles = 0, mode = 0;
 };
@@ -99,6 +102,17 @@ struct ConvArgs {
   // all of whose rows sit in groups with group_open[g] == 0 is not computed (its outputs keep their old contents)
   const int* row_group = nullptr;
   const int* group_open = nullptr;
+};
+
+// Operand precision of the calling thread's conv2d / gemm launches while the scope lives: 0 = exact fp32 MFMA, 2 / 3 =
+// bf16-split operands (ymk_conv_bf16.hip).  A model's forward opens one with its "conv_split" parameter; without a scope
+// the process-wide ymk_debug_option("conv_split") applies.
+class ConvSplitScope {
+ public:
+  explicit ConvSplitScope(int split);
+  ~ConvSplitScope();
+ private:
+  int prev_;
 };
 
 // out must be pre-shaped (n, oh, ow, cout[, ld]); for EPI_DECONV2X2 out is (n, 2h, 2w, cout/4).
@@ -158,6 +172,7 @@ class WeightStore {
   std::map<std::string, HostTensor> t_;
 };
 
+struct ConvW;
 // Device buffer pool owned by a model (weights). Freed with the model.
 class DevicePool {
  public:
@@ -170,6 +185,9 @@ class DevicePool {
   std::vector<void*> ptrs_;
   size_t bytes_ = 0;
 };
+
+// bf16-split copies of a packed fp32 panel (c.w2 / c.w3), built on the device; call after c.w, c.kpad, c.cout are set
+void make_split_panels(DevicePool& pool, ConvW& c);
 
 // conv (+ optional BatchNorm folded to scale/bias) from a state-dict
 ConvW make_conv(DevicePool& pool, const WeightStore& ws, const std::string& conv_prefix,
@@ -195,6 +213,8 @@ class Model {
   DevicePool pool;
   Arena arena;
   bool finalized = false;
+  // "conv_split" parameter (ymk_model_set_param; may be changed between forwards): operand precision of this model's convs
+  int conv_split() const { return (int)param("conv_split", -1); }
 };
 
 Model* create_dbnet();

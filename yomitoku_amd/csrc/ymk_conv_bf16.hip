@@ -1,0 +1,319 @@
+// Implicit-GEMM convolution with bf16-SPLIT operands and fp32 accumulation (gfx950), an opt-in alternative to the exact
+// fp32-MFMA kernel of ymk_conv.hip for the same layers (models/dbnet_plus.py:33-38,56-127; rtdetr_backbone.py;
+// parseq_transformer.py): same GEMM view, same gathers, same epilogue.
+//
+// Why: v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (157 TFLOP/s); v_mfma_f32_32x32x16_bf16 is 16 x faster.  An
+// fp32 value splits exactly into bf16 pieces x = x_h + x_m + x_l (8 significand bits each, round-to-nearest at every
+// step, remainders exact in fp32), so a product is a sum of bf16 x bf16 products, each exact in fp32:
+//   NS = 3 planes, 6 MFMAs   x_h y_h + (x_h y_m + x_m y_h) + (x_m y_m + x_h y_l + x_l y_h)   dropped terms <= 2^-23 |xy|
+//   NS = 2 planes, 3 MFMAs   x_h y_h + (x_h y_l + x_l y_h)                                   dropped terms <= 2^-15 |xy|
+// i.e. fp32-grade products at 16 / 6 = 2.7 x the fp32 matrix rate, or tf32-and-a-half-grade ones at 5.3 x.  Accumulation
+// is fp32 inside the MFMA (not an fmaf chain in k order: results agree with the fp32 kernel to rounding, not bit for bit).
+//
+// Data path: activations stay fp32 in HBM; a thread splits the 4 floats it stages into NS x 4 bf16 on the way to LDS
+// (v_cvt_pk_bf16_f32, 11 VALU per 2 values for three planes).  Weights are split once at model finalize into panels
+// [Cout^128][K tiles][NS][32] bf16, so a K tile's B rows are copied to LDS verbatim.  LDS row = NS x 64 B + 16 B pad
+// (conflict-free ds_read_b128: row stride 36 or 52 dwords = 4 x odd), one ds_read_b128 per (32-row tile, plane, 16-k
+// step) feeds v_mfma_f32_32x32x16_bf16: lane l holds row l & 31, k = 8 (l >> 5) .. + 7 of the step, for A and B alike.
+#include <atomic>
+#include <string>
+
+#include "ymk_conv_kernel.h"
+
+namespace ymk {
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// 4 floats -> NS planes of 4 bf16 (8 B each)
+template <int NS>
+__device__ __forceinline__ void split4(const f32x4 v, uint2* planes) {
+  f32x2_t a = {v.x, v.y}, b = {v.z, v.w};
+#pragma unroll
+  for (int pl = 0; pl < NS; ++pl) {
+    const bf16x2_t pa = __builtin_convertvector(a, bf16x2_t), pb = __builtin_convertvector(b, bf16x2_t);
+    planes[pl].x = __builtin_bit_cast(unsigned, pa);
+    planes[pl].y = __builtin_bit_cast(unsigned, pb);
+    if (pl + 1 < NS) {
+      a -= __builtin_convertvector(pa, f32x2_t);  // exact: the remainder of a round-to-nearest cut fits fp32
+      b -= __builtin_convertvector(pb, f32x2_t);
+    }
+  }
+}
+
+// blocks of this shape a CU's 160 KB of LDS holds (at most 2 are asked for) -> minimum waves per SIMD for the register allocator
+template <int BM, int BN, int WM, int WN, int NS>
+constexpr int bf16_waves_per_simd() {
+  constexpr int lds = 2 * (BM + BN) * (NS * 64 + 16);
+  constexpr int blocks = 2 * lds <= 160 * 1024 ? 2 : 1;
+  return blocks * 64 * WM * WN / 256;
+}
+
+template <int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(64 * WM * WN, (bf16_waves_per_simd<BM, BN, WM, WN, NS>())) void conv_igemm_bf16(ConvK p, const uint4* __restrict__ wsplit) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int ROWB = NS * 64 + 16;           // bytes of an LDS row: NS planes of 32 bf16 + pad
+  constexpr int STAGE_B = (BM + BN) * ROWB;    // bytes of one K-tile stage
+  constexpr int RPP = NT / 8;                  // A rows staged per pass (8 threads x 16 B of fp32 per 32-k row)
+  constexpr int APASS = BM / RPP;
+  static_assert(BM % RPP == 0, "tile rows must divide by the staging pass");
+  constexpr int PPR = NS * 4;                  // 16 B pieces of a B row per K tile
+  constexpr int BPASS = (BN * PPR + NT - 1) / NT;
+  constexpr int LDC = BN + 4;
+  constexpr int ECAP = 2 * STAGE_B / 4 / LDC;  // rows of the fp32 output tile the two stages can hold
+  constexpr int EROWS = ECAP >= BM ? BM : (ECAP >= BM / 2 ? BM / 2 : BM / 4);  // rows per epilogue pass: divides BM
+  static_assert(EROWS >= WTM && EROWS % WTM == 0 && EROWS <= ECAP, "an epilogue pass must hold whole wave tiles");
+  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE_B];
+
+  const int t = threadIdx.x;
+  int tile;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = tile / p.ntiles_n, tile_n = tile - tile_m * p.ntiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (!tile_needed<BM, NT>(p, m0, t)) return;
+
+  const int colq = t & 7, rowb = t >> 3;
+  int pixb[APASS], ih0[APASS], iw0[APASS];
+  const bool pointwise = (p.fast & 1) && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.stride_w == 1 && p.pad == 0;
+#pragma unroll
+  for (int i = 0; i < APASS; ++i) {
+    const int m = m0 + rowb + RPP * i;
+    if (m < p.M && pointwise) {
+      pixb[i] = m;
+      ih0[i] = 0;
+      iw0[i] = 0;
+    } else if (m < p.M) {
+      const int ohw = p.OH * p.OW;
+      const int n = m / ohw, rem = m - n * ohw;
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      pixb[i] = n * p.H * p.W;
+      ih0[i] = oh * p.stride - p.pad;
+      iw0[i] = ow * p.stride_w - p.pad;
+    } else {
+      pixb[i] = 0;
+      ih0[i] = -(1 << 20);
+      iw0[i] = 0;
+    }
+  }
+  const int ktiles = p.Kpad >> 5;
+  // B pieces of this thread: piece q = t + NT * j of the tile's BN x PPR, row-major
+  const uint4* wsrc[BPASS];
+  int boff[BPASS];  // byte offset inside the B half of a stage, or -1 past the tile
+#pragma unroll
+  for (int j = 0; j < BPASS; ++j) {
+    const int q = t + NT * j;
+    const int row = q / PPR, piece = q - row * PPR;
+    const bool ok = q < BN * PPR;
+    wsrc[j] = wsplit + ((size_t)(n0 + (ok ? row : 0)) * ktiles) * PPR + piece;
+    boff[j] = ok ? row * ROWB + piece * 16 : -1;
+  }
+
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+  f32x4 ra[APASS];
+  uint4 rb[BPASS];
+  int cur_kh = 0, cur_kw = 0, cur_cc = 0;
+  unsigned voff[APASS];
+#pragma unroll
+  for (int i = 0; i < APASS; ++i) voff[i] = OOB_OFFSET;
+
+  auto load_tile = [&](int kt) {
+    if (cur_cc == 0) {  // wave-uniform: a new filter tap
+      const int dh = cur_kh * p.dil, dw = cur_kw * p.dil;
+#pragma unroll
+      for (int i = 0; i < APASS; ++i) {
+        const int ih = ih0[i] + dh, iw = iw0[i] + dw;
+        const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        const unsigned off = ((unsigned)(pixb[i] + ih * p.W + iw) * (unsigned)p.in_ld + (unsigned)(colq * 4)) * 4u;
+        voff[i] = ok ? off : OOB_OFFSET;
+      }
+    }
+    const bool chan_ok = cur_cc * 32 + colq * 4 < p.C;
+    const int soff = cur_cc * 128;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(chan_ok ? voff[i] : OOB_OFFSET), soff, 0);
+      ra[i] = __builtin_bit_cast(f32x4, v);
+    }
+    if (++cur_cc == p.ctiles) {
+      cur_cc = 0;
+      if (++cur_kw == p.KW) {
+        cur_kw = 0;
+        ++cur_kh;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) rb[j] = wsrc[j][(size_t)kt * PPR];
+  };
+
+  auto store_tile = [&](int buf) {
+    char* As = lds + buf * STAGE_B;
+    char* Bs = As + BM * ROWB;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      uint2 pl[NS];
+      split4<NS>(ra[i], pl);
+      char* row = As + (rowb + RPP * i) * ROWB + colq * 8;
+#pragma unroll
+      for (int q = 0; q < NS; ++q) *reinterpret_cast<uint2*>(row + q * 64) = pl[q];
+    }
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j)
+      if (boff[j] >= 0) *reinterpret_cast<uint4*>(Bs + boff[j]) = rb[j];
+  };
+
+  const int wv = t >> 6, lane = t & 63;
+  const int wm = wv / WN, wn = wv - wm * WN;
+  const int li = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  auto compute = [&](int buf) {
+    const char* As = lds + buf * STAGE_B + (wm * WTM + li) * ROWB + lh * 16;
+    const char* Bs = lds + buf * STAGE_B + BM * ROWB + (wn * WTN + li) * ROWB + lh * 16;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {  // two 16-k steps per K tile
+      bf16x8_t fa[TM][NS], fb[TN][NS];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int q = 0; q < NS; ++q) fa[a][q] = *reinterpret_cast<const bf16x8_t*>(As + a * 32 * ROWB + q * 64 + s * 32);
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int q = 0; q < NS; ++q) fb[b][q] = *reinterpret_cast<const bf16x8_t*>(Bs + b * 32 * ROWB + q * 64 + s * 32);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          // smallest terms first
+          if (NS == 3) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][NS - 1], fb[b][0], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][NS - 1], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], acc[a][b], 0, 0, 0);
+          }
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][0], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][1], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][0], acc[a][b], 0, 0, 0);
+        }
+    }
+  };
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < ktiles) load_tile(kt + 1);
+    compute(buf);
+    if (kt + 1 < ktiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* Cs = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int e0 = 0; e0 < BM; e0 += EROWS) {
+    if (e0 > 0) __syncthreads();
+    if (wm * WTM >= e0 && wm * WTM < e0 + EROWS) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = wm * WTM - e0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            Cs[row * LDC + wn * WTN + b * 32 + li] = acc[a][b][r];
+          }
+    }
+    __syncthreads();
+    epilogue_tile<EROWS, BN, NT>(p, Cs, m0 + e0, n0, t);
+  }
+}
+
+// ---- fp32 panel [rows][kpad] -> split panel [rows][kpad / 32][NS][32] bf16 (once, at model finalize)
+template <int NS>
+__global__ void k_split_panel(const float* __restrict__ w, unsigned short* __restrict__ out, size_t n_elems, int kpad) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_elems) return;
+  const size_t row = i / kpad;
+  const int k = (int)(i - row * kpad), kt = k >> 5, kk = k & 31;
+  float r = w[i];
+#pragma unroll
+  for (int pl = 0; pl < NS; ++pl) {
+    const __bf16 h = (__bf16)r;
+    out[((row * (kpad >> 5) + kt) * NS + pl) * 32 + kk] = __builtin_bit_cast(unsigned short, h);
+    r -= (float)h;
+  }
+}
+
+void make_split_panels(DevicePool& pool, ConvW& c) {
+  if (c.mode != 0 || c.w == nullptr) return;  // 4-channel stems keep the fp32 kernel
+  const size_t rows = (size_t)((c.cout + 127) / 128 * 128), n = rows * c.kpad;
+  unsigned short* w2 = reinterpret_cast<unsigned short*>(pool.alloc((n * 2 * 2 + 3) / 4));
+  unsigned short* w3 = reinterpret_cast<unsigned short*>(pool.alloc((n * 3 * 2 + 3) / 4));
+  const int blocks = (int)((n + 255) / 256);
+  hipLaunchKernelGGL(k_split_panel<2>, dim3(blocks), dim3(256), 0, nullptr, c.w, w2, n, c.kpad);
+  hipLaunchKernelGGL(k_split_panel<3>, dim3(blocks), dim3(256), 0, nullptr, c.w, w3, n, c.kpad);
+  YMK_HIP(hipGetLastError());
+  YMK_HIP(hipStreamSynchronize(nullptr));
+  c.w2 = w2;
+  c.w3 = w3;
+}
+
+template <int BM, int BN, int WM, int WN, int NS>
+static void launch_bf16(hipStream_t s, ConvK& k, const void* wsplit) {
+  const int mt = (k.M + BM - 1) / BM, nt = (k.Cout + BN - 1) / BN;
+  k.ntiles_n = nt;
+  auto* e = conv_prof_open(s, k, BM, BN, mt * nt, 10 * NS);
+  hipLaunchKernelGGL((conv_igemm_bf16<BM, BN, WM, WN, NS>), dim3(mt * nt), dim3(64 * WM * WN), 0, s, k,
+                     reinterpret_cast<const uint4*>(wsplit));
+  if (e) YMK_HIP(hipEventRecord(e->second, s));
+}
+
+// tile shapes, ymk_debug_option("conv_split_tile", v): 0 = the measured best per plane count (two planes: 128 x 128 with 16
+// waves, 250-300 TFLOP/s-equivalent on the K >= 1152 layers; three planes: 256 x 128 with 16 waves, 130-145 - profiles/
+// r03_conv_sweep_bf16_split.txt); for A/B runs 1 = 128 x 64 (8 waves), 2 = 256 x 128 (16), 3 = 128 x 128 (16), 4 = 128 x 128 (8)
+static std::atomic<int> g_split_tile{0};
+bool conv_bf16_debug_option(const std::string& key, int value) {
+  if (key != "conv_split_tile") return false;
+  g_split_tile = value;
+  return true;
+}
+
+bool conv2d_bf16_split(hipStream_t s, ConvK& k, const ConvW& w, int ns) {
+  if (w.mode != 0 || (ns != 2 && ns != 3)) return false;
+  const void* ws = ns == 2 ? (const void*)w.w2 : (const void*)w.w3;
+  if (ws == nullptr) return false;
+  const long blocks128 = (long)((k.M + 127) / 128) * ((w.cout + 127) / 128);
+  if (blocks128 < 256) return false;  // grid-starved launches keep the fp32 paths (split-K / small tiles)
+  int tile = g_split_tile.load(std::memory_order_relaxed);
+  if (tile == 0) tile = ns == 2 ? 3 : 2;
+  const bool narrow = w.cout <= 64 || tile == 1;
+  if (ns == 2) {
+    if (narrow) launch_bf16<128, 64, 4, 2, 2>(s, k, ws);
+    else if (tile == 2) launch_bf16<256, 128, 4, 4, 2>(s, k, ws);
+    else if (tile == 3) launch_bf16<128, 128, 4, 4, 2>(s, k, ws);
+    else launch_bf16<128, 128, 4, 2, 2>(s, k, ws);
+  } else {
+    if (narrow) launch_bf16<128, 64, 4, 2, 3>(s, k, ws);
+    else if (tile == 2) launch_bf16<256, 128, 4, 4, 3>(s, k, ws);
+    else if (tile == 3) launch_bf16<128, 128, 4, 4, 3>(s, k, ws);
+    else launch_bf16<128, 128, 4, 2, 3>(s, k, ws);
+  }
+  YMK_HIP(hipGetLastError());
+  return true;
+}
+
+}  // namespace ymk

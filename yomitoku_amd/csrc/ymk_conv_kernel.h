@@ -1,0 +1,169 @@
+// Device-side pieces shared by the implicit-GEMM convolution kernels (ymk_conv.hip: exact fp32 MFMA; ymk_conv_bf16.hip:
+// bf16-split operands, fp32 accumulate): the launch record, the row predicate and the epilogue.
+#pragma once
+#include <utility>
+
+#include "ymk_common.h"
+
+namespace ymk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvK {
+  const float* in;
+  const float* w;
+  const float* scale;
+  const float* bias;
+  const float* res;
+  float* out;
+  int H, W, C, in_ld;
+  int OH, OW, Cout, out_ld, res_ld, res_post;
+  int KH, KW, stride, stride_w, pad, dil;
+  int Kpad, ctiles, mode;
+  int M;        // n*oh*ow
+  int act, epi;
+  int ntiles_n;
+  unsigned in_bytes;  // extent of the input view (buffer descriptor range)
+  int vec;      // 1: Cout, leading dims and pointers allow 16 B epilogue accesses
+  const int* row_group;   // optional (ConvArgs): row m -> group id ...
+  const int* group_open;  // ... and the per-group "still needed" word; M tiles without a needed row return at once
+  int fast;     // bit 0: pointwise index shortcut, bit 1: residual prefetch (both on; ymk_debug_option("conv_fast") for A/B runs)
+};
+
+// true when some row of the block's M tile [m0, m0 + BM) is still needed (or no row predicate was given); block-uniform
+template <int BM, int NT>
+__device__ __forceinline__ bool tile_needed(const ConvK& p, int m0, int t) {
+  if (!p.row_group) return true;
+  int live = 0;
+  for (int r = t; r < BM; r += NT) {
+    const int m = m0 + r;
+    if (m < p.M && p.group_open[p.row_group[m]] != 0) live = 1;
+  }
+  return __syncthreads_or(live) != 0;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case ACT_RELU: return fmaxf(v, 0.f);
+    case ACT_SILU: return v / (1.f + expf(-v));
+    case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    default: return v;
+  }
+}
+
+constexpr int LDK = 36;  // padded K-tile row (floats)
+
+// A-operand gathers go through a raw buffer descriptor: padding taps and tail rows use an offset
+// beyond num_records, for which the hardware returns zeros - no branch, no select after the load,
+// so the loaded registers flow straight to ds_write and their wait can sit after the MFMAs.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in SSA registers
+constexpr unsigned OOB_OFFSET = 0xFFFFFFF0u;
+constexpr unsigned SPLITK_OOB_ROW = 0xC0000000u;  // conv_splitk: row base of a masked pixel (+ channel bytes, no wrap)
+
+// ---- epilogue over a block tile staged in LDS as Cs[BM][BN + 4]: scale/bias, residual (before or after
+// the activation), activation, plain or 2x2 pixel-shuffle store; NT threads, 16 B per lane, full rows coalesced.
+// rows a thread stores in epilogue_tile (row r0 + RPP * i, i < NR)
+template <int BM, int BN, int NT>
+struct EpiRows {
+  static constexpr int TPR = BN / 4, RPP = NT / TPR, NR = (BM + RPP - 1) / RPP;
+};
+
+// the residual values of the thread's epilogue rows, fetched ahead of the last K tile's MFMAs (short-K layers: the
+// epilogue is a large share of the block's life, and its only long-latency operation is this read)
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void prefetch_residual(const ConvK& p, int m0, int n0, int t, float4* rr) {
+  using E = EpiRows<BM, BN, NT>;
+  const int c4 = t % E::TPR, r0 = t / E::TPR;
+  const int co = n0 + c4 * 4;
+#pragma unroll
+  for (int i = 0; i < E::NR; ++i) {
+    const int m = m0 + r0 + E::RPP * i;
+    rr[i] = (co < p.Cout && m < p.M && r0 + E::RPP * i < BM) ? *reinterpret_cast<const float4*>(p.res + (size_t)m * p.res_ld + co)
+                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+template <int BM, int BN, int NT, bool PRE = false>
+__device__ __forceinline__ void epilogue_tile(const ConvK& p, const float* Cs, int m0, int n0, int t, const float4* pre = nullptr) {
+  constexpr int LDC = BN + 4;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int TPR = BN / 4;        // threads per output row
+  constexpr int RPP = NT / TPR;     // rows per pass
+  const int c4 = t % TPR, r0 = t / TPR;
+  const int co = n0 + c4 * 4;
+  if (co >= p.Cout) return;
+  const int ohw = p.OH * p.OW;
+  if (p.vec) {
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = zero4;
+    if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + co);
+    if (p.bias) bi = *reinterpret_cast<const float4*>(p.bias + co);
+    int cq = co, ab = 0;
+    if (p.epi == EPI_DECONV2X2) {
+      const int cq_n = p.Cout >> 2;
+      ab = co / cq_n;
+      cq = co - ab * cq_n;
+    }
+#pragma unroll(PRE ? EpiRows<BM, BN, NT>::NR : 4)
+    for (int i = 0; i < EpiRows<BM, BN, NT>::NR; ++i) {
+      const int row = r0 + RPP * i;
+      const int m = m0 + row;
+      if (row >= BM || m >= p.M) break;
+      float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + c4 * 4);
+      v.x = v.x * sc.x + bi.x;
+      v.y = v.y * sc.y + bi.y;
+      v.z = v.z * sc.z + bi.z;
+      v.w = v.w * sc.w + bi.w;
+      size_t o;
+      float4 rr = zero4;
+      if (p.epi == EPI_STORE) {
+        if (p.res) {
+          rr = PRE ? pre[i] : *reinterpret_cast<const float4*>(p.res + (size_t)m * p.res_ld + co);
+          if (!p.res_post) {
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+          }
+        }
+        o = (size_t)m * p.out_ld + co;
+      } else {  // ConvTranspose2d(k=2, s=2): co = (a2*2+b2)*Cq + cq -> pixel (2oh+a2, 2ow+b2)
+        const int n = m / ohw, rem = m - n * ohw;
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        const size_t opix = ((size_t)n * (2 * p.OH) + 2 * oh + (ab >> 1)) * (2 * p.OW) + 2 * ow + (ab & 1);
+        o = opix * p.out_ld + cq;
+      }
+      v.x = apply_act(v.x, p.act);
+      v.y = apply_act(v.y, p.act);
+      v.z = apply_act(v.z, p.act);
+      v.w = apply_act(v.w, p.act);
+      if (p.res_post) {  // y = res + act(conv): CSPRep "x_1 + conv2(x)" (rtdetr_hybrid_encoder.py:209-213)
+        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+      }
+      *reinterpret_cast<float4*>(p.out + o) = v;
+      if (PRE) __builtin_amdgcn_sched_barrier(0);  // one row at a time: the 16-wave tiles have 64 registers per lane
+    }
+  } else {  // ragged Cout / unaligned rows: scalar stores (EPI_STORE only)
+    for (int row = r0; row < BM; row += RPP) {
+      const int m = m0 + row;
+      if (m >= p.M) break;
+      for (int e = 0; e < 4 && co + e < p.Cout; ++e) {
+        float v = Cs[row * LDC + c4 * 4 + e];
+        v = v * (p.scale ? p.scale[co + e] : 1.f) + (p.bias ? p.bias[co + e] : 0.f);
+        const float rr = p.res ? p.res[(size_t)m * p.res_ld + co + e] : 0.f;
+        if (!p.res_post) v += rr;
+        v = apply_act(v, p.act);
+        if (p.res_post) v += rr;
+        p.out[(size_t)m * p.out_ld + co + e] = v;
+      }
+    }
+  }
+}
+
+
+// per-launch timing hooks (bench.py roofline leg), defined in ymk_conv.hip
+std::pair<hipEvent_t, hipEvent_t>* conv_prof_open(hipStream_t s, const ConvK& k, int BM, int BN, int grid, int ksplit);
+
+// bf16-split path (ymk_conv_bf16.hip): true when the launch was taken (ns = 2: hi/lo, 3 MFMAs per product tile;
+// ns = 3: hi/mid/lo, 6 MFMAs)
+bool conv2d_bf16_split(hipStream_t s, ConvK& k, const ConvW& w, int ns);
+
+}  // namespace ymk

@@ -539,7 +539,7 @@ class DocumentAnalyzer:
             out.extend((self._stage_finish(w, k), None, None) for k in range(len(chunk)))
         return out
 
-    def serve(self, sources, wave: int = 8, in_flight: int = 3, defer_full_gc: bool = True):
+    def serve(self, sources, wave: int = 8, in_flight: int = 4, defer_full_gc: bool = True):
         """The multi-page entry point: host pages (uint8 H x W x 3 BGR arrays) and / or image file paths in, one result
         per page out, in page order - the page loop of cli/main.py:105-137 as a stage pipeline on one GPU from one
         process (yomitoku_amd/serving.py): pinned staging + H2D on a copy stream, `wave` pages per device batch, up to

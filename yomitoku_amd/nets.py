@@ -61,6 +61,7 @@ class HipNet:
         self._device_index = None
         self._sd = None
         self.training = False
+        self._conv_split = None
 
     # -- nn.Module-ish surface used by the reference modules (eval/to)
     def eval(self):
@@ -108,11 +109,23 @@ class HipNet:
                     f"set_tensor {name}",
                 )
             _lib.check(lib.ymk_model_finalize(h), "ymk_model_finalize")
+            if self._conv_split is not None:
+                _lib.check(lib.ymk_model_set_param(h, b"conv_split", float(self._conv_split)), "set_param conv_split")
         except Exception:
             lib.ymk_model_destroy(h)
             raise
         self._h = h
         self._device_index = int(device_index)
+
+    def set_conv_split(self, planes):
+        """Operand precision of THIS model's convolutions / linear layers (include/ymk.h, "conv_split"): 0 = exact fp32 MFMA
+        (the default), 2 / 3 = fp32 operands cut into 2 / 3 bf16 planes with fp32 accumulation, None = follow the
+        process-wide switch.  Takes effect from the next forward."""
+        self._conv_split = None if planes is None else int(planes)
+        if self._h is not None:
+            _lib.check(_lib.load().ymk_model_set_param(self._h, b"conv_split", float(-1 if planes is None else int(planes))),
+                       "set_param conv_split")
+        return self
 
     def close(self):
         if self._h is not None:

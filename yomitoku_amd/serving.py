@@ -109,7 +109,7 @@ def _full_gc_deferred(on: bool):
 
 
 class PagePipeline:
-    def __init__(self, analyzer, wave: int = 8, in_flight: int = 3, defer_full_gc: bool = True, stage_priority=None):
+    def __init__(self, analyzer, wave: int = 8, in_flight: int = 4, defer_full_gc: bool = True, stage_priority=None):
         """stage_priority: {"detect" | "recognize" | "layout": HIP stream priority (0 default, -1 high)}; also read from
         YMK_STAGE_PRIORITY="recognize:-1,..." (measurement knob)."""
         self.analyzer = analyzer
