@@ -118,3 +118,38 @@ def test_adjacency_predicates_basic():
     assert calc_iou([0, 0, 10, 10], [0, 0, 10, 10]) == 1.0 and calc_iou([0, 0, 10, 10], [20, 20, 30, 30]) == 0
     for rule in ("hard", "soft", "nest", "child"):
         assert isinstance(is_right_adjacent(a, b, rule=rule), bool) and isinstance(is_bottom_adjacent(a, b, rule=rule), bool)
+
+
+def test_adjacency_matrices_equal_the_scalar_predicates():
+    """The matrix form behind calc_adjacent_holes_to_cells against the scalar restatement of utils/misc.py:299-441 (itself
+    pinned through tests/golden/cells.json) on random table-like boxes, touching, nested and degenerate ones included."""
+    from yomitoku_amd.geometry import adjacency_matrices, is_bottom_adjacent, is_right_adjacent
+
+    rng = np.random.default_rng(11)
+    for trial in range(30):
+        n, m = int(rng.integers(1, 14)), int(rng.integers(1, 14))
+        def boxes(k):
+            x1, y1 = rng.integers(0, 300, k), rng.integers(0, 300, k)
+            w, h = rng.integers(0 if trial % 5 == 0 else 4, 120, k), rng.integers(0 if trial % 5 == 0 else 4, 80, k)
+            return np.stack([x1, y1, x1 + w, y1 + h], 1).tolist()
+        a, b = boxes(n), boxes(m)
+        if trial % 3 == 0:  # make some exact neighbours: b_j starts where a_i ends
+            for i in range(min(n, m)):
+                b[i] = [a[i][2] + int(rng.integers(0, 20)), a[i][1] + int(rng.integers(-5, 6)), a[i][2] + 60, a[i][3] + int(rng.integers(-5, 6))]
+        right, bottom = adjacency_matrices(a, b)
+        for i in range(n):
+            for j in range(m):
+                assert bool(right[i][j]) == is_right_adjacent(a[i], b[j]), (a[i], b[j])
+                assert bool(bottom[i][j]) == is_bottom_adjacent(a[i], b[j]), (a[i], b[j])
+    r, d = adjacency_matrices([], [[0, 0, 1, 1]])
+    assert r.shape == (0, 1) and d.shape == (0, 1)
+
+
+def test_choose_role_ties():
+    from yomitoku_amd.table_cell_detector import choose_role
+
+    assert choose_role({}) is None
+    assert choose_role({"cell": 2, "header": 2, "empty": 0}) == "cell"
+    assert choose_role({"cell": 0, "header": 3, "empty": 3}) == "header"
+    assert choose_role({"cell": 1, "header": 0, "empty": 4}) == "empty"
+    assert choose_role({"cell": 0, "header": 0, "empty": 0}) == "cell"

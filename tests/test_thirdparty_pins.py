@@ -1,0 +1,224 @@
+"""The oracle's restatements of cv2 / pyclipper / torchvision / timm against the libraries' OWN outputs, stored by
+`python -m oracle.pin_third_party` on a machine that has them (they are not installable in the
+build container).  Every test SKIPS - loudly - while its file is absent; with the files present this is what turns
+"parity unpinned" into "pinned" for INTER_AREA, warpPerspective, findContours order, minAreaRect, fillPoly + mean,
+Clipper's round offset, the dilated ResNet-50 and the timm ViT."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import pin_third_party as pin
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(lib):
+    path = os.path.join(GOLD, f"thirdparty_{lib}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{os.path.relpath(path)} not generated: run `python -m oracle.pin_third_party` where {lib} is installed - "
+                    f"until then the oracle's {lib} restatement is NOT pinned against the library (parity partial)")
+    return np.load(path, allow_pickle=False)
+
+
+def test_pin_script_inputs_are_deterministic():
+    """What the stored outputs belong to: the seeded inputs must come out the same on every machine."""
+    a, b = pin.area_cases(), pin.area_cases()
+    assert all(np.array_equal(x[1], y[1]) and x[2] == y[2] for x, y in zip(a, b)) and len(a) == 12
+    assert np.array_equal(pin.contour_maps()[7], pin.contour_maps()[7]) and len(pin.contour_maps()) == 20
+    assert np.array_equal(pin.prob_map(), pin.prob_map()) and (pin.prob_map() > 0.3).any()
+    t = pin.seeded_tensor("layer1.0.conv1.weight", (64, 64, 1, 1), 201)
+    assert t.shape == (64, 64, 1, 1) and np.array_equal(t.numpy(), pin.seeded_tensor("layer1.0.conv1.weight", (64, 64, 1, 1), 201).numpy())
+    assert len(pin.unclip_boxes()) == 30 and len(pin.point_sets()) == 28 and len(pin.warp_cases()) == 6
+
+
+def test_inter_area_resize():
+    from oracle.cvlike import resize_area
+
+    z = _load("cv2")
+    for name, src, dsize in pin.area_cases():
+        want, got = z[f"area_{name}"], resize_area(src, dsize)
+        assert got.shape == want.shape and got.dtype == want.dtype
+        if src.dtype == np.uint8:
+            assert np.array_equal(got, want), name
+        else:
+            assert np.abs(got - want).max() < 1e-3, name  # 0..255 data: float summation order only
+
+
+def test_warp_perspective():
+    from oracle.cvlike import perspective_transform, warp_perspective
+
+    z = _load("cv2")
+    for name, img, quad in pin.warp_cases():
+        if f"warp_{name}" not in z.files:
+            continue
+        q = np.array(quad, dtype=np.int64)
+        w, h = int(np.linalg.norm(q[0] - q[1])), int(np.linalg.norm(q[1] - q[2]))
+        M = perspective_transform(np.float32(q), np.float32([[0, 0], [w, 0], [w, h], [0, h]]))
+        assert np.allclose(M, z[f"warp_M_{name}"], rtol=1e-9, atol=1e-9), name
+        assert np.array_equal(warp_perspective(img, M, (w, h)), z[f"warp_{name}"]), name
+
+
+def test_find_contours_order_and_points():
+    """RETR_LIST order (it fixes detection order and the max_candidates cut) and the contours themselves: every vertex
+    CHAIN_APPROX_SIMPLE keeps lies on the restated pixel chain, in the same cyclic order, starting at the same pixel."""
+    from oracle.cvlike import find_borders
+
+    z = _load("cv2")
+    for k, m in enumerate(pin.contour_maps()):
+        chains = find_borders(m)
+        assert len(chains) == int(z[f"contours_{k}_count"]), k
+        for i, chain in enumerate(chains):
+            want = [tuple(p) for p in z[f"contours_{k}_{i}"].tolist()]
+            assert tuple(chain[0]) == want[0], (k, i)
+            pos = 0
+            for p in want:  # a subsequence of the chain
+                while pos < len(chain) and tuple(chain[pos]) != p:
+                    pos += 1
+                assert pos < len(chain), (k, i, p)
+
+
+def test_min_area_rect():
+    from oracle.cvlike import min_area_rect
+
+    z = _load("cv2")
+    for k, pts in enumerate(pin.point_sets()):
+        box, short = min_area_rect([tuple(p) for p in pts.tolist()])
+        want = z[f"minrect_{k}_box"]
+        assert abs(short - float(z[f"minrect_{k}_short"])) < 1e-3, k
+        # same rectangle: corner sets agree whatever corner each library starts from
+        d = np.abs(np.asarray(box)[:, None, :] - want[None, :, :]).max(-1)
+        assert (d.min(1) < 1e-2).all() and (d.min(0) < 1e-2).all(), k
+
+
+def test_polygon_mean():
+    from oracle.cvlike import find_borders, polygon_mean
+
+    z = _load("cv2")
+    pm = pin.prob_map()
+    chains = find_borders(pm > 0.3)
+    assert len(chains) == int(z["polymean_count"])
+    for i, chain in enumerate(chains):
+        assert abs(polygon_mean(pm, chain) - float(z[f"polymean_{i}"])) < 1e-6, i
+
+
+def test_clipper_round_offset():
+    import math
+
+    from oracle.cvlike import offset_round
+
+    z = _load("pyclipper")
+    for k, box in enumerate(pin.unclip_boxes()):
+        area = length = 0.0
+        for i in range(4):
+            a, b = box[i].astype(np.float64), box[(i + 1) % 4].astype(np.float64)
+            area += a[0] * b[1] - b[0] * a[1]
+            length += math.hypot(b[0] - a[0], b[1] - a[1])
+        box_dist = min(box[:, 0].max() - box[:, 0].min(), box[:, 1].max() - box[:, 1].min())
+        distance = abs(area) * 0.5 * (3.5 / math.sqrt(box_dist)) / length
+        assert abs(distance - float(z[f"unclip_{k}_distance"])) < 1e-6 * max(1.0, distance), k  # shapely's area / length
+        assert int(z[f"unclip_{k}_paths"]) == 1, k
+        assert [list(p) for p in offset_round(box, distance)] == z[f"unclip_{k}_0"].tolist(), k
+
+
+def test_dilated_resnet50_features():
+    import torch
+
+    from oracle._refstubs import _ResNet50
+    from oracle.dbnet import resnet50_dilated_features
+
+    z = _load("torchvision")
+    names = [(k, v.shape) for k, v in _ResNet50([False, False, True]).state_dict().items() if v.dtype.is_floating_point]
+    sd = {"backbone.body." + k: v for k, v in pin.seeded_state_dict(names, 201).items()}
+    x = torch.randn(1, 3, 64, 96, generator=torch.Generator().manual_seed(202))
+    with torch.no_grad():
+        feats = resnet50_dilated_features(sd, x)
+    for i, f in enumerate(feats, start=1):
+        want = z[f"layer{i}"]
+        assert tuple(f.shape) == want.shape
+        assert np.abs(f.numpy() - want).max() < 1e-4 * max(1.0, float(np.abs(want).max())), i
+
+
+def test_timm_vit_features():
+    import torch
+
+    from oracle._refstubs import _TimmViT
+    from oracle.parseq import make_cfg, vit_encode
+
+    z = _load("timm")
+    stub = _TimmViT(img_size=(32, 800), patch_size=(4, 8), embed_dim=192, depth=2, num_heads=6, mlp_ratio=4)
+    names = [(k, v.shape) for k, v in stub.state_dict().items() if v.dtype.is_floating_point]
+    sd = {"encoder." + k: v for k, v in pin.seeded_state_dict(names, 203).items()}
+    cfg = make_cfg(patch=(4, 8), enc_dim=192, enc_heads=6, enc_depth=2)
+    x = torch.randn(2, 3, 32, 800, generator=torch.Generator().manual_seed(204))
+    with torch.no_grad():
+        y = vit_encode(sd, cfg, x)
+    want = z["features"]
+    assert tuple(y.shape) == want.shape
+    assert np.abs(y.numpy() - want).max() < 1e-4 * max(1.0, float(np.abs(want).max()))
+
+
+def test_consumers_run_end_to_end_on_self_generated_files(tmp_path, monkeypatch):
+    """Plumbing check, NOT a pin: files with the keys and shapes the pin script writes, but filled from the oracle's own
+    restatements, must satisfy every comparator above - so that the day the real files arrive, a failure means a
+    numerical disagreement with the library and not a typo in a key."""
+    import math
+
+    import torch
+
+    from oracle import cvlike
+    from oracle._refstubs import _ResNet50, _TimmViT
+    from oracle.dbnet import resnet50_dilated_features
+    from oracle.parseq import make_cfg, vit_encode
+
+    cv = {}
+    for name, src, dsize in pin.area_cases():
+        cv[f"area_{name}"] = cvlike.resize_area(src, dsize)
+    for name, img, quad in pin.warp_cases():
+        q = np.array(quad, dtype=np.int64)
+        w, h = int(np.linalg.norm(q[0] - q[1])), int(np.linalg.norm(q[1] - q[2]))
+        if w <= 0 or h <= 0:
+            continue
+        M = cvlike.perspective_transform(np.float32(q), np.float32([[0, 0], [w, 0], [w, h], [0, h]]))
+        cv[f"warp_M_{name}"], cv[f"warp_{name}"] = M, cvlike.warp_perspective(img, M, (w, h))
+    for k, m in enumerate(pin.contour_maps()):
+        chains = cvlike.find_borders(m)
+        cv[f"contours_{k}_count"] = np.array(len(chains))
+        for i, c in enumerate(chains):
+            cv[f"contours_{k}_{i}"] = np.array(c, dtype=np.int32).reshape(-1, 2)
+    for k, pts in enumerate(pin.point_sets()):
+        box, short = cvlike.min_area_rect([tuple(p) for p in pts.tolist()])
+        cv[f"minrect_{k}_box"], cv[f"minrect_{k}_short"] = np.asarray(box, dtype=np.float32), np.array(short)
+    pm = pin.prob_map()
+    chains = cvlike.find_borders(pm > 0.3)
+    cv["polymean_count"] = np.array(len(chains))
+    for i, c in enumerate(chains):
+        cv[f"polymean_{i}"] = np.array(cvlike.polygon_mean(pm, c))
+    np.savez_compressed(tmp_path / "thirdparty_cv2.npz", **cv)
+    cl = {}
+    for k, box in enumerate(pin.unclip_boxes()):
+        area = length = 0.0
+        for i in range(4):
+            a, b = box[i].astype(np.float64), box[(i + 1) % 4].astype(np.float64)
+            area += a[0] * b[1] - b[0] * a[1]
+            length += math.hypot(b[0] - a[0], b[1] - a[1])
+        dist = abs(area) * 0.5 * (3.5 / math.sqrt(min(box[:, 0].max() - box[:, 0].min(), box[:, 1].max() - box[:, 1].min()))) / length
+        cl[f"unclip_{k}_distance"], cl[f"unclip_{k}_paths"] = np.array(dist), np.array(1)
+        cl[f"unclip_{k}_0"] = np.array(cvlike.offset_round(box, dist), dtype=np.int64)
+    np.savez_compressed(tmp_path / "thirdparty_pyclipper.npz", **cl)
+    names = [(k, v.shape) for k, v in _ResNet50([False, False, True]).state_dict().items() if v.dtype.is_floating_point]
+    sd = {"backbone.body." + k: v for k, v in pin.seeded_state_dict(names, 201).items()}
+    with torch.no_grad():
+        feats = resnet50_dilated_features(sd, torch.randn(1, 3, 64, 96, generator=torch.Generator().manual_seed(202)))
+    np.savez_compressed(tmp_path / "thirdparty_torchvision.npz", **{f"layer{i}": f.numpy() for i, f in enumerate(feats, start=1)})
+    stub = _TimmViT(img_size=(32, 800), patch_size=(4, 8), embed_dim=192, depth=2, num_heads=6, mlp_ratio=4)
+    names = [(k, v.shape) for k, v in stub.state_dict().items() if v.dtype.is_floating_point]
+    sd = {"encoder." + k: v for k, v in pin.seeded_state_dict(names, 203).items()}
+    with torch.no_grad():
+        y = vit_encode(sd, make_cfg(patch=(4, 8), enc_dim=192, enc_heads=6, enc_depth=2), torch.randn(2, 3, 32, 800, generator=torch.Generator().manual_seed(204)))
+    np.savez_compressed(tmp_path / "thirdparty_timm.npz", features=y.numpy())
+    monkeypatch.setattr(sys.modules[__name__], "GOLD", str(tmp_path))
+    for check in (test_inter_area_resize, test_warp_perspective, test_find_contours_order_and_points, test_min_area_rect, test_polygon_mean,
+                  test_clipper_round_offset, test_dilated_resnet50_features, test_timm_vit_features):
+        check()

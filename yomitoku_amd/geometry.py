@@ -158,3 +158,52 @@ def is_bottom_adjacent(box_a, box_b, dist_threshold=15, overlap_ratio_th=0.1, ig
     dists = _edge_distances((ax1, ay2), (ax2, ay2), (bx1, by1), (bx2, by1))
     hard = math.hypot(ax1 - bx1, ay2 - by1) < dist_threshold and math.hypot(ax2 - bx2, ay2 - by1) < dist_threshold
     return bool(_adjacent(dists, hard, rule, dist_threshold))
+
+
+# ---- the same two predicates (rule "soft", the one calc_adjacent_holes_to_cells uses) for every pair of two box lists at
+# once.  Every distance is the same float64 expression as in the scalar form (numpy's hypot is C hypot, like math.hypot),
+# so the flags are identical; tests/test_cells.py compares the two forms on random boxes.
+def _p2s_matrix(px, py, ax, ay, bx, by):
+    import numpy as np
+
+    abx, aby = bx - ax, by - ay
+    apx, apy = px - ax, py - ay
+    denom = abx * abx + aby * aby
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = np.maximum(0.0, np.minimum(1.0, (apx * abx + apy * aby) / denom))
+    t = np.where(denom == 0, 0.0, t)  # a degenerate segment: distance to its one point
+    return np.hypot(px - (ax + t * abx), py - (ay + t * aby))
+
+
+def adjacency_matrices(boxes_a, boxes_b, dist_threshold=15, overlap_ratio_th=0.1, ignore_dist_threshold=10):
+    """(right, bottom): right[i][j] = is_right_adjacent(a_i, b_j), bottom[i][j] = is_bottom_adjacent(a_i, b_j), rule "soft"."""
+    import numpy as np
+
+    if len(boxes_a) == 0 or len(boxes_b) == 0:
+        empty = np.zeros((len(boxes_a), len(boxes_b)), dtype=bool)
+        return empty, empty.copy()
+    a = np.asarray(boxes_a, dtype=np.float64).reshape(-1, 4)[:, None, :]
+    b = np.asarray(boxes_b, dtype=np.float64).reshape(-1, 4)[None, :, :]
+    ax1, ay1, ax2, ay2 = (a[..., k] + 0 * b[..., 0] for k in range(4))
+    bx1, by1, bx2, by2 = (b[..., k] + 0 * a[..., 0] for k in range(4))
+
+    def soft(p1, p2, q1, q2):
+        d1, d2 = _p2s_matrix(*p1, *q1, *q2), _p2s_matrix(*p2, *q1, *q2)
+        d3, d4 = _p2s_matrix(*q1, *p1, *p2), _p2s_matrix(*q2, *p1, *p2)
+        near = np.maximum(d1, d4) < dist_threshold
+        for d in (np.maximum(d2, d3), np.maximum(d3, d4), np.maximum(d1, d2)):
+            near |= d < dist_threshold
+        return near
+
+    def overlap(i1, i2, j1, j2):
+        return np.maximum(0.0, np.minimum(i2, j2) - np.maximum(i1, j1))
+
+    right = ~(bx1 < ax1)
+    right &= ~(overlap(ay1, ay2, by1, by2) < overlap_ratio_th * np.minimum(ay2 - ay1, by2 - by1))
+    right &= ~((np.hypot(ax2 - bx1, ay2 - by1) < ignore_dist_threshold) | (np.hypot(ax2 - bx1, ay1 - by2) < ignore_dist_threshold))
+    right &= soft((ax2, ay1), (ax2, ay2), (bx1, by1), (bx1, by2))
+    bottom = ~(by1 < ay1)
+    bottom &= ~(overlap(ax1, ax2, bx1, bx2) < overlap_ratio_th * np.minimum(ax2 - ax1, bx2 - bx1))
+    bottom &= ~((np.hypot(ax2 - bx1, ay2 - by1) < ignore_dist_threshold) | (np.hypot(ax1 - bx2, ay2 - by1) < ignore_dist_threshold))
+    bottom &= soft((ax1, ay2), (ax2, ay2), (bx1, by1), (bx2, by1))
+    return right, bottom

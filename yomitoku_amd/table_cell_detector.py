@@ -19,7 +19,7 @@ import torch
 from . import _lib, imaging
 from .base import BaseModelCatalog, BaseModule, load_config, logger
 from .configs import TableCellParserRTDETRv2Config
-from .geometry import calc_iou, filter_by_flag, is_bottom_adjacent, is_contained, is_right_adjacent
+from .geometry import adjacency_matrices, calc_iou, containment_matrix, filter_by_flag, is_contained
 from .layout_parser import RTDETRPostProcessor, load_local_checkpoint
 from .nets import RTDETRv2
 from .schemas import CellSchema, RegionSchema, TableDetectorSchema
@@ -61,15 +61,10 @@ def filter_contained_rectangles_with_category(category_elements, ignore_categori
 
 
 def filter_contained_rectangles_across_categories(category_elements, source, target):
-    """Drop `target` boxes that lie inside a `source` box (table_cell_detector.py:100-113)."""
-    src = [e["box"] for e in category_elements[source]]
-    tgt = [e["box"] for e in category_elements[target]]
-    keep = [True] * len(tgt)
-    for src_box in src:
-        for j, tgt_box in enumerate(tgt):
-            if is_contained(src_box, tgt_box):
-                keep[j] = False
-    category_elements[target] = filter_by_flag(category_elements[target], keep)
+    """`target` boxes more than 80 % inside some `source` box go (table_cell_detector.py:100-113): one containment matrix
+    over all (source, target) pairs instead of the pair loop."""
+    inside = containment_matrix([e["box"] for e in category_elements[source]], [e["box"] for e in category_elements[target]], 0.8)
+    category_elements[target] = filter_by_flag(category_elements[target], (~inside.any(axis=0)).tolist())
     return category_elements
 
 
@@ -91,38 +86,34 @@ def find_holes_as_rects(table_shape, cell_boxes, pad=2, close_ksize=5, min_area=
         return out[: n.value].tolist()
 
 
+_ROLES = ("cell", "header", "empty")
+
+
 def choose_role(role_counts):
+    """Majority role; among equals the earlier of cell / header / empty - which is the reference's "ties go to cell, else
+    the first candidate" (table_cell_detector.py:146-158) because `cell` comes first."""
     if not role_counts:
         return None
-    max_count = max(role_counts.values())
-    candidates = [r for r, c in role_counts.items() if c == max_count]
-    if len(candidates) > 1 and "cell" in candidates:  # ties go to "cell"
-        return "cell"
-    return candidates[0]
+    return max(role_counts, key=lambda r: (role_counts[r], -list(role_counts).index(r)))
 
 
 def calc_adjacent_holes_to_cells(holes, cells):
-    """A hole becomes a cell when detected cells touch it on more than two sides; its role is the majority role of those
-    neighbours (table_cell_detector.py:161-192)."""
+    """A hole becomes a cell when detected cells touch it on more than two of its four sides; its role is the majority role
+    over every (side, neighbour) contact (table_cell_detector.py:161-192).  All hole x cell contacts come from four
+    adjacency matrices (geometry.adjacency_matrices) instead of 4 x holes x cells scalar predicates."""
+    if not holes:
+        return []
+    hole_boxes, cell_boxes = [h["box"] for h in holes], [c["box"] for c in cells]
+    right, down = adjacency_matrices(hole_boxes, cell_boxes)   # the cell is the hole's right / lower neighbour
+    left, up = (m.T for m in adjacency_matrices(cell_boxes, hole_boxes))  # the hole is the cell's right / lower neighbour
+    sides = right.any(1).astype(int) + left.any(1) + down.any(1) + up.any(1)
+    contacts = right.astype(np.int64) + left + down + up  # a cell counts once per side it touches
+    role_of = np.array([_ROLES.index(c["role"]) for c in cells], dtype=np.int64).reshape(-1)
+    counts = np.stack([(contacts * (role_of == k)[None, :]).sum(1) for k in range(len(_ROLES))], axis=1) if cells else np.zeros((len(holes), 3), np.int64)
     kept = []
-    for hole in holes:
-        edge_counts = {d: 0 for d in ("R", "L", "D", "U")}
-        role_counts = {r: 0 for r in ("cell", "header", "empty")}
-        for node in cells:
-            if is_right_adjacent(hole["box"], node["box"]):
-                edge_counts["R"] += 1
-                role_counts[node["role"]] += 1
-            if is_right_adjacent(node["box"], hole["box"]):
-                edge_counts["L"] += 1
-                role_counts[node["role"]] += 1
-            if is_bottom_adjacent(hole["box"], node["box"]):
-                edge_counts["D"] += 1
-                role_counts[node["role"]] += 1
-            if is_bottom_adjacent(node["box"], hole["box"]):
-                edge_counts["U"] += 1
-                role_counts[node["role"]] += 1
-        if sum(c > 0 for c in edge_counts.values()) > 2:
-            hole["role"] = choose_role(role_counts)
+    for hole, n_sides, row in zip(holes, sides.tolist(), counts):
+        if n_sides > 2:
+            hole["role"] = _ROLES[int(np.argmax(row))]  # first maximum: cell before header before empty
             kept.append(hole)
     return kept
 
