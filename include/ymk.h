@@ -149,6 +149,8 @@ int ymk_prof_begin(void);
  *   prints one line per launch      "parseq_unfused" (0)  1: per-op PARSeq decoder step at every width
  *   "conv_fast" (3)      bit 0: index shortcut of 1x1 / stride-1 layers, bit 1: residual rows fetched ahead (0 = the A/B baseline)
  *   "dec_rows" (0)       samples per block of the fused greedy step: 0 = by row count, 1 / 2 / 4 forced (bit-identical results)
+ *   "parseq_no_rowmax" (0)  1: the fused greedy loop writes every step's logits and arg-maxes them from memory (round-2 form);
+ *                        0: the vocabulary head's epilogue reduces each 64-column tile to (max, column) and no AR logits exist
  *   "conv_split" (0)     2 / 3: convolutions that fill the chip run with their fp32 operands cut into 2 / 3 bf16 planes and
  *                        3 / 6 v_mfma_f32_32x32x16_bf16 per product tile, fp32 accumulation (ymk_conv_bf16.hip); 0 = exact fp32 MFMA.
  *                        Also set for a whole process by the environment variable YMK_CONV_SPLIT (yomitoku_amd/_lib.py).

@@ -9,7 +9,10 @@
               8 x 8 patches, depth 12) on two widths against the oracle forward;
   configs[3]  one whole DocumentAnalyzerSchema against the ORACLE chain (not against the product's own stages):
               continuous stages within tolerance, every discrete stage fed the same upstream tensor on both sides,
-              and the final schema equal to the (reference-pinned) aggregation of the oracle-side stage results.
+              and the final schema equal to the (reference-pinned) aggregation of the oracle-side stage results - on a
+              1000 x 1400 page and on BASELINE's 1600 x 1200;
+  at the shapes the bench runs: configs[2] on all 2048 lines (16 mini-batches, two grouped forwards), and a wave-sized
+              grouped forward (~650 lines, 30 mini-batches, rows-per-block of the fused greedy step on auto).
 """
 import numpy as np
 import pytest
@@ -83,7 +86,85 @@ def test_parseq_large_v4_1_geometry(dev, width, batch):
     assert (out - ref).abs().max().item() < 1e-3
 
 
-def test_whole_page_schema_vs_oracle_chain(dev):
+def test_text_recognizer_2048_lines_every_mini_batch(dev):
+    """configs[2] at its full size: ONE TextRecognizer("parseq") call on 2048 lines = 16 mini-batches of 128 through two
+    grouped forwards.  The oracle chain (oracle.pipeline.recognize: crops, bucketing, batching, decode, un-permutation) runs
+    over all 2048 lines; its network forward is the CPU oracle for two of the 16 mini-batches (the narrowest and a middle
+    one: a 128-line full-depth forward costs tens of seconds on the host) and the product's own SINGLE-group call for the
+    others - so every mini-batch of the grouped forwards is checked against its own call, two of them against the
+    oracle, and strings / directions / points / scores of all 2048 lines against the chain."""
+    from oracle import pipeline as op
+    from oracle.parseq import PRESETS, make_cfg, parseq_forward
+    from yomitoku_amd.text_recognizer import TextRecognizer
+    from yomitoku_amd.utils.synth import parseq_state_dict, synthetic_line_sheet
+
+    sheet, quads = synthetic_line_sheet(seed=1, n_lines=2048)
+    rec = TextRecognizer(model_name="parseq", from_pretrained=False, device="cuda:0", dynamic_width=True, batch_bucketing=True)
+    sd = parseq_state_dict(1236, patch=(8, 8), enc_dim=512, dec_dim=512, num_tokens=7312, eos_bias=6.5)
+    rec.model.load_state_dict(sd)
+    batches, _, _, order = rec.preprocess(sheet, quads)
+    assert len(batches) == 16 and all(len(b) == 128 for b in batches) and order is not None
+    res, _ = rec(sheet, quads)
+    ocfg = make_cfg(**PRESETS["parseq"])
+    calls = []
+
+    def forward(x):
+        k = len(calls)
+        calls.append(tuple(x.shape))
+        if k in (0, 8):
+            return parseq_forward(sd, ocfg, x)
+        return rec.model(x.to(dev)).cpu()
+
+    contents, scores, directions = op.recognize(sd, ocfg, sheet, quads, rec.charset, dynamic_width=True, batch_bucketing=True,
+                                                width_budget=None, max_batch_size=None, batch_size=128, forward=forward)
+    assert len(calls) == 16 and calls[0][0] == 128
+    assert res.points == quads and len(res.contents) == 2048
+    assert res.contents == contents and res.directions == directions
+    assert np.allclose(res.scores, scores, rtol=1e-3, atol=1e-6)
+    print("2048 lines: distinct strings", len(set(contents)), "widest mini-batch", max(c[3] for c in calls), "px")
+
+
+def test_wave_sized_grouped_forward(dev):
+    """The shape the analyzer bench runs: ~650 lines in 30 mini-batches of one grouped forward, rows-per-block of the fused
+    greedy step left on AUTO (more than 288 rows: two rows per block).  Six groups against the oracle, every group against
+    its own single-group call (tokens, step counts, logits)."""
+    from oracle.parseq import parseq_forward
+    from tests.test_parseq_gpu import LOGIT_TOL, _groups, _net
+    from yomitoku_amd.utils.synth import parseq_state_dict
+
+    sd = parseq_state_dict(1235, eos_bias=5.5)
+    ocfg, net = _net(dev, sd)
+    rng = np.random.default_rng(8)
+    shapes = []
+    while sum(b for b, _ in shapes) < 640 or len(shapes) < 30:
+        w = int(rng.choice([72, 96, 128, 160, 200, 240, 320, 400, 560, 800]))
+        shapes.append((int(min(32, max(1, 8000 // w - int(rng.integers(0, 4))))), w))
+    xs = _groups(300, shapes)
+    rows = sum(x.shape[0] for x in xs)
+    assert rows >= 600 and len(xs) >= 25
+    logits, out_lens, steps = net.forward_groups([x.to(dev) for x in xs])
+    lg = logits.cpu()
+    assert len(set(steps)) > 3, "groups should stop at different steps"
+    small = sorted(range(len(xs)), key=lambda g: xs[g].shape[0] * xs[g].shape[3])
+    oracle_groups = set(small[:4] + small[len(small) // 2 : len(small) // 2 + 2])
+    row = 0
+    for g, (x, n, st) in enumerate(zip(xs, out_lens, steps)):
+        got = lg[row : row + x.shape[0], :n]
+        one = net(x.to(dev)).cpu()
+        assert net.last_ar_steps == st, g
+        assert torch.equal(one.argmax(-1), got.argmax(-1)) and (one - got).abs().max().item() < 1e-4, g
+        if g in oracle_groups:
+            ref, ref_steps = parseq_forward(sd, ocfg, x, return_steps=True)
+            assert st == ref_steps and got.shape == ref.shape, g
+            assert torch.equal(got.argmax(-1), ref.argmax(-1)) and (got - ref).abs().max().item() < LOGIT_TOL, g
+        row += x.shape[0]
+    again, _, _ = net.forward_groups([x.to(dev) for x in xs])
+    assert torch.equal(again.cpu(), lg), "bit-identical on repeat"
+    print("wave-sized forward:", rows, "lines,", len(xs), "groups, steps", min(steps), "..", max(steps))
+
+
+@pytest.mark.parametrize("page_hw", [(1000, 1400), (1600, 1200)])
+def test_whole_page_schema_vs_oracle_chain(dev, page_hw):
     from oracle import pipeline as op
     from oracle.dbnet import dbnet_forward
     from oracle.parseq import PRESETS, make_cfg
@@ -96,7 +177,7 @@ def test_whole_page_schema_vs_oracle_chain(dev):
     from yomitoku_amd.utils.synth import dbnet_state_dict, parseq_state_dict, synthetic_page_with_truth
     from yomitoku_amd.utils.synth_rtdetr import rtdetr_state_dict
 
-    img = synthetic_page_with_truth(3, 1000, 1400)[0]
+    img = synthetic_page_with_truth(3, *page_hw)[0]
     configs = {
         "ocr": {"text_detector": {"from_pretrained": False},
                 "text_recognizer": {"model_name": "parseq-tiny-dynw-v4", "from_pretrained": False, "dynamic_width": True,
@@ -132,14 +213,14 @@ def test_whole_page_schema_vs_oracle_chain(dev):
                            ref_preds["pred_logits"].numpy(), ref_preds["pred_boxes"].numpy())
     lay = lp.postprocess(preds, img.shape[:2])
     tables = []
-    assert len(lay.tables) <= 6, "pick a checkpoint with a handful of tables: each one costs an oracle forward on the CPU"
     if lay.tables:
         batch, metas = ts.preprocess(img, [t.box for t in lay.tables])
         tp = ts.model(batch)
         for i, (t, meta) in enumerate(zip(lay.tables, metas)):
-            (rp, _), = op.tables(sds["tab"], img, [t.box])
-            assert_same_detections(tp["pred_logits"][i : i + 1].cpu().numpy(), tp["pred_boxes"][i : i + 1].cpu().numpy(),
-                                   rp["pred_logits"].numpy(), rp["pred_boxes"].numpy())
+            if i < 4:  # each table costs an oracle forward on the CPU: the first four against the oracle, all through the product
+                (rp, _), = op.tables(sds["tab"], img, [t.box])
+                assert_same_detections(tp["pred_logits"][i : i + 1].cpu().numpy(), tp["pred_boxes"][i : i + 1].cpu().numpy(),
+                                       rp["pred_logits"].numpy(), rp["pred_boxes"].numpy())
             table = ts.postprocess({"pred_logits": tp["pred_logits"][i : i + 1], "pred_boxes": tp["pred_boxes"][i : i + 1]}, meta)
             if table.n_row > 0 and table.n_col > 0:
                 tables.append(table)

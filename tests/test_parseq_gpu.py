@@ -280,3 +280,31 @@ def test_fused_step_rows_per_block_agree_bit_for_bit(dev, refine):
     finally:
         _lib.debug_option("dec_rows", 0)
     assert torch.equal(one, four)  # nets.PARSeq.forward returns logits[:, :out_len]
+
+
+def test_row_max_head_gives_the_same_tokens_as_arg_max_over_stored_logits(dev):
+    """With a refinement pass to follow, the greedy loop's vocabulary head keeps only (max, column) per 64-column tile
+    (EPI_ROWMAX) instead of writing B x 7119 logits per step.  (value, lowest column) is a total order, so tokens, step
+    counts, repetition cuts and therefore the refined logits must be exactly those of the stored-logits form - compared
+    here on a grouped forward with early-finishing groups, and on a single batch."""
+    from yomitoku_amd import _lib
+    from yomitoku_amd.utils.synth import parseq_state_dict
+
+    sd = parseq_state_dict(1235, eos_bias=5.5)
+    _, net = _net(dev, sd)
+    xs = [x.to(dev) for x in _groups(53, [(7, 160), (3, 800), (9, 72), (1, 96), (6, 320), (5, 64), (40, 128)])]
+    outs = {}
+    try:
+        for flag in (1, 0):
+            _lib.debug_option("parseq_no_rowmax", flag)
+            logits, out_lens, steps = net.forward_groups(xs)
+            single = net(xs[0])
+            outs[flag] = (logits.cpu(), list(out_lens), list(steps), single.cpu(), net.last_ar_steps)
+    finally:
+        _lib.debug_option("parseq_no_rowmax", 0)
+    a, b = outs[1], outs[0]
+    assert a[1] == b[1] and a[2] == b[2] and a[4] == b[4]
+    # the head GEMM of the row-max form always takes 64 x 64 tiles (never split-K), so AR logits may differ from the stored
+    # form's in their last bits - tokens may not; the refined logits then agree to rounding
+    assert torch.equal(a[0].argmax(-1), b[0].argmax(-1)) and (a[0] - b[0]).abs().max().item() < 1e-4
+    assert torch.equal(a[3].argmax(-1), b[3].argmax(-1)) and (a[3] - b[3]).abs().max().item() < 1e-4

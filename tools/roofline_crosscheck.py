@@ -1,6 +1,6 @@
 """Cross-check bench.py's live HIP-event roofline against rocprofv3 of the same command.
 
-    rocprofv3 --kernel-trace --stats -d DIR -o kt -- python bench.py --roofline-only --procs 1 --workers 1 > line.json
+    rocprofv3 --kernel-trace --stats -d DIR -o kt -- python bench.py --roofline-only --no-cpu-baseline > line.json
     python tools/roofline_crosscheck.py line.json DIR out.json [FETCH_DIR WRITE_DIR traffic.json]
 
 `bench.py --roofline-only` runs, in this order: the serial pass once untimed (shapes seen once), the SAME serial pass
@@ -68,7 +68,7 @@ def main(argv):
     in_span = [r for r in rows if int(block[0]["Start_Timestamp"]) <= int(r["Start_Timestamp"]) <= int(block[-1]["End_Timestamp"])]
     all_kernels_ns = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in in_span)
     out = {
-        "command": "rocprofv3 --kernel-trace --stats -- python bench.py --roofline-only --procs 1 --workers 1",
+        "command": "rocprofv3 --kernel-trace --stats -- python bench.py --roofline-only --no-cpu-baseline",
         "conv_dispatches_in_trace": total, "timed_block_launches": launches, "pages_in_block": pages,
         "rocprof_avg_launch_us": round(sum(dur) / len(dur) / 1e3, 2), "bench_avg_launch_us": roof["avg_launch_us"],
         "rocprof_conv_ms_per_page": round(sum(dur) / 1e6 / pages, 4), "bench_kernel_ms_per_page": roof["kernel_ms_per_page"],
@@ -89,7 +89,7 @@ def main(argv):
         write, n_w = _counter_block(argv[5], "WRITE_SIZE", launches, tail)
         traffic = {
             "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --roofline-only "
-                      "--procs 1 --workers 1; conv dispatches of the timed serial pass only",
+                      "--no-cpu-baseline; conv dispatches of the timed serial pass only",
             "kernels": "conv_igemm<*> + conv_splitk<*>", "launches": launches,
             "conv_dispatches_in_fetch_pass": n_f, "conv_dispatches_in_write_pass": n_w,
             "fetch_bytes_per_launch_as_reported": round(fetch), "write_bytes_per_launch": round(write),

@@ -101,10 +101,15 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
-    split = os.environ.get("YMK_CONV_SPLIT")
-    if split:  # evaluation switch: bf16-split conv operands for the whole process (ymk.h: ymk_debug_option "conv_split")
-        if lib.ymk_debug_option(b"conv_split", int(split)) != 0:
-            raise YmkError("YMK_CONV_SPLIT: " + lib.ymk_last_error().decode("utf-8", "replace"))
+    # evaluation switches for a whole process (include/ymk.h: ymk_debug_option): YMK_CONV_SPLIT=2 is short for
+    # YMK_DEBUG_OPTIONS="conv_split=2"; several options are comma separated
+    spec = os.environ.get("YMK_DEBUG_OPTIONS", "")
+    if os.environ.get("YMK_CONV_SPLIT"):
+        spec += ",conv_split=" + os.environ["YMK_CONV_SPLIT"]
+    for item in filter(None, (x.strip() for x in spec.split(","))):
+        key, _, value = item.partition("=")
+        if lib.ymk_debug_option(key.strip().encode(), int(value)) != 0:
+            raise YmkError(f"YMK_DEBUG_OPTIONS ({item}): " + lib.ymk_last_error().decode("utf-8", "replace"))
     return lib
 
 

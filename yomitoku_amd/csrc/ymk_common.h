@@ -89,7 +89,11 @@ struct ConvW {
   int kpad = 0, ctiles = 0, mode = 0;
 };
 
-enum Epi : int { EPI_STORE = 0, EPI_DECONV2X2 = 1 };
+// EPI_ROWMAX: instead of the tile, every row's (largest value, its column) within the tile: out[m][tile_n] = {max as float,
+// column as int bits}, ld = 2 * ntiles_n floats, 64-column tiles - the greedy loop's vocabulary head, whose logits are only
+// ever arg-maxed (models/parseq.py:224); ties keep the lowest column, as torch.argmax does.
+enum Epi : int { EPI_STORE = 0, EPI_DECONV2X2 = 1, EPI_ROWMAX = 2 };
+constexpr int ROWMAX_TILE_N = 64;
 
 struct ConvArgs {
   int stride = 1, pad = 0, dil = 1;
@@ -121,7 +125,7 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
 // Row-major GEMM view of the same kernel: out[m][:] = act(A[m][:] . W^T * scale + bias + res[m][:]).
 // `res_ld == 0` broadcasts one residual row to every m.
 void gemm(hipStream_t s, const float* A, int M, int K, int lda, const ConvW& w, int act, const float* res, int res_ld,
-          float* out, int out_ld, const int* row_group = nullptr, const int* group_open = nullptr);
+          float* out, int out_ld, const int* row_group = nullptr, const int* group_open = nullptr, int epi = EPI_STORE);
 
 // Host-side packing: OIHW fp32 -> panel. `cin_pad4` packs for the tap4 mode (cin<=4).
 void pack_conv_weight(const float* oihw, int cout, int cin, int kh, int kw, bool tap4,

@@ -642,7 +642,10 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
     YMK_CHECK(in.c == 4 && in.ld == 4, "conv tap4 mode wants a 4-channel packed input");
   }
   YMK_CHECK(((uintptr_t)in.p & 15) == 0, "conv: input not 16B aligned");
-  if (a.epi == EPI_STORE) {
+  if (a.epi == EPI_ROWMAX) {
+    YMK_CHECK(a.res == nullptr && a.act == ACT_NONE && w.mode == 0, "row-max epilogue: plain linear layers only");
+    YMK_CHECK(out.ld == 2 * ((w.cout + ROWMAX_TILE_N - 1) / ROWMAX_TILE_N), "row-max epilogue: out must be [M][2 * ceil(Cout / 64)]");
+  } else if (a.epi == EPI_STORE) {
     YMK_CHECK(out.n == in.n && out.h == k.OH && out.w == k.OW && out.c == w.cout, "conv: bad output shape");
     if (a.res && a.res->ld != 0)  // ld == 0: one row broadcast over every output pixel
       YMK_CHECK(a.res->n == out.n && a.res->h == out.h && a.res->w == out.w && a.res->c == out.c, "conv: bad residual shape");
@@ -665,6 +668,16 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
   }
   k.fast = g_conv_fast.load(std::memory_order_relaxed);
 
+  if (a.epi == EPI_ROWMAX) {  // fixed 64-column tiles (the caller sized the partial table for them), never split-K
+    k.vec = 0;
+    const int mt = (k.M + 63) / 64, nt = (k.Cout + ROWMAX_TILE_N - 1) / ROWMAX_TILE_N;
+    k.ntiles_n = nt;
+    auto* e = conv_prof_open(s, k, 64, 64, mt * nt, 1);
+    hipLaunchKernelGGL((conv_igemm<64, 64, 2, 2, 0, 1>), dim3(mt * nt), dim3(256), 0, s, k);
+    if (e) YMK_HIP(hipEventRecord(e->second, s));
+    YMK_HIP(hipGetLastError());
+    return;
+  }
   {  // opt-in: bf16-split operands with fp32 accumulation for the launches that fill the chip (measurement / evaluation)
     const int split = t_conv_split >= 0 ? t_conv_split : g_conv_split.load(std::memory_order_relaxed);
     if (split != 0 && a.row_group == nullptr && conv2d_bf16_split(s, k, w, split)) return;
@@ -699,7 +712,7 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
 }
 
 void gemm(hipStream_t s, const float* A, int M, int K, int lda, const ConvW& w, int act, const float* res, int res_ld,
-          float* out, int out_ld, const int* row_group, const int* group_open) {
+          float* out, int out_ld, const int* row_group, const int* group_open, int epi) {
   YMK_CHECK(K == w.cin, "gemm: K " + std::to_string(K) + " != weight in-features " + std::to_string(w.cin));
   Tensor in{const_cast<float*>(A), 1, 1, M, K, lda};
   Tensor o{out, 1, 1, M, w.cout, out_ld};
@@ -709,6 +722,7 @@ void gemm(hipStream_t s, const float* A, int M, int K, int lda, const ConvW& w, 
   a.res = res ? &r : nullptr;
   a.row_group = row_group;
   a.group_open = group_open;
+  a.epi = epi;
   conv2d(s, in, w, a, o);
 }
 

@@ -43,24 +43,28 @@ __device__ __forceinline__ void split4(const f32x4 v, uint2* planes) {
 }
 
 // blocks of this shape a CU's 160 KB of LDS holds (at most 2 are asked for) -> minimum waves per SIMD for the register allocator
-template <int BM, int BN, int WM, int WN, int NS>
+template <int BM, int BN, int WM, int WN, int NS, int KS>
 constexpr int bf16_waves_per_simd() {
-  constexpr int lds = 2 * (BM + BN) * (NS * 64 + 16);
+  constexpr int lds = 2 * (BM + BN) * (KS * NS * 64 + 16);
   constexpr int blocks = 2 * lds <= 160 * 1024 ? 2 : 1;
   return blocks * 64 * WM * WN / 256;
 }
 
-template <int BM, int BN, int WM, int WN, int NS>
-__global__ __launch_bounds__(64 * WM * WN, (bf16_waves_per_simd<BM, BN, WM, WN, NS>())) void conv_igemm_bf16(ConvK p, const uint4* __restrict__ wsplit) {
+// KS: 32-k tiles per LDS stage (a stage = one barrier interval: KS = 2 halves the barriers per k and doubles the MFMAs a wave
+// issues between them); PF: stages the global loads run ahead of the MFMAs (2 = two register sets, as conv_igemm's PF).
+template <int BM, int BN, int WM, int WN, int NS, int KS, int PF>
+__global__ __launch_bounds__(64 * WM * WN, (bf16_waves_per_simd<BM, BN, WM, WN, NS, KS>())) void conv_igemm_bf16(ConvK p, const uint4* __restrict__ wsplit) {
+  static_assert(PF == 1 || PF == 2, "prefetch distance 1 or 2 stages");
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int ROWB = NS * 64 + 16;           // bytes of an LDS row: NS planes of 32 bf16 + pad
-  constexpr int STAGE_B = (BM + BN) * ROWB;    // bytes of one K-tile stage
+  constexpr int TILEB = NS * 64;               // bytes of one 32-k tile of a row: NS planes of 32 bf16
+  constexpr int ROWB = KS * TILEB + 16;        // bytes of an LDS row: KS tiles + pad (row stride = 4 x odd dwords)
+  constexpr int STAGE_B = (BM + BN) * ROWB;    // bytes of one stage
   constexpr int RPP = NT / 8;                  // A rows staged per pass (8 threads x 16 B of fp32 per 32-k row)
   constexpr int APASS = BM / RPP;
   static_assert(BM % RPP == 0, "tile rows must divide by the staging pass");
-  constexpr int PPR = NS * 4;                  // 16 B pieces of a B row per K tile
+  constexpr int PPR = NS * 4;                  // 16 B pieces of a B row per 32-k tile
   constexpr int BPASS = (BN * PPR + NT - 1) / NT;
   constexpr int LDC = BN + 4;
   constexpr int ECAP = 2 * STAGE_B / 4 / LDC;  // rows of the fp32 output tile the two stages can hold
@@ -102,7 +106,8 @@ __global__ __launch_bounds__(64 * WM * WN, (bf16_waves_per_simd<BM, BN, WM, WN, 
       iw0[i] = 0;
     }
   }
-  const int ktiles = p.Kpad >> 5;
+  const int ktiles = p.Kpad >> 5;   // a multiple of KS (the launcher checks)
+  const int nstages = ktiles / KS;
   // B pieces of this thread: piece q = t + NT * j of the tile's BN x PPR, row-major
   const uint4* wsrc[BPASS];
   int boff[BPASS];  // byte offset inside the B half of a stage, or -1 past the tile
@@ -116,56 +121,63 @@ __global__ __launch_bounds__(64 * WM * WN, (bf16_waves_per_simd<BM, BN, WM, WN, 
   }
 
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
-  f32x4 ra[APASS];
-  uint4 rb[BPASS];
+  f32x4 ra[PF][KS][APASS];
+  uint4 rb[PF][KS][BPASS];
   int cur_kh = 0, cur_kw = 0, cur_cc = 0;
   unsigned voff[APASS];
 #pragma unroll
   for (int i = 0; i < APASS; ++i) voff[i] = OOB_OFFSET;
 
-  auto load_tile = [&](int kt) {
-    if (cur_cc == 0) {  // wave-uniform: a new filter tap
-      const int dh = cur_kh * p.dil, dw = cur_kw * p.dil;
+  // stage st (K tiles st * KS .. + KS - 1) -> register set `set`; the tap cursor walks K tile by K tile
+  auto load_stage = [&](int st, int set) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (cur_cc == 0) {  // wave-uniform: a new filter tap
+        const int dh = cur_kh * p.dil, dw = cur_kw * p.dil;
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+          const int ih = ih0[i] + dh, iw = iw0[i] + dw;
+          const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+          const unsigned off = ((unsigned)(pixb[i] + ih * p.W + iw) * (unsigned)p.in_ld + (unsigned)(colq * 4)) * 4u;
+          voff[i] = ok ? off : OOB_OFFSET;
+        }
+      }
+      const bool chan_ok = cur_cc * 32 + colq * 4 < p.C;
+      const int soff = cur_cc * 128;
 #pragma unroll
       for (int i = 0; i < APASS; ++i) {
-        const int ih = ih0[i] + dh, iw = iw0[i] + dw;
-        const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        const unsigned off = ((unsigned)(pixb[i] + ih * p.W + iw) * (unsigned)p.in_ld + (unsigned)(colq * 4)) * 4u;
-        voff[i] = ok ? off : OOB_OFFSET;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(chan_ok ? voff[i] : OOB_OFFSET), soff, 0);
+        ra[set][ks][i] = __builtin_bit_cast(f32x4, v);
       }
-    }
-    const bool chan_ok = cur_cc * 32 + colq * 4 < p.C;
-    const int soff = cur_cc * 128;
-#pragma unroll
-    for (int i = 0; i < APASS; ++i) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(chan_ok ? voff[i] : OOB_OFFSET), soff, 0);
-      ra[i] = __builtin_bit_cast(f32x4, v);
-    }
-    if (++cur_cc == p.ctiles) {
-      cur_cc = 0;
-      if (++cur_kw == p.KW) {
-        cur_kw = 0;
-        ++cur_kh;
+      if (++cur_cc == p.ctiles) {
+        cur_cc = 0;
+        if (++cur_kw == p.KW) {
+          cur_kw = 0;
+          ++cur_kh;
+        }
       }
-    }
 #pragma unroll
-    for (int j = 0; j < BPASS; ++j) rb[j] = wsrc[j][(size_t)kt * PPR];
+      for (int j = 0; j < BPASS; ++j) rb[set][ks][j] = wsrc[j][(size_t)(st * KS + ks) * PPR];
+    }
   };
 
-  auto store_tile = [&](int buf) {
+  auto store_stage = [&](int buf, int set) {
     char* As = lds + buf * STAGE_B;
     char* Bs = As + BM * ROWB;
 #pragma unroll
-    for (int i = 0; i < APASS; ++i) {
-      uint2 pl[NS];
-      split4<NS>(ra[i], pl);
-      char* row = As + (rowb + RPP * i) * ROWB + colq * 8;
+    for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-      for (int q = 0; q < NS; ++q) *reinterpret_cast<uint2*>(row + q * 64) = pl[q];
+      for (int i = 0; i < APASS; ++i) {
+        uint2 pl[NS];
+        split4<NS>(ra[set][ks][i], pl);
+        char* row = As + (rowb + RPP * i) * ROWB + ks * TILEB + colq * 8;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) *reinterpret_cast<uint2*>(row + q * 64) = pl[q];
+      }
+#pragma unroll
+      for (int j = 0; j < BPASS; ++j)
+        if (boff[j] >= 0) *reinterpret_cast<uint4*>(Bs + boff[j] + ks * TILEB) = rb[set][ks][j];
     }
-#pragma unroll
-    for (int j = 0; j < BPASS; ++j)
-      if (boff[j] >= 0) *reinterpret_cast<uint4*>(Bs + boff[j]) = rb[j];
   };
 
   const int wv = t >> 6, lane = t & 63;
@@ -180,46 +192,64 @@ __global__ __launch_bounds__(64 * WM * WN, (bf16_waves_per_simd<BM, BN, WM, WN, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+  // product terms, smallest first: (A plane, B plane)
+  constexpr int NTERM = NS == 3 ? 6 : 3;
+  constexpr int TA[6] = {NS - 1, 0, 1, 1, 0, 0};
+  constexpr int TB[6] = {0, NS - 1, 1, 0, 1, 0};
+  constexpr int T0 = NS == 3 ? 0 : 3;
+
   auto compute = [&](int buf) {
     const char* As = lds + buf * STAGE_B + (wm * WTM + li) * ROWB + lh * 16;
     const char* Bs = lds + buf * STAGE_B + BM * ROWB + (wn * WTN + li) * ROWB + lh * 16;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {  // two 16-k steps per K tile
-      bf16x8_t fa[TM][NS], fb[TN][NS];
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int a = 0; a < TM; ++a)
+      for (int s = 0; s < 2; ++s) {  // two 16-k steps per 32-k tile
+        bf16x8_t fa[TM][NS], fb[TN][NS];
 #pragma unroll
-        for (int q = 0; q < NS; ++q) fa[a][q] = *reinterpret_cast<const bf16x8_t*>(As + a * 32 * ROWB + q * 64 + s * 32);
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-      for (int b = 0; b < TN; ++b)
+          for (int q = 0; q < NS; ++q) fa[a][q] = *reinterpret_cast<const bf16x8_t*>(As + a * 32 * ROWB + ks * TILEB + q * 64 + s * 32);
 #pragma unroll
-        for (int q = 0; q < NS; ++q) fb[b][q] = *reinterpret_cast<const bf16x8_t*>(Bs + b * 32 * ROWB + q * 64 + s * 32);
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
-      for (int a = 0; a < TM; ++a)
+          for (int q = 0; q < NS; ++q) fb[b][q] = *reinterpret_cast<const bf16x8_t*>(Bs + b * 32 * ROWB + ks * TILEB + q * 64 + s * 32);
+        // term-major: consecutive MFMAs go to different accumulators whenever a wave owns more than one 32 x 32 tile
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          // smallest terms first
-          if (NS == 3) {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][NS - 1], fb[b][0], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][NS - 1], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], acc[a][b], 0, 0, 0);
-          }
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][0], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][1], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][0], acc[a][b], 0, 0, 0);
-        }
-    }
+        for (int tm = 0; tm < NTERM; ++tm)
+#pragma unroll
+          for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][TA[T0 + tm]], fb[b][TB[T0 + tm]], acc[a][b], 0, 0, 0);
+      }
   };
 
-  load_tile(0);
-  store_tile(0);
+  load_stage(0, 0);
+  store_stage(0, 0);
+  if (PF == 2 && nstages > 1) load_stage(1, 1);
   __syncthreads();
-  for (int kt = 0; kt < ktiles; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < ktiles) load_tile(kt + 1);
-    compute(buf);
-    if (kt + 1 < ktiles) store_tile(buf ^ 1);
-    __syncthreads();
+  if (PF == 1) {
+    for (int st = 0; st < nstages; ++st) {
+      const int buf = st & 1;
+      if (st + 1 < nstages) load_stage(st + 1, 0);
+      compute(buf);
+      if (st + 1 < nstages) store_stage(buf ^ 1, 0);
+      __syncthreads();
+    }
+  } else {
+    // stage s travels in register set s & 1: loaded at the top of step s - 2, written to LDS[s & 1] at the end of step s - 1
+    for (int st = 0; st < nstages; st += 2) {
+      if (st + 2 < nstages) load_stage(st + 2, 0);
+      compute(0);
+      if (st + 1 < nstages) store_stage(1, PF - 1);
+      __syncthreads();
+      if (st + 1 >= nstages) break;
+      if (st + 3 < nstages) load_stage(st + 3, PF - 1);
+      compute(1);
+      if (st + 2 < nstages) store_stage(0, 0);
+      __syncthreads();
+    }
   }
 
   float* Cs = reinterpret_cast<float*>(lds);
@@ -272,24 +302,51 @@ void make_split_panels(DevicePool& pool, ConvW& c) {
   c.w3 = w3;
 }
 
-template <int BM, int BN, int WM, int WN, int NS>
+template <int BM, int BN, int WM, int WN, int NS, int KS = 1, int PF = 1>
 static void launch_bf16(hipStream_t s, ConvK& k, const void* wsplit) {
+  if (KS > 1 && (k.Kpad >> 5) % KS != 0) {  // a stage holds KS whole K tiles: odd tile counts take the one-tile form
+    launch_bf16<BM, BN, WM, WN, NS, 1, PF>(s, k, wsplit);
+    return;
+  }
   const int mt = (k.M + BM - 1) / BM, nt = (k.Cout + BN - 1) / BN;
   k.ntiles_n = nt;
   auto* e = conv_prof_open(s, k, BM, BN, mt * nt, 10 * NS);
-  hipLaunchKernelGGL((conv_igemm_bf16<BM, BN, WM, WN, NS>), dim3(mt * nt), dim3(64 * WM * WN), 0, s, k,
+  hipLaunchKernelGGL((conv_igemm_bf16<BM, BN, WM, WN, NS, KS, PF>), dim3(mt * nt), dim3(64 * WM * WN), 0, s, k,
                      reinterpret_cast<const uint4*>(wsplit));
   if (e) YMK_HIP(hipEventRecord(e->second, s));
 }
 
-// tile shapes, ymk_debug_option("conv_split_tile", v): 0 = the measured best per plane count (two planes: 128 x 128 with 16
-// waves, 250-300 TFLOP/s-equivalent on the K >= 1152 layers; three planes: 256 x 128 with 16 waves, 130-145 - profiles/
-// r03_conv_sweep_bf16_split.txt); for A/B runs 1 = 128 x 64 (8 waves), 2 = 256 x 128 (16), 3 = 128 x 128 (16), 4 = 128 x 128 (8)
+// tile shapes, ymk_debug_option("conv_split_tile", v): 0 = the measured best per plane count (profiles/
+// r03_conv_sweep_bf16_split*.txt); for A/B runs
+//   1 = 128 x 64, 8 waves          2 = 256 x 128, 16 waves        3 = 128 x 128, 16 waves        4 = 128 x 128, 8 waves
+//   5 = 128 x 128, 16 waves, 64-k stages              6 = the same, loads two stages ahead
+//   7 = 128 x 128, 8 waves, 64-k stages, two ahead    8 = 256 x 128, 16 waves, 32-k stages, two ahead
+//   9 = 128 x 128, 8 waves, 32-k stages, two ahead   10 = 128 x 128, 16 waves, 32-k stages, two ahead
 static std::atomic<int> g_split_tile{0};
 bool conv_bf16_debug_option(const std::string& key, int value) {
   if (key != "conv_split_tile") return false;
   g_split_tile = value;
   return true;
+}
+
+template <int NS>
+static void dispatch_bf16(hipStream_t s, ConvK& k, const void* ws, int tile, bool narrow) {
+  if (narrow) {
+    launch_bf16<128, 64, 4, 2, NS>(s, k, ws);
+    return;
+  }
+  switch (tile) {
+    case 2: launch_bf16<256, 128, 4, 4, NS>(s, k, ws); break;
+    case 4: launch_bf16<128, 128, 4, 2, NS>(s, k, ws); break;
+    // 64-k stages of three planes do not fit the CU's LDS (205 KB): those selectors keep 32-k stages there
+    case 5: launch_bf16<128, 128, 4, 4, NS, NS == 2 ? 2 : 1, 1>(s, k, ws); break;
+    case 6: launch_bf16<128, 128, 4, 4, NS, NS == 2 ? 2 : 1, 2>(s, k, ws); break;
+    case 7: launch_bf16<128, 128, 4, 2, NS, NS == 2 ? 2 : 1, 2>(s, k, ws); break;
+    case 8: launch_bf16<256, 128, 4, 4, NS, 1, 2>(s, k, ws); break;
+    case 9: launch_bf16<128, 128, 4, 2, NS, 1, 2>(s, k, ws); break;
+    case 10: launch_bf16<128, 128, 4, 4, NS, 1, 2>(s, k, ws); break;
+    default: launch_bf16<128, 128, 4, 4, NS>(s, k, ws); break;
+  }
 }
 
 bool conv2d_bf16_split(hipStream_t s, ConvK& k, const ConvW& w, int ns) {
@@ -301,17 +358,8 @@ bool conv2d_bf16_split(hipStream_t s, ConvK& k, const ConvW& w, int ns) {
   int tile = g_split_tile.load(std::memory_order_relaxed);
   if (tile == 0) tile = ns == 2 ? 3 : 2;
   const bool narrow = w.cout <= 64 || tile == 1;
-  if (ns == 2) {
-    if (narrow) launch_bf16<128, 64, 4, 2, 2>(s, k, ws);
-    else if (tile == 2) launch_bf16<256, 128, 4, 4, 2>(s, k, ws);
-    else if (tile == 3) launch_bf16<128, 128, 4, 4, 2>(s, k, ws);
-    else launch_bf16<128, 128, 4, 2, 2>(s, k, ws);
-  } else {
-    if (narrow) launch_bf16<128, 64, 4, 2, 3>(s, k, ws);
-    else if (tile == 2) launch_bf16<256, 128, 4, 4, 3>(s, k, ws);
-    else if (tile == 3) launch_bf16<128, 128, 4, 4, 3>(s, k, ws);
-    else launch_bf16<128, 128, 4, 2, 3>(s, k, ws);
-  }
+  if (ns == 2) dispatch_bf16<2>(s, k, ws, tile, narrow);
+  else dispatch_bf16<3>(s, k, ws, tile, narrow);
   YMK_HIP(hipGetLastError());
   return true;
 }

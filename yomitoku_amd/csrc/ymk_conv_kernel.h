@@ -93,6 +93,43 @@ __device__ __forceinline__ void epilogue_tile(const ConvK& p, const float* Cs, i
   constexpr int RPP = NT / TPR;     // rows per pass
   const int c4 = t % TPR, r0 = t / TPR;
   const int co = n0 + c4 * 4;
+  if (p.epi == EPI_ROWMAX) {
+    // every row of the tile -> (max over this tile's columns of scale * acc + bias, its column); the TPR lanes that hold a
+    // row are neighbours in a wave (TPR divides 64), so the row reduction is TPR / 2 .. 1 xor-shuffles; ties: lowest column
+    const int ntn = p.ntiles_n, tn = n0 / BN;
+    for (int row = r0; row < BM; row += RPP) {  // BM % RPP == 0: every lane of a row group takes the same trips
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = co + e;
+        if (c < p.Cout) {
+          const float v = Cs[row * LDC + c4 * 4 + e] * (p.scale ? p.scale[c] : 1.f) + (p.bias ? p.bias[c] : 0.f);
+          if (v > best) {
+            best = v;
+            bi = c;
+          }
+        }
+      }
+#pragma unroll
+      for (int o = TPR / 2; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > best || (ov == best && oi < bi)) {
+          best = ov;
+          bi = oi;
+        }
+      }
+      const int m = m0 + row;
+      if (c4 == 0 && m < p.M) {
+        float2 pr;
+        pr.x = best;
+        pr.y = __int_as_float(bi);
+        *reinterpret_cast<float2*>(p.out + ((size_t)m * ntn + tn) * 2) = pr;
+      }
+    }
+    return;
+  }
   if (co >= p.Cout) return;
   const int ohw = p.OH * p.OW;
   if (p.vec) {

@@ -24,9 +24,12 @@ void tile_rows(hipStream_t s, const float* src, int rows, int D, float* dst, int
 
 static std::atomic<int> g_parseq_unfused{0};  // ymk_debug_option("parseq_unfused", 1): per-op decoder path for every width (tests)
 static bool parseq_unfused() { return g_parseq_unfused.load(std::memory_order_relaxed) != 0; }
+static std::atomic<int> g_parseq_no_rowmax{0};  // ymk_debug_option("parseq_no_rowmax", 1): keep the AR logits (A/B, tests)
+static bool parseq_no_rowmax() { return g_parseq_no_rowmax.load(std::memory_order_relaxed) != 0; }
 bool parseq_debug_option(const std::string& key, int value) {
-  if (key != "parseq_unfused") return false;
-  g_parseq_unfused = value;
+  if (key == "parseq_unfused") g_parseq_unfused = value;
+  else if (key == "parseq_no_rowmax") g_parseq_no_rowmax = value;
+  else return false;
   return true;
 }
 
@@ -314,7 +317,14 @@ class ParseqModel : public Model {
     float* t1 = arena.alloc_f((size_t)MR * D);
     float* t2 = arena.alloc_f((size_t)MR * D);
     float* hdec = arena.alloc_f((size_t)MR * lin1_.cout);
-    float* arlog = arena.alloc_f((size_t)MR * C);
+    // greedy steps through the fused decoder kernel, with a refinement pass to follow: the AR logits are only ever arg-maxed
+    // (models/parseq.py:224), so the vocabulary head reduces each 64-column tile to (max, column) in its epilogue and no
+    // [B][steps][C] logit buffer exists at all (1.9 GB at 655 rows); otherwise the steps' logits are kept - they are the output
+    const bool fused = parseq_dec_step_supported(D, dh_, lin1_.cout, Lmax, NS) && !parseq_unfused();
+    const bool ar_rowmax = fused && refine_ > 0 && !parseq_no_rowmax();
+    const int head_tiles = (C + ROWMAX_TILE_N - 1) / ROWMAX_TILE_N;
+    float* arlog = ar_rowmax ? nullptr : arena.alloc_f((size_t)MR * C);
+    float* armax = ar_rowmax ? arena.alloc_f((size_t)B * head_tiles * 2) : nullptr;
     int* tok = (int*)arena.alloc_bytes((size_t)MR * sizeof(int));
     int* raw = (int*)arena.alloc_bytes((size_t)MR * sizeof(int));
     int* tok2 = (int*)arena.alloc_bytes((size_t)MR * sizeof(int));
@@ -418,7 +428,6 @@ class ParseqModel : public Model {
       }
     };
     int steps = NS;
-    const bool fused = parseq_dec_step_supported(D, dh_, lin1_.cout, L, NS) && !parseq_unfused();
     for (int i = 0; i < NS; ++i) {
       const int* prev = i > 0 ? not_done + i - 1 : nullptr;
       if (fused) {
@@ -428,7 +437,10 @@ class ParseqModel : public Model {
         parseq_dec_step(s, w, tok, NS, i, skv, NS, memkv, L, mem_tab.koff, mem_tab.klen, t1, prev, B, gid, gop, ng);
         // the vocabulary head skips the M tiles whose rows all sit in mini-batches that finished at an earlier step
         const int* open_prev = (gop && i > 0) ? gop + (size_t)(i - 1) * ng : nullptr;
-        gemm(s, t1, B, D, D, head_, ACT_NONE, nullptr, 0, arlog + (size_t)i * C, NS * C, open_prev ? gid : nullptr, open_prev);
+        if (ar_rowmax)
+          gemm(s, t1, B, D, D, head_, ACT_NONE, nullptr, 0, armax, 2 * head_tiles, open_prev ? gid : nullptr, open_prev, EPI_ROWMAX);
+        else
+          gemm(s, t1, B, D, D, head_, ACT_NONE, nullptr, 0, arlog + (size_t)i * C, NS * C, open_prev ? gid : nullptr, open_prev);
       } else {
         // content row i (token tok[:, i]) -> norm_c -> K|V cache row i
         ctx_embed_ln(s, tok, NS, i, 1, emb_, posq_, ncg_, ncb_, 1e-5f, cn, NS, D, B);
@@ -439,9 +451,14 @@ class ParseqModel : public Model {
         gemm(s, t1, B, D, D, sa_o_, ACT_NONE, posq_ + (size_t)i * D, 0, qcur, D);
         stream_tail(s, qcur, B, B, 1, memkv, L, mem_t, t1, t2, hdec, arlog + (size_t)i * C, NS * C);
       }
-      greedy_step(s, arlog + (size_t)i * C, (long)NS * C, C, i, NS, tok, raw, NS, state, eos_, rep_on_, rep_pmax_, rep_p1_,
-                  rep_min_, not_done + i, i > 0 ? not_done + i - 1 : nullptr, arrived + i,
-                  i + 1 < NS ? host_flags_dev_ + i : nullptr /* the last step's count is never read */, B, gid, gop, ng);
+      if (ar_rowmax)
+        greedy_step(s, armax, (long)2 * head_tiles, head_tiles, i, NS, tok, raw, NS, state, eos_, rep_on_, rep_pmax_, rep_p1_, rep_min_,
+                    not_done + i, i > 0 ? not_done + i - 1 : nullptr, arrived + i, i + 1 < NS ? host_flags_dev_ + i : nullptr, B, gid,
+                    gop, ng, 1);
+      else
+        greedy_step(s, arlog + (size_t)i * C, (long)NS * C, C, i, NS, tok, raw, NS, state, eos_, rep_on_, rep_pmax_, rep_p1_,
+                    rep_min_, not_done + i, i > 0 ? not_done + i - 1 : nullptr, arrived + i,
+                    i + 1 < NS ? host_flags_dev_ + i : nullptr /* the last step's count is never read */, B, gid, gop, ng);
       if (i + 1 < NS && i >= LAG && wait_flag(i - LAG) == 0) {  // every row held an <eos> after step i - LAG
         steps = i - LAG + 1;
         break;

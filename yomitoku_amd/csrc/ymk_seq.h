@@ -32,7 +32,7 @@ void ctx_embed_ln(hipStream_t s, const int* tok, int ld_tok, int pos0, int npos,
 void greedy_step(hipStream_t s, const float* logits, long ld_b, int C, int step, int num_steps, int* tok, int* raw,
                  int ld_tok, int* state, int eos_id, int rep_on, int period_max, int min_run_p1, int min_repeats,
                  int* not_done, const int* prev_not_done, int* arrived, int* host_flag, int B, const int* gid = nullptr,
-                 int* gopen = nullptr, int ng = 1);
+                 int* gopen = nullptr, int ng = 1, int partials = 0);  // partials: `logits` holds C (max, column) pairs per row
 void refine_prep(hipStream_t s, const int* raw, int ld_tok, int S, int bos_id, int eos_id, int* tok2, unsigned char* kpm,
                  int B, const int* gid = nullptr, const int* gsteps = nullptr);
 void row_argmax(hipStream_t s, const float* logits, int rows, int C, int* out);

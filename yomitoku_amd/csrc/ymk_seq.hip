@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void k_greedy_step(const float* __restrict__ l
                                                      int period_max, int min_run_p1, int min_repeats,
                                                      int* __restrict__ not_done, const int* __restrict__ prev_not_done,
                                                      int* __restrict__ arrived, int* __restrict__ host_flag,
-                                                     const int* __restrict__ gid, int* __restrict__ gopen, int ng) {
+                                                     const int* __restrict__ gid, int* __restrict__ gopen, int ng, int partials) {
   const int b = blockIdx.x, t = threadIdx.x;
   // speculative step issued after every row already held an <eos>: change nothing (not_done stays 0)
   if (prev_not_done && *prev_not_done == 0) return;
@@ -532,10 +532,36 @@ __global__ __launch_bounds__(256) void k_greedy_step(const float* __restrict__ l
   const bool frozen = gid && step > 0 && gopen[(size_t)(step - 1) * ng + g] == 0;
   __shared__ float sv[256];
   __shared__ int si[256];
-  if (!frozen) {  // block-uniform
+  if (!frozen && !partials) {  // block-uniform
     float mx, unused;
     int am;
     row_reduce_256<false>(logits + (size_t)b * ld_b, C, sv, si, mx, am, unused);
+  }
+  if (!frozen && partials) {
+    // the vocabulary head already reduced each 64-column tile to (max, column) (EPI_ROWMAX): C <= 256 pairs per row here;
+    // (value, lowest column) is a total order, so this tree gives the arg-max row_reduce_256 finds on the full row
+    const float2* pr = reinterpret_cast<const float2*>(logits + (size_t)b * ld_b);
+    float v = -INFINITY;
+    int i = 0x7fffffff;
+    if (t < C) {
+      const float2 q = pr[t];
+      v = q.x;
+      i = __float_as_int(q.y);
+    }
+    sv[t] = v;
+    si[t] = i;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (t < o) {
+        const float v2 = sv[t + o];
+        const int i2 = si[t + o];
+        if (v2 > sv[t] || (v2 == sv[t] && i2 < si[t])) {
+          sv[t] = v2;
+          si[t] = i2;
+        }
+      }
+      __syncthreads();
+    }
   }
   if (t != 0) return;
   int* st = state + b * 4;
@@ -596,10 +622,11 @@ __global__ __launch_bounds__(256) void k_greedy_step(const float* __restrict__ l
 void greedy_step(hipStream_t s, const float* logits, long ld_b, int C, int step, int num_steps, int* tok, int* raw,
                  int ld_tok, int* state, int eos_id, int rep_on, int period_max, int min_run_p1, int min_repeats,
                  int* not_done, const int* prev_not_done, int* arrived, int* host_flag, int B, const int* gid, int* gopen,
-                 int ng) {
+                 int ng, int partials) {
+  YMK_CHECK(!partials || C <= 256, "greedy step: at most 256 partial (max, column) pairs per row");
   hipLaunchKernelGGL(k_greedy_step, dim3(B), dim3(256), 0, s, logits, ld_b, C, step, num_steps, tok, raw, ld_tok, state,
                      eos_id, rep_on, period_max, min_run_p1, min_repeats, not_done, prev_not_done, arrived, host_flag, gid,
-                     gopen, ng);
+                     gopen, ng, partials);
   YMK_HIP(hipGetLastError());
 }
 
