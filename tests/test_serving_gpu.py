@@ -3,6 +3,7 @@ order) must give each page what `__call__` gives it alone, keep going past a pag
 device buffers steady (reference: the page loop and per-file error handling of cli/main.py:105-137, 555-564)."""
 import numpy as np
 import pytest
+import torch
 
 from tests.test_pipeline_gpu import _assert_same_schema
 
@@ -68,15 +69,17 @@ def test_a_stage_failure_inside_a_wave_costs_only_its_page(dev, imgs):
     an = _analyzer()
     singles = [an(img)[0].model_dump() for img in imgs[:5]]
     rec = an.text_recognizer
-    inner = rec.recognize_pages
+    inner = rec.forward_plan  # the stage that owns the PARSeq model: one grouped forward for the whole wave
     culprit = imgs[2].shape
 
-    def touchy(pages, points_list):
-        if any(tuple(p.shape) == culprit and int(p[0, 0, 0]) == 7 for p in pages):
-            raise RuntimeError("recogniser choked on this page")
-        return inner(pages, points_list)
+    def touchy(plan):
+        for _, _, ds, _ in plan["preps"]:
+            page0 = ds.page if isinstance(ds.page, torch.Tensor) else ds.page[0]  # a pyramid when some lines use a down-scaled level
+            if tuple(page0.shape) == culprit and int(page0[0, 0, 0]) == 7:
+                raise RuntimeError("recogniser choked on this page")
+        return inner(plan)
 
-    rec.recognize_pages = touchy
+    rec.forward_plan = touchy
     bad = imgs[2].copy()
     bad[0, 0, 0] = 7
     out = an.serve([imgs[0], imgs[1], bad, imgs[3], imgs[4]], wave=4, in_flight=2)

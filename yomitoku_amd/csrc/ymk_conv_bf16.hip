@@ -322,6 +322,7 @@ static void launch_bf16(hipStream_t s, ConvK& k, const void* wsplit) {
 //   5 = 128 x 128, 16 waves, 64-k stages              6 = the same, loads two stages ahead
 //   7 = 128 x 128, 8 waves, 64-k stages, two ahead    8 = 256 x 128, 16 waves, 32-k stages, two ahead
 //   9 = 128 x 128, 8 waves, 32-k stages, two ahead   10 = 128 x 128, 16 waves, 32-k stages, two ahead
+//   11 = 256 x 256, 16 waves (64 x 64 per wave), two planes
 static std::atomic<int> g_split_tile{0};
 bool conv_bf16_debug_option(const std::string& key, int value) {
   if (key != "conv_split_tile") return false;
@@ -345,6 +346,10 @@ static void dispatch_bf16(hipStream_t s, ConvK& k, const void* ws, int tile, boo
     case 8: launch_bf16<256, 128, 4, 4, NS, 1, 2>(s, k, ws); break;
     case 9: launch_bf16<128, 128, 4, 2, NS, 1, 2>(s, k, ws); break;
     case 10: launch_bf16<128, 128, 4, 4, NS, 1, 2>(s, k, ws); break;
+    case 11:  // 256 x 256, 16 waves of 64 x 64 (two planes only: three do not fit the LDS); Cout < 256 keeps 128-wide tiles
+      if (NS == 2 && k.Cout >= 256) launch_bf16<256, 256, 4, 4, 2>(s, k, ws);
+      else launch_bf16<128, 128, 4, 4, NS>(s, k, ws);
+      break;
     default: launch_bf16<128, 128, 4, 4, NS>(s, k, ws); break;
   }
 }
