@@ -119,10 +119,19 @@ def test_a_poisoned_page_fails_alone(stage):
 
 
 def test_bad_inputs_are_per_page_failures(tmp_path):
+    from PIL import Image
+
     an = StubAnalyzer()
     pipe = PagePipeline(an, wave=2, in_flight=2)
     out = pipe.serve([page(0), str(tmp_path / "missing.png"), page(2)])
     assert out[0][0] == 0 and out[2][0] == 2 and isinstance(out[1], Exception)
+    # a multi-frame file contributes one page per frame; with_source names the file and the frame of every entry
+    frames = [Image.fromarray(np.full((40, 40, 3), 40 * k, dtype=np.uint8)) for k in range(3)]
+    tiff = str(tmp_path / "three.tiff")
+    frames[0].save(tiff, save_all=True, append_images=frames[1:])
+    tagged = pipe.serve([page(0), tiff, str(tmp_path / "missing.png"), page(5)], with_source=True)
+    assert [(s, f) for s, f, _ in tagged] == [(0, 0), (1, 0), (1, 1), (1, 2), (2, 0), (3, 0)]
+    assert isinstance(tagged[4][2], Exception) and tagged[5][2][0] == 5 and tagged[0][2][0] == 0
     pipe.close()
 
 

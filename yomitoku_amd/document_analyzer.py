@@ -539,14 +539,15 @@ class DocumentAnalyzer:
             out.extend((self._stage_finish(w, k), None, None) for k in range(len(chunk)))
         return out
 
-    def serve(self, sources, wave: int = 8, in_flight: int = 4, defer_full_gc: bool = True):
+    def serve(self, sources, wave: int = 8, in_flight: int = 4, defer_full_gc: bool = True, with_source: bool = False):
         """The multi-page entry point: host pages (uint8 H x W x 3 BGR arrays) and / or image file paths in, one result
         per page out, in page order - the page loop of cli/main.py:105-137 as a stage pipeline on one GPU from one
         process (yomitoku_amd/serving.py): pinned staging + H2D on a copy stream, `wave` pages per device batch, up to
         `in_flight` waves between upload and aggregation.  A page's entry is its DocumentAnalyzerSchema - equal to
         `__call__(img)[0]` - or, when the page (or its file) failed, the exception object; the other pages are not
         affected (cli/main.py:555-564).  `defer_full_gc`: postpone CPython's generation-2 garbage collections until
-        the job is done (a full pass holds the GIL for 100+ ms with a few hundred results alive and stalls every stage)."""
+        the job is done (a full pass holds the GIL for 100+ ms with a few hundred results alive and stalls every stage).
+        `with_source`: (source index, frame index, entry) triples, for callers that write one output per file page."""
         from .serving import PagePipeline
 
         if self.visualize:
@@ -557,7 +558,7 @@ class DocumentAnalyzer:
                 pipe.close()
             pipe = self._pipeline = PagePipeline(self, wave=wave, in_flight=in_flight)
         pipe.defer_full_gc = bool(defer_full_gc)
-        return pipe.serve(sources)
+        return pipe.serve(sources, with_source=with_source)
 
     def close(self):
         pipe = getattr(self, "_pipeline", None)

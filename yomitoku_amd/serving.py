@@ -247,15 +247,17 @@ class PagePipeline:
         self._q["detect"].put(wave)
         self._q["layout"].put(wave)
 
-    def serve(self, sources: Iterable) -> List:
+    def serve(self, sources: Iterable, with_source: bool = False) -> List:
         """sources: uint8 H x W x 3 BGR arrays and / or image file paths (a multi-frame file contributes one entry per
         frame).  Returns one entry per page, in order: the DocumentAnalyzerSchema, or the exception that page (or
-        file) raised."""
+        file) raised.  with_source=True: (source index, frame index within the source, entry) triples instead - what a
+        caller that writes `<file>_p<page>.json` per page needs (cli/main.py:122-137)."""
         from .data.functions import load_image
 
         with self._serve_lock, _full_gc_deferred(self.defer_full_gc):
             job = self._job = _Job()
             n = 0
+            origin = []  # page id -> (source index, frame index)
             pend_ids, pend_imgs = [], []
 
             def flush():
@@ -283,7 +285,7 @@ class PagePipeline:
                     except Exception as exc:  # noqa: BLE001
                         job.results[idx] = exc
 
-            for src in sources:
+            for si, src in enumerate(sources):
                 if isinstance(src, np.ndarray):
                     frames = [src]
                 else:
@@ -292,9 +294,11 @@ class PagePipeline:
                     except Exception as exc:  # noqa: BLE001 - cli/main.py:555-564: log, go on with the next file
                         logger.error("cannot load %s: %s: %s", src, type(exc).__name__, exc)
                         job.results[n] = exc
+                        origin.append((si, 0))
                         n += 1
                         continue
-                for frame in frames:
+                for fi, frame in enumerate(frames):
+                    origin.append((si, fi))
                     pend_ids.append(n)
                     pend_imgs.append(frame)
                     n += 1
@@ -309,6 +313,8 @@ class PagePipeline:
                         break
                     job.cond.wait(timeout=0.05)
             self.last_job = {"pages": n, "waves": job.waves, "retried_pages": job.retried_pages}
+            if with_source:
+                return [(origin[i][0], origin[i][1], job.results[i]) for i in range(n)]
             return [job.results[i] for i in range(n)]
 
     def close(self):
