@@ -42,7 +42,8 @@ ymk_model* ymk_model_create(const char* kind, int device);
 void ymk_model_destroy(ymk_model* m);
 /* One parameter may also be set on a finalized model: "conv_split" = 0 (exact fp32 MFMA, the default), 2 or 3 (this
  * model's convolutions / linear layers that fill the chip run with their fp32 operands cut into 2 / 3 bf16 planes, fp32
- * accumulation: ymk_conv_bf16.hip), -1 (follow the process-wide ymk_debug_option). */
+ * accumulation: ymk_conv_bf16.hip), -1 (follow the process-wide ymk_debug_option).  parseq only: "conv_split_encoder" - the
+ * same choice for the ViT blocks' linear layers alone (the decoder and the vocabulary head then follow "conv_split"). */
 int ymk_model_set_param(ymk_model* m, const char* key, double value);
 int ymk_model_set_tensor(ymk_model* m, const char* name, const float* host_data, int ndim, const int64_t* dims);
 int ymk_model_finalize(ymk_model* m);

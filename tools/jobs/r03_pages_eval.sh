@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+O=gpurun_out/r03o; rm -rf $O; mkdir -p $O
+timeout 900 python tools/split_eval_pages.py 48 > $O/split_eval_pages.json 2> $O/err.log || tail -8 $O/err.log
+cat $O/split_eval_pages.json

@@ -1,0 +1,55 @@
+"""Discrete outputs of whole pages with the bf16-split convolutions on the detector and the two RT-DETRv2 nets (recogniser
+exact) against the exact-fp32 run of the same analyzer: every string / box / order / id leaf of the DocumentAnalyzerSchemas
+of N synthetic pages, through DocumentAnalyzer.serve.  Prints one JSON line."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch  # noqa: E402
+
+from split_eval import schema_diff  # noqa: E402
+
+
+def main():
+    from yomitoku_amd import DocumentAnalyzer
+    from yomitoku_amd.utils.synth import dbnet_state_dict, parseq_state_dict, synthetic_page_with_truth
+    from yomitoku_amd.utils.synth_rtdetr import rtdetr_state_dict
+
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    lite = {"ocr": {"text_detector": {"from_pretrained": False},
+                    "text_recognizer": {"model_name": "parseq-tiny-dynw-v4", "from_pretrained": False, "dynamic_width": True, "batch_bucketing": True, "source_downscale": True}},
+            "layout_analyzer": {"layout_parser": {"from_pretrained": False}, "table_structure_recognizer": {"from_pretrained": False}}}
+    an = DocumentAnalyzer(configs=lite, device="cuda:0")
+    an.text_detector.model.load_state_dict(dbnet_state_dict(1234, out_bias=-2.0))
+    an.text_recognizer.model.load_state_dict(parseq_state_dict(1235, eos_bias=6.0))
+    an.layout.layout_parser.model.load_state_dict(rtdetr_state_dict(1240, num_classes=6, score_bias=-2.0))
+    an.layout.table_structure_recognizer.model.load_state_dict(rtdetr_state_dict(1241, num_classes=3, score_bias=-1.0))
+    pages = [synthetic_page_with_truth(100 + i, *((1600, 1200) if i % 3 else (1200, 1600)))[0] for i in range(n)]
+    base = [r.model_dump() for r in an.serve(pages)]
+    nets = (an.text_detector.model, an.layout.layout_parser.model, an.layout.table_structure_recognizer.model)
+    for m in nets:
+        m.set_conv_split(2)
+    split = [r.model_dump() for r in an.serve(pages)]
+    for m in nets:
+        m.set_conv_split(0)
+    again = [r.model_dump() for r in an.serve(pages)]
+    out = {"pages": n, "words": sum(len(d["words"]) for d in base), "tables": sum(len(d["tables"]) for d in base),
+           "paragraphs": sum(len(d["paragraphs"]) for d in base)}
+    for label, other in (("split_det_layout_table_vs_fp32", split), ("fp32_repeat_vs_fp32", again)):
+        st = {"discrete": 0, "leaves": 0, "float_rel": 0.0}
+        pages_diff = 0
+        for a, b in zip(other, base):
+            before = st["discrete"]
+            schema_diff(a, b, st)
+            pages_diff += st["discrete"] > before
+        out[label] = {"discrete_leaves": st["leaves"], "discrete_leaves_differing": st["discrete"], "pages_with_a_difference": pages_diff,
+                      "max_rel_score_diff": st["float_rel"]}
+    print(json.dumps(out))
+    an.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,8 @@
 
 #include <atomic>
 
+#include <optional>
+
 #include "ymk_common.h"
 #include "ymk_seq.h"
 #include "ymk_decstep.h"
@@ -382,6 +384,12 @@ class ParseqModel : public Model {
       }
     }
     const float scale = 1.f / std::sqrt((float)hd);
+    // "conv_split_encoder" (>= 0): operand precision of the ViT blocks' linear layers alone - the memory K|V projection, the
+    // decoder and the vocabulary head then follow "conv_split" (the logits come straight out of the head GEMM, so its
+    // products are the ones whose rounding shows; the encoder's pass through twelve LayerNorms on the way)
+    const int enc_split = (int)param("conv_split_encoder", -1);
+    std::optional<ConvSplitScope> enc_scope;
+    if (enc_split >= 0) enc_scope.emplace(enc_split);
     for (const EncBlock& b : blocks_) {
       ln(s, xs, b.ln1g, b.ln1b, 1e-6f, y, M, D);
       gemm(s, y, M, D, D, b.qkv, ACT_NONE, nullptr, 0, qkv, 3 * D);
@@ -393,6 +401,7 @@ class ParseqModel : public Model {
       gemm(s, hbuf, M, b.fc1.cout, b.fc1.cout, b.fc2, ACT_NONE, xs, D, xs, D);
     }
     ln(s, xs, enc_ng_, enc_nb_, 1e-6f, mem, M, D);
+    enc_scope.reset();
 
     // ---------------- decoder: batch-invariant pieces + memory K|V
     gemm(s, mem, M, D, D, ca_kv_, ACT_NONE, nullptr, 0, memkv, 2 * D);

@@ -111,6 +111,8 @@ class HipNet:
             _lib.check(lib.ymk_model_finalize(h), "ymk_model_finalize")
             if self._conv_split is not None:
                 _lib.check(lib.ymk_model_set_param(h, b"conv_split", float(self._conv_split)), "set_param conv_split")
+            for k, v in getattr(self, "_extra_params", {}).items():
+                _lib.check(lib.ymk_model_set_param(h, k.encode(), float(v)), f"set_param {k}")
         except Exception:
             lib.ymk_model_destroy(h)
             raise
@@ -125,6 +127,14 @@ class HipNet:
         if self._h is not None:
             _lib.check(_lib.load().ymk_model_set_param(self._h, b"conv_split", float(-1 if planes is None else int(planes))),
                        "set_param conv_split")
+        return self
+
+    def set_param(self, key: str, value: float):
+        """A scalar parameter of the live handle (ymk_model_set_param); kept for rebuilds.  Used for the evaluation switches
+        that may change between forwards ("conv_split", "conv_split_encoder")."""
+        self._extra_params = dict(getattr(self, "_extra_params", {}), **{key: float(value)})
+        if self._h is not None:
+            _lib.check(_lib.load().ymk_model_set_param(self._h, key.encode(), float(value)), f"set_param {key}")
         return self
 
     def close(self):
