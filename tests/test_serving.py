@@ -22,6 +22,7 @@ class StubAnalyzer:
         self.delay = delay
         self.log = []
         self.in_flight_seen = 0
+        self.lanes_seen = set()
         self._live = set()
         self._lock = threading.Lock()
 
@@ -50,7 +51,8 @@ class StubAnalyzer:
         self._poison(wave, "crops")
         wave.rec_plan = list(wave.dets)
 
-    def _stage_recognize(self, wave):
+    def _stage_recognize(self, wave, lane=0):
+        self.lanes_seen.add(lane)
         time.sleep(self.delay)
         self._poison(wave, "recognize")
         wave.rec_plan = [d * 2 for d in wave.rec_plan]
@@ -96,8 +98,12 @@ def test_results_in_page_order_and_waves_of_the_asked_size():
     assert [o[2] for o in out] == [4] * 16 + [2] * 2  # 4 full waves and a last wave of 2
     assert pipe.last_job == {"pages": 18, "waves": 5, "retried_pages": 0}
     assert 1 <= an.in_flight_seen <= 3
+    assert an.lanes_seen == {0, 1}  # two recogniser lanes took waves (results still in page order)
     assert pipe.serve([]) == []
     pipe.close()
+    one = PagePipeline(StubAnalyzer(), wave=4, in_flight=3, rec_lanes=1)
+    assert [o[0] for o in one.serve([page(i) for i in range(9)])] == list(range(9)) and one.analyzer.lanes_seen == {0}
+    one.close()
 
 
 @pytest.mark.parametrize("stage", [1, 2, 3, 4, 5, 6, 7, 8, 9])

@@ -60,6 +60,14 @@ def test_serve_equals_per_page_calls_and_isolates_a_poisoned_page(dev, imgs, tmp
             else:
                 _assert_same_schema(want, got.model_dump())
     assert an.serve([]) == []
+    # the default pipeline keeps two recogniser forwards in flight: a second PARSeq handle with the same weights exists
+    # and both produced the results compared above (waves alternate between the lanes)
+    rep = an.text_recognizer._replicas.get(1)
+    assert rep is not None and rep._source_sd is an.text_recognizer.model._sd and rep.weight_bytes == an.text_recognizer.model.weight_bytes
+    out1 = an.serve(sources, wave=3, in_flight=3, rec_lanes=1)
+    for want, got in zip(expect, out1):
+        if want is not None:
+            _assert_same_schema(want, got.model_dump())
     an.close()
 
 
@@ -72,12 +80,12 @@ def test_a_stage_failure_inside_a_wave_costs_only_its_page(dev, imgs):
     inner = rec.forward_plan  # the stage that owns the PARSeq model: one grouped forward for the whole wave
     culprit = imgs[2].shape
 
-    def touchy(plan):
+    def touchy(plan, model=None):
         for _, _, ds, _ in plan["preps"]:
             page0 = ds.page if isinstance(ds.page, torch.Tensor) else ds.page[0]  # a pyramid when some lines use a down-scaled level
             if tuple(page0.shape) == culprit and int(page0[0, 0, 0]) == 7:
                 raise RuntimeError("recogniser choked on this page")
-        return inner(plan)
+        return inner(plan, model)
 
     rec.forward_plan = touchy
     bad = imgs[2].copy()

@@ -17,6 +17,7 @@
 // step) feeds v_mfma_f32_32x32x16_bf16: lane l holds row l & 31, k = 8 (l >> 5) .. + 7 of the step, for A and B alike.
 #include <atomic>
 #include <string>
+#include <type_traits>
 
 #include "ymk_conv_kernel.h"
 
@@ -54,7 +55,8 @@ constexpr int bf16_waves_per_simd() {
 // issues between them); PF: stages the global loads run ahead of the MFMAs (2 = two register sets, as conv_igemm's PF).
 template <int BM, int BN, int WM, int WN, int NS, int KS, int PF>
 __global__ __launch_bounds__(64 * WM * WN, (bf16_waves_per_simd<BM, BN, WM, WN, NS, KS>())) void conv_igemm_bf16(ConvK p, const uint4* __restrict__ wsplit) {
-  static_assert(PF == 1 || PF == 2, "prefetch distance 1 or 2 stages");
+  static_assert(PF >= 1 && PF <= 3, "prefetch: 1 = one stage ahead, 2 = two ahead, 3 = two ahead with the LDS stores threaded through the MFMAs");
+  constexpr int NSET = PF == 1 ? 1 : 2;  // register sets of staged loads
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -121,8 +123,8 @@ __global__ __launch_bounds__(64 * WM * WN, (bf16_waves_per_simd<BM, BN, WM, WN, 
   }
 
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
-  f32x4 ra[PF][KS][APASS];
-  uint4 rb[PF][KS][BPASS];
+  f32x4 ra[NSET][KS][APASS];
+  uint4 rb[NSET][KS][BPASS];
   int cur_kh = 0, cur_kw = 0, cur_cc = 0;
   unsigned voff[APASS];
 #pragma unroll
@@ -225,11 +227,85 @@ __global__ __launch_bounds__(64 * WM * WN, (bf16_waves_per_simd<BM, BN, WM, WN, 
       }
   };
 
+  // PF == 3: the same MFMAs with the next stage's conversion + LDS stores slotted between them, one chunk (one A pass: split
+  // + NS ds_write_b64, or one B piece: ds_write_b128) every `stride` MFMAs, pinned by scheduling fences.  A wave issues in
+  // order and an MFMA occupies the matrix pipe for 32 cycles: the few VALU / DS instructions behind it ride in its shadow
+  // instead of forming a separate phase between the last MFMA and the barrier (the staged data was loaded a whole stage
+  // earlier, so no chunk waits on memory).
+  auto compute_store = [&](int buf, int sbuf, int set, auto do_store) {
+    constexpr bool STORE = decltype(do_store)::value;
+    const char* As = lds + buf * STAGE_B + (wm * WTM + li) * ROWB + lh * 16;
+    const char* Bs = lds + buf * STAGE_B + BM * ROWB + (wn * WTN + li) * ROWB + lh * 16;
+    char* SA = lds + sbuf * STAGE_B;
+    char* SB = SA + BM * ROWB;
+    constexpr int NCH = KS * (APASS + BPASS);
+    constexpr int NM = KS * 2 * NTERM * TM * TN;
+    constexpr int STRIDE = NM / NCH > 0 ? NM / NCH : 1;
+    auto chunk = [&](int c) {
+      const int ks = c / (APASS + BPASS), r = c - ks * (APASS + BPASS);
+      if (r < APASS) {
+        uint2 pl[NS];
+        split4<NS>(ra[set][ks][r], pl);
+        char* row = SA + (rowb + RPP * r) * ROWB + ks * TILEB + colq * 8;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) *reinterpret_cast<uint2*>(row + q * 64) = pl[q];
+      } else {
+        const int j = r - APASS;
+        if (boff[j] >= 0) *reinterpret_cast<uint4*>(SB + boff[j] + ks * TILEB) = rb[set][ks][j];
+      }
+    };
+    int mi = 0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8_t fa[TM][NS], fb[TN][NS];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int q = 0; q < NS; ++q) fa[a][q] = *reinterpret_cast<const bf16x8_t*>(As + a * 32 * ROWB + ks * TILEB + q * 64 + s * 32);
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+          for (int q = 0; q < NS; ++q) fb[b][q] = *reinterpret_cast<const bf16x8_t*>(Bs + b * 32 * ROWB + ks * TILEB + q * 64 + s * 32);
+#pragma unroll
+        for (int tm = 0; tm < NTERM; ++tm)
+#pragma unroll
+          for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][TA[T0 + tm]], fb[b][TB[T0 + tm]], acc[a][b], 0, 0, 0);
+              if (STORE && mi % STRIDE == STRIDE - 1 && mi / STRIDE < NCH) {
+                __builtin_amdgcn_sched_barrier(0);
+                chunk(mi / STRIDE);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+              ++mi;
+            }
+      }
+    if (STORE) {
+#pragma unroll
+      for (int c = NM / STRIDE; c < NCH; ++c) chunk(c);  // more chunks than MFMA slots (short stages): the rest at the end
+    }
+  };
+
   load_stage(0, 0);
   store_stage(0, 0);
-  if (PF == 2 && nstages > 1) load_stage(1, 1);
+  if (PF >= 2 && nstages > 1) load_stage(1, 1);
   __syncthreads();
-  if (PF == 1) {
+  if (PF == 3) {
+    for (int st = 0; st < nstages; st += 2) {
+      if (st + 2 < nstages) load_stage(st + 2, 0);
+      if (st + 1 < nstages) compute_store(0, 1, NSET - 1, std::true_type{});
+      else compute_store(0, 1, NSET - 1, std::false_type{});
+      __syncthreads();
+      if (st + 1 >= nstages) break;
+      if (st + 3 < nstages) load_stage(st + 3, NSET - 1);
+      if (st + 2 < nstages) compute_store(1, 0, 0, std::true_type{});
+      else compute_store(1, 0, 0, std::false_type{});
+      __syncthreads();
+    }
+  } else if (PF == 1) {
     for (int st = 0; st < nstages; ++st) {
       const int buf = st & 1;
       if (st + 1 < nstages) load_stage(st + 1, 0);
@@ -242,10 +318,10 @@ __global__ __launch_bounds__(64 * WM * WN, (bf16_waves_per_simd<BM, BN, WM, WN, 
     for (int st = 0; st < nstages; st += 2) {
       if (st + 2 < nstages) load_stage(st + 2, 0);
       compute(0);
-      if (st + 1 < nstages) store_stage(1, PF - 1);
+      if (st + 1 < nstages) store_stage(1, NSET - 1);
       __syncthreads();
       if (st + 1 >= nstages) break;
-      if (st + 3 < nstages) load_stage(st + 3, PF - 1);
+      if (st + 3 < nstages) load_stage(st + 3, NSET - 1);
       compute(1);
       if (st + 2 < nstages) store_stage(0, 0);
       __syncthreads();
@@ -323,6 +399,7 @@ static void launch_bf16(hipStream_t s, ConvK& k, const void* wsplit) {
 //   7 = 128 x 128, 8 waves, 64-k stages, two ahead    8 = 256 x 128, 16 waves, 32-k stages, two ahead
 //   9 = 128 x 128, 8 waves, 32-k stages, two ahead   10 = 128 x 128, 16 waves, 32-k stages, two ahead
 //   11 = 256 x 256, 16 waves (64 x 64 per wave), two planes
+//   12 / 13 / 14 = 128 x 128 x 16 waves / 256 x 128 x 16 waves / 128 x 128 x 8 waves with the stores threaded through the MFMAs
 static std::atomic<int> g_split_tile{0};
 bool conv_bf16_debug_option(const std::string& key, int value) {
   if (key != "conv_split_tile") return false;
@@ -346,6 +423,9 @@ static void dispatch_bf16(hipStream_t s, ConvK& k, const void* ws, int tile, boo
     case 8: launch_bf16<256, 128, 4, 4, NS, 1, 2>(s, k, ws); break;
     case 9: launch_bf16<128, 128, 4, 2, NS, 1, 2>(s, k, ws); break;
     case 10: launch_bf16<128, 128, 4, 4, NS, 1, 2>(s, k, ws); break;
+    case 12: launch_bf16<128, 128, 4, 4, NS, 1, 3>(s, k, ws); break;
+    case 13: launch_bf16<256, 128, 4, 4, NS, 1, 3>(s, k, ws); break;
+    case 14: launch_bf16<128, 128, 4, 2, NS, 1, 3>(s, k, ws); break;
     case 11:  // 256 x 256, 16 waves of 64 x 64 (two planes only: three do not fit the LDS); Cout < 256 keeps 128-wide tiles
       if (NS == 2 && k.Cout >= 256) launch_bf16<256, 256, 4, 4, 2>(s, k, ws);
       else launch_bf16<128, 128, 4, 4, NS>(s, k, ws);

@@ -461,10 +461,11 @@ class DocumentAnalyzer:
         """Per-page mini-batches (bucketing, width budget) and the crop kernels that build their tensors."""
         wave.rec_plan = self.text_recognizer.plan_pages(wave.pages, [d.points for d in wave.dets])
 
-    def _stage_recognize(self, wave):
-        """One grouped PARSeq forward over the mini-batches of all pages of the wave (owns the recogniser's model; with
-        `rec_orientation_fallback` the decode happens here too, because the retry runs further forwards)."""
-        self.text_recognizer.forward_plan(wave.rec_plan)
+    def _stage_recognize(self, wave, lane=0):
+        """One grouped PARSeq forward over the mini-batches of all pages of the wave, on the recogniser handle of `lane`
+        (serve keeps two forwards in flight: TextRecognizer.replica_model); with `rec_orientation_fallback` the decode
+        happens here too, because the retry runs further forwards."""
+        self.text_recognizer.forward_plan(wave.rec_plan, self.text_recognizer.replica_model(lane))
         if self.text_recognizer.rec_orientation_fallback:
             self._stage_decode(wave)
 
@@ -539,7 +540,7 @@ class DocumentAnalyzer:
             out.extend((self._stage_finish(w, k), None, None) for k in range(len(chunk)))
         return out
 
-    def serve(self, sources, wave: int = 8, in_flight: int = 4, defer_full_gc: bool = True, with_source: bool = False):
+    def serve(self, sources, wave: int = 8, in_flight: int = 4, defer_full_gc: bool = True, with_source: bool = False, rec_lanes: int = 2):
         """The multi-page entry point: host pages (uint8 H x W x 3 BGR arrays) and / or image file paths in, one result
         per page out, in page order - the page loop of cli/main.py:105-137 as a stage pipeline on one GPU from one
         process (yomitoku_amd/serving.py): pinned staging + H2D on a copy stream, `wave` pages per device batch, up to
@@ -547,16 +548,18 @@ class DocumentAnalyzer:
         `__call__(img)[0]` - or, when the page (or its file) failed, the exception object; the other pages are not
         affected (cli/main.py:555-564).  `defer_full_gc`: postpone CPython's generation-2 garbage collections until
         the job is done (a full pass holds the GIL for 100+ ms with a few hundred results alive and stalls every stage).
-        `with_source`: (source index, frame index, entry) triples, for callers that write one output per file page."""
+        `with_source`: (source index, frame index, entry) triples, for callers that write one output per file page.
+        `rec_lanes`: recogniser forwards in flight (2: a second PARSeq handle with the same weights; serving.py)."""
         from .serving import PagePipeline
 
         if self.visualize:
             raise NotImplementedError("visualisation is out of scope of the MI355X path (visualize=False only)")
         pipe = getattr(self, "_pipeline", None)
-        if pipe is None or (pipe.wave, pipe.in_flight) != (max(1, int(wave)), max(1, int(in_flight))):
+        if pipe is None or (pipe.wave, pipe.in_flight, pipe.rec_lanes_asked) != (max(1, int(wave)), max(1, int(in_flight)), int(rec_lanes)):
             if pipe is not None:
                 pipe.close()
-            pipe = self._pipeline = PagePipeline(self, wave=wave, in_flight=in_flight)
+            pipe = self._pipeline = PagePipeline(self, wave=wave, in_flight=in_flight, rec_lanes=rec_lanes)
+            pipe.rec_lanes_asked = int(rec_lanes)
         pipe.defer_full_gc = bool(defer_full_gc)
         return pipe.serve(sources, with_source=with_source)
 

@@ -8,7 +8,7 @@ leaves the device mostly idle, so `DocumentAnalyzer.serve` runs the page loop as
     detect          DBNet forwards over the wave, maps back in one DMA per forward               HIP stream
     boxes           DB box extraction, C++, GIL released                                         host
     crops           per-page mini-batches (bucketing, width budget) + the crop kernels           HIP stream
-    recognize       ONE grouped PARSeq forward with one greedy loop per wave                     HIP stream
+    recognize       ONE grouped PARSeq forward with one greedy loop per wave; TWO lanes (below)   HIP stream x 2
     decode          token decode, un-permutation                                                 host
     layout          RT-DETRv2 layout forward over the wave                                       HIP stream
     tables          layout boxes (host), table-structure forward over all table crops            HIP stream
@@ -18,9 +18,11 @@ leaves the device mostly idle, so `DocumentAnalyzer.serve` runs the page loop as
 The host halves are their own stages on purpose: a thread that owns a network only ever launches - it never sits in box
 logic or string decoding while its stream runs dry (measured: with crop planning / decode inside the recognise stage
 and the table grid logic inside the layout stage the GPU was idle 16 % of a job, in 10-20 ms holes).
-Every network exists ONCE (no replicas): a model handle is only ever used by its own stage thread, which is what
-include/ymk.h asks for; five compute streams plus the copy stream fit the eight hardware queues the package asks the
-HIP runtime for.  Wave k + 1 is in the detector while wave k decodes text and its tables are parsed; up to `in_flight`
+Every network exists once, except the recogniser, which has a second PARSeq handle (a replica of the first's weights,
+~50 MB for the --lite model): the grouped forward is the longest stage and half of it is the greedy loop - ~100 dependent,
+nearly empty launches - so two lanes let wave k + 1's encoder fill the chip while wave k's loop idles through its steps.  A
+model handle is only ever used by one thread, which is what include/ymk.h asks for; six compute streams plus the copy
+stream fit the eight hardware queues the package asks the HIP runtime for.  Wave k + 1 is in the detector while wave k decodes text and its tables are parsed; up to `in_flight`
 waves are between upload and aggregation (a ring of pinned map buffers per wave slot), which bounds host and device
 memory.
 
@@ -109,12 +111,20 @@ def _full_gc_deferred(on: bool):
 
 
 class PagePipeline:
-    def __init__(self, analyzer, wave: int = 8, in_flight: int = 4, defer_full_gc: bool = True, stage_priority=None):
-        """stage_priority: {"detect" | "recognize" | "layout": HIP stream priority (0 default, -1 high)}; also read from
+    def __init__(self, analyzer, wave: int = 8, in_flight: int = 4, defer_full_gc: bool = True, stage_priority=None,
+                 rec_lanes: int = 2):
+        """rec_lanes: recogniser forwards in flight.  The grouped PARSeq forward is two phases with opposite appetites - the
+        ViT encoder (large GEMMs) and the greedy loop (~100 dependent, nearly empty launches) - and it is the longest stage;
+        with two lanes (each its own PARSeq handle and HIP stream, the second a replica of the first's weights) wave k + 1's
+        encoder fills the chip while wave k's loop idles through its steps.  Forced to 1 with `rec_orientation_fallback`
+        (its retry forwards run on the module's own model from the decode path).
+        stage_priority: {"detect" | "recognize" | "layout": HIP stream priority (0 default, -1 high)}; also read from
         YMK_STAGE_PRIORITY="recognize:-1,..." (measurement knob)."""
         self.analyzer = analyzer
         self.defer_full_gc = bool(defer_full_gc)
         self.stage_priority = dict(stage_priority or {})
+        rec = getattr(analyzer, "text_recognizer", None)
+        self.rec_lanes = 1 if getattr(rec, "rec_orientation_fallback", False) else max(1, int(os.environ.get("YMK_REC_LANES", rec_lanes)))
         for item in filter(None, os.environ.get("YMK_STAGE_PRIORITY", "").split(",")):
             name, _, value = item.partition(":")
             self.stage_priority.setdefault(name.strip(), int(value))
@@ -141,13 +151,21 @@ class PagePipeline:
                 ("decode", a._stage_decode, False, ("finish",)),
                 ("layout", a._stage_layout, True, ("tables",)), ("tables", a._stage_tables, True, ("cells",)),
                 ("cells", a._stage_cells, False, ("finish",)), ("finish", self._finish, False, ()))
-        self._threads = [threading.Thread(target=self._loop, args=spec, name=f"ymk-{spec[0]}", daemon=True) for spec in plan]
+        self._workers = {spec[0]: (self.rec_lanes if spec[0] == "recognize" else 1) for spec in plan}
+        self._threads = [threading.Thread(target=self._loop, args=spec + (lane,), name=f"ymk-{spec[0]}-{lane}" if self._workers[spec[0]] > 1 else f"ymk-{spec[0]}",
+                                          daemon=True) for spec in plan for lane in range(self._workers[spec[0]])]
         for t in self._threads:
             t.start()
 
     # ------------------------------------------------------------------ stage threads
-    def _loop(self, name, fn, on_gpu, outs):
+    def _loop(self, name, fn, on_gpu, outs, lane=0):
         stream = None
+        if self._workers[name] > 1:  # a stage with several lanes tells its function which one is calling
+            inner = fn
+
+            def fn(wave):
+                return inner(wave, lane)
+
         if on_gpu and self._gpu:
             torch.cuda.set_device(self.device)
             stream = torch.cuda.Stream(device=self.device, priority=self.stage_priority.get(name, 0))
@@ -318,7 +336,8 @@ class PagePipeline:
             return [job.results[i] for i in range(n)]
 
     def close(self):
-        for q in self._q.values():
-            q.put(_STOP)
+        for name, q in self._q.items():
+            for _ in range(self._workers[name]):
+                q.put(_STOP)
         for t in self._threads:
             t.join(timeout=10)

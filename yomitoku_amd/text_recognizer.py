@@ -9,6 +9,7 @@ the PARSeq forward, and the softmax -> (arg-max, max-prob) reduction the tokeniz
 from __future__ import annotations
 
 import logging
+import threading
 import unicodedata
 from typing import List, Optional
 
@@ -137,6 +138,7 @@ class TextRecognizer(BaseModule):
         # mini-batch of a call already shares one grouped forward, so the value is accepted and has no effect
         self.num_parallel_batches = int(num_parallel_batches)
         self.source_downscale = bool(source_downscale)
+        self._replicas, self._replica_lock = {}, threading.Lock()
         self.model.to(self.device)
 
     # ------------------------------------------------------------------ batching (text_recognizer.py:115-203)
@@ -234,14 +236,15 @@ class TextRecognizer(BaseModule):
                 tensors.append(self._collate(dataset, plans))
         return tensors
 
-    def _forward_jobs(self, tensors, chunks):
+    def _forward_jobs(self, tensors, chunks, model=None):
         """One PARSeq forward per chunk (nets.PARSeq.forward_groups): every mini-batch keeps its own padded width and its
         own early-stop step count, the launches are shared.  Returns per job (ids, probs) as numpy B x S."""
+        model = model or self.model
         out = [None] * len(tensors)
         for start, stop in chunks:
             part = tensors[start:stop]
-            logits, out_lens, _ = self.model.forward_groups(part)
-            ids, probs = self.model.token_stats(logits)
+            logits, out_lens, _ = model.forward_groups(part)
+            ids, probs = model.token_stats(logits)
             ids, probs = ids.cpu().numpy(), probs.cpu().numpy()
             row = 0
             for k, (t, n) in enumerate(zip(part, out_lens)):
@@ -327,11 +330,35 @@ class TextRecognizer(BaseModule):
         return {"preps": preps, "jobs": jobs, "spans": spans, "chunks": self._forward_chunks(jobs), "tensors": self._collate_jobs(jobs),
                 "stats": None}
 
-    def forward_plan(self, plan):
-        """ALL mini-batches of all pages through shared PARSeq forwards; fills plan["stats"]."""
-        plan["stats"] = self._forward_jobs(plan["tensors"], plan["chunks"]) if plan["jobs"] else []
+    def forward_plan(self, plan, model=None):
+        """ALL mini-batches of all pages through shared PARSeq forwards; fills plan["stats"].  `model`: another handle with
+        the same weights (`replica_model`), for callers that keep two forwards in flight."""
+        plan["stats"] = self._forward_jobs(plan["tensors"], plan["chunks"], model) if plan["jobs"] else []
         plan["tensors"] = None
         return plan
+
+    def replica_model(self, lane: int):
+        """Lane 0: the module's own net.  Lane k > 0: a further PARSeq handle holding the same weights (built on first use,
+        rebuilt when the module's weights change; the evaluation switches of the module's net are mirrored), with its own
+        workspace - so that a second forward can be in flight on another thread and HIP stream."""
+        if lane == 0:
+            return self.model
+        with self._replica_lock:
+            rep = self._replicas.get(lane)
+            if rep is None or rep._source_sd is not self.model._sd:
+                if rep is not None:
+                    rep.close()
+                rep = type(self.model)(self.model.cfg).load_state_dict(self.model._sd).to(self.device)
+                rep._source_sd = self.model._sd
+                rep.tokenizer = self.tokenizer
+                rep.reserve(self.MAX_LINES_PER_FORWARD, int(self._cfg.data.img_size[0]), int(self._cfg.data.img_size[1]), self.device)
+                self._replicas[lane] = rep
+            if rep._conv_split != self.model._conv_split:
+                rep.set_conv_split(self.model._conv_split)
+            for k, v in getattr(self.model, "_extra_params", {}).items():
+                if getattr(rep, "_extra_params", {}).get(k) != v:
+                    rep.set_param(k, v)
+            return rep
 
     def finish_plan(self, plan):
         """Token decode, un-permutation, optional 180-degree retry (which runs further forwards: call it from the thread
