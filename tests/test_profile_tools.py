@@ -93,3 +93,27 @@ def test_pmc_aggregate_sums_per_kernel(tmp_path):
     got = {r["kernel"]: (int(r["dispatch_rows"]), float(r["sum"])) for r in csv.DictReader(open(dst))}
     n_conv = sum(1 for r in rows if r[0] == CONV)
     assert got[CONV] == (n_conv, 3.0 * n_conv) and got[OTHER][0] == len(rows) - n_conv
+
+
+def test_gpu_timeline_finds_the_job_and_its_busy_fraction(tmp_path):
+    """tools/gpu_timeline.py on a synthetic kernel trace: set-up dispatches, 0.6 s of silence, a job of two overlapping
+    streams with one 5 ms hole, silence again.  The job is the stretch between the silences; busy = union of intervals."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gpu_timeline
+
+    ms = 1_000_000
+    rows = [(CONV, 0, 2 * ms), (OTHER, 3 * ms, 4 * ms)]  # set-up
+    t0 = 700 * ms
+    for i in range(10):  # stream A: 10 x 8 ms back to back; stream B: 4 ms kernels inside them
+        rows.append((CONV, t0 + i * 8 * ms, t0 + (i + 1) * 8 * ms))
+        rows.append((OTHER, t0 + i * 8 * ms + 2 * ms, t0 + i * 8 * ms + 6 * ms))
+    rows.append((CONV, t0 + 85 * ms, t0 + 95 * ms))  # after a 5 ms hole
+    rows.append((OTHER, t0 + 800 * ms, t0 + 801 * ms))  # teardown, after the closing silence
+    d = str(tmp_path / "kt")
+    _write_csv(d, rows)
+    out = gpu_timeline.analyse(gpu_timeline.kernel_rows(d))
+    assert out["dispatches"] == 21 and abs(out["wall_ms"] - 95.0) < 1e-6
+    assert abs(out["gpu_busy_frac"] - 90.0 / 95.0) < 1e-3
+    assert abs(out["sum_of_kernel_time_over_wall"] - 130.0 / 95.0) < 1e-2
+    assert out["idle_ms_by_gap_size"][">1ms"] == 5.0 and out["largest_gaps"][0]["ms"] == 5.0
+    assert set(out["kernel_time_ms_by_family"]) == {"conv_igemm", "k_layernorm"}

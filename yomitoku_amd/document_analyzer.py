@@ -568,6 +568,7 @@ class DocumentAnalyzer:
         if pipe is not None:
             pipe.close()
             self._pipeline = None
+        self.text_recognizer.close_replicas()
 
     def __call__(self, img):
         self.img = img

@@ -360,6 +360,13 @@ class TextRecognizer(BaseModule):
                     rep.set_param(k, v)
             return rep
 
+    def close_replicas(self):
+        """Release the extra PARSeq handles (weights + reserved workspace) that replica_model built."""
+        with self._replica_lock:
+            for rep in self._replicas.values():
+                rep.close()
+            self._replicas = {}
+
     def finish_plan(self, plan):
         """Token decode, un-permutation, optional 180-degree retry (which runs further forwards: call it from the thread
         that owns the model when `rec_orientation_fallback` is on).  One TextRecognizerSchema per page."""
