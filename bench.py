@@ -720,7 +720,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "pages_per_step_per_gpu": len(seeds) if args.total_pages else args.pages,
                        "parallelism": (f"page-sharded x{world} GPU(s), one process per GPU: DocumentAnalyzer.serve, waves of {args.wave} "
-                                       f"pages, {args.in_flight} waves in flight"
+                                       f"pages, {args.in_flight} waves in flight, 2 recogniser lanes"
                                        if args.workload == "analyzer" else f"page-sharded x{world} GPU(s), one batch of {args.pages} per forward"),
                        "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "checkpoints": "seeded synthetic (no network)", **extra},
