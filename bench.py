@@ -683,8 +683,14 @@ def main():
     # ---- secondary metrics (rank 0, N=1): the recogniser's lines/s and the default model set, in this same process
     secondary = None
     if rank == 0 and world == 1 and args.workload == "analyzer" and not (DRY or args.roofline_only or args.no_secondary):
-        secondary = {"pages_per_s_bf16x2_split_det_layout_table": split_metrics(args, an, host_pages)}
-        secondary.update(secondary_metrics(args, device, sds, pages))
+        # a failing secondary leg must not cost the run its headline line: the error is reported in its place
+        secondary = {}
+        for name, leg in (("pages_per_s_bf16x2_split_det_layout_table", lambda: {"pages_per_s_bf16x2_split_det_layout_table": split_metrics(args, an, host_pages)}),
+                          ("recogniser_and_default_model_set", lambda: secondary_metrics(args, device, sds, pages))):
+            try:
+                secondary.update(leg())
+            except Exception as exc:  # noqa: BLE001
+                secondary[name] = {"error": f"{type(exc).__name__}: {exc}"}
 
     # ---- CPU baseline leg (rank 0, N=1): oracle chain on the host cores, bounded sample
     cpu = None
