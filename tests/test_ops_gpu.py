@@ -55,6 +55,13 @@ CASES = [
 # (ymk_conv.hip try_splitk candidates: 64x64/4, 64x32/4, 64x32/8, 32x32/4, 32x32/8 waves)
 ROUTES = ([("auto", {}), ("igemm", {"no_splitk": 1})] + [(f"splitk{i}", {"splitk_force": i}) for i in range(5)]
           + [(f"variant{v}", {"no_splitk": 1, "conv_variant": v}) for v in range(1, 7)])
+# conv_fast bit 2: accumulators straight to global memory for every plain store; bit 3: swizzled K tiles (three 128 x 64
+# blocks per CU); bit 4: direct epilogue where 16-byte stores are impossible (ragged Cout).  27 is the library's default,
+# 3 the LDS-staged epilogue / padded K tiles of round 2.
+EPILOGUES = [("staged, padded (round 2)", {"conv_fast": 3}), ("direct", {"conv_fast": 7}), ("swizzled", {"conv_fast": 11}),
+             ("direct+swizzled", {"conv_fast": 15})]
+ROUTES += [(f"{name}, variant{v}", dict(opts, no_splitk=1, conv_variant=v)) for name, opts in EPILOGUES for v in (0, 1, 2, 3, 4, 7, 8)]
+RESET = (("splitk_force", -1), ("no_splitk", 0), ("conv_variant", 0), ("conv_fast", 27))
 
 
 @pytest.mark.parametrize("route", ROUTES, ids=[r[0] for r in ROUTES])
@@ -67,7 +74,40 @@ def test_conv2d_matches_torch(dev, case, route):
             _lib.debug_option(key, val)
         _conv_case(dev, case, hipops)
     finally:
-        for key, val in (("splitk_force", -1), ("no_splitk", 0), ("conv_variant", 0)):
+        for key, val in RESET:
+            _lib.debug_option(key, val)
+
+
+@pytest.mark.parametrize("epilogue", EPILOGUES, ids=[e[0] for e in EPILOGUES])
+@pytest.mark.parametrize("case", CASES + [(8, 64, 50, 74, 256, 1, 1, 0, 1), (8, 256, 40, 37, 64, 3, 1, 1, 1), (1, 192, 1, 29000, 200, 1, 1, 0, 1),
+                                         (1, 192, 1, 12000, 7119, 1, 1, 0, 1)])
+def test_conv_epilogue_variants_are_bit_identical(dev, case, epilogue):
+    """The direct epilogue and the swizzled K-tile layout change where values travel, not what is computed: every output
+    bit under the library's default (swizzled 128 x 64 tiles, direct epilogue for ragged Cout) equals the one under each
+    other setting, with and without residual, for every activation (the last cases have enough blocks for the wide tiles)."""
+    from yomitoku_amd import _lib, hipops
+
+    n, cin, h, w, cout, k, stride, pad, dil = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, cin, h, w, generator=g).to(dev)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    scale, bias = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    oh, ow = (h + 2 * pad - dil * (k - 1) - 1) // stride + 1, (w + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    res = torch.randn(n, cout, oh, ow, generator=g).to(dev)
+    configs = [(None, None, None, "none"), (scale, bias, res, "relu"), (scale, None, None, "gelu"), (None, bias, res, "silu"),
+               (scale, bias, None, "sigmoid")]
+    try:
+        for no_splitk in (0, 1):
+            _lib.debug_option("no_splitk", no_splitk)
+            want = [hipops.conv2d(x, wt, sc, bi, rs, stride, pad, dil, act) for sc, bi, rs, act in configs]
+            for key, val in epilogue[1].items():
+                _lib.debug_option(key, val)
+            got = [hipops.conv2d(x, wt, sc, bi, rs, stride, pad, dil, act) for sc, bi, rs, act in configs]
+            _lib.debug_option("conv_fast", _lib.CONV_FAST_DEFAULT)
+            for (sc, bi, rs, act), a, b in zip(configs, want, got):
+                assert torch.equal(a, b), (act, rs is not None, float((a - b).abs().max()))
+    finally:
+        for key, val in RESET:
             _lib.debug_option(key, val)
 
 

@@ -119,6 +119,9 @@ def check(status: int, what: str = "ymk call"):
         raise YmkError(f"{what} failed: {msg.decode('utf-8', 'replace') if msg else status}")
 
 
+CONV_FAST_DEFAULT = 27  # ymk_debug_option("conv_fast"): the library's default bits (include/ymk.h)
+
+
 def debug_option(key: str, value: int):
     """Test / measurement knob of the library (include/ymk.h: ymk_debug_option)."""
     check(load().ymk_debug_option(key.encode(), int(value)), f"ymk_debug_option({key})")

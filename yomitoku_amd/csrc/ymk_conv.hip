@@ -35,9 +35,29 @@ namespace ymk {
 
 // PF: K tiles the global loads run ahead of the MFMAs (1: the tile consumed next; 2: one more - two register sets, so a
 // load has two compute phases to come back from MALL / HBM before its ds_write waits for it)
-template <int BM, int BN, int WM, int WN, int MODE, int PF = 1>
-__global__ __launch_bounds__(64 * WM * WN, (2 * (BM + BN) * LDK * 4 <= 80 * 1024 ? 2 : 1) * WM * WN / 4) void conv_igemm(ConvK p) {
+// OPT bit 0: accumulators go straight to global memory (every wave on its own: no LDS staging, no block barrier in the
+//            epilogue; a half-wave writes 128 contiguous bytes of an output row per store) - EPI_STORE launches only
+// OPT bit 1: K-tile rows of 32 floats with the 16-byte slots XOR-swizzled over row pairs instead of rows padded to 36:
+//            the 128 x 64 tile then takes 48 KB of LDS and THREE blocks share a CU
+constexpr int lds_row(int opt) { return (opt & 2) ? 32 : LDK; }
+constexpr int blocks_per_cu(int bm, int bn, int opt) {
+  const int bytes = 2 * (bm + bn) * lds_row(opt) * 4;
+  return 3 * bytes <= 160 * 1024 ? 3 : 2 * bytes <= 160 * 1024 ? 2 : 1;
+}
+// float offset of 16-byte slot `slot` (0..7) of K-tile row `row`.  Swizzled form: a pair of rows is one 256-byte line
+// (all 64 banks), slot index (row parity, slot) XOR (pair index mod 8): the 16 rows a ds_read_b128 phase touches at one
+// slot land in 16 distinct slots of the line, and so do the 2 rows x 8 slots of a ds_write_b128 phase
+template <int OPT>
+__device__ __forceinline__ int lds_slot(int row, int slot) {
+  if (OPT & 2) return (row >> 1) * 64 + ((((row & 1) << 3) | slot) ^ ((row >> 1) & 7)) * 4;
+  return row * LDK + slot * 4;
+}
+
+template <int BM, int BN, int WM, int WN, int MODE, int PF = 1, int OPT = 0>
+__global__ __launch_bounds__(64 * WM * WN, ((OPT & 2) ? blocks_per_cu(BM, BN, OPT) : 2 * (BM + BN) * LDK * 4 <= 80 * 1024 ? 2 : 1) * WM * WN / 4) void conv_igemm(ConvK p) {
   static_assert(PF == 1 || PF == 2, "prefetch distance 1 or 2");
+  constexpr int LDR = lds_row(OPT);
+  static_assert(!(OPT & 2) || (64 * WM * WN / 8) % 16 == 0, "swizzle: staging passes must keep (row >> 1) & 7");
   constexpr int NT = 64 * WM * WN;             // 4, 8 or 16 waves
   static_assert(NT == 256 || NT == 512 || NT == 1024, "4, 8 or 16 waves per block");
   constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
@@ -45,7 +65,7 @@ __global__ __launch_bounds__(64 * WM * WN, (2 * (BM + BN) * LDK * 4 <= 80 * 1024
   constexpr int RPP = NT / 8;                  // rows staged per pass (8 threads x 16 B per 32-float row)
   constexpr int APASS = BM / RPP, BPASS = BN / RPP;
   static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must divide by the staging pass");
-  constexpr int STAGE = (BM + BN) * LDK;
+  constexpr int STAGE = (BM + BN) * LDR;
   constexpr int LDC = BN + 4;  // epilogue staging row (floats)
   constexpr int EROWS = (2 * STAGE / LDC) / 32 * 32 < BM ? (2 * STAGE / LDC) / 32 * 32 : BM;  // rows per epilogue pass
   static_assert(EROWS >= WTM && EROWS % WTM == 0, "an epilogue pass must hold whole wave tiles");
@@ -150,15 +170,16 @@ __global__ __launch_bounds__(64 * WM * WN, (2 * (BM + BN) * LDK * 4 <= 80 * 1024
       rb[set][j] = *reinterpret_cast<const f32x4*>(wrow + (size_t)(RPP * j) * p.Kpad + kt * 32);
   };
 
+  const int st_off = lds_slot<OPT>(rowb, colq);  // RPP is a multiple of 16 rows: the passes only add whole lines
   auto store_tile = [&](int buf, int set) {
-    float* As = lds + buf * STAGE;
-    float* Bs = As + BM * LDK;
+    float* As = lds + buf * STAGE + st_off;
+    float* Bs = As + BM * LDR;
 #pragma unroll
     for (int i = 0; i < APASS; ++i)
-      *reinterpret_cast<f32x4*>(As + (rowb + RPP * i) * LDK + colq * 4) = ra[set][i];
+      *reinterpret_cast<f32x4*>(As + RPP * i * LDR) = ra[set][i];
 #pragma unroll
     for (int j = 0; j < BPASS; ++j)
-      *reinterpret_cast<f32x4*>(Bs + (rowb + RPP * j) * LDK + colq * 4) = rb[set][j];
+      *reinterpret_cast<f32x4*>(Bs + RPP * j * LDR) = rb[set][j];
   };
 
   // ---- MFMA coordinates
@@ -176,18 +197,23 @@ __global__ __launch_bounds__(64 * WM * WN, (2 * (BM + BN) * LDK * 4 <= 80 * 1024
 
   const int ktiles = p.Kpad >> 5;
 
+  int a_off[4], b_off[4];  // chunk kc of this lane's rows (tile rows step by 32: whole lines, the swizzle term stays)
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc) {
+    a_off[kc] = lds_slot<OPT>(wm * WTM + li, 2 * kc + lh);
+    b_off[kc] = BM * LDR + lds_slot<OPT>(wn * WTN + li, 2 * kc + lh);
+  }
   auto compute = [&](int buf) {
-    const float* As = lds + buf * STAGE + (wm * WTM + li) * LDK + lh * 4;
-    const float* Bs = lds + buf * STAGE + BM * LDK + (wn * WTN + li) * LDK + lh * 4;
+    const float* Ts = lds + buf * STAGE;
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) {
       f32x4 fa[TM], fb[TN];
 #pragma unroll
       for (int a = 0; a < TM; ++a)
-        fa[a] = *reinterpret_cast<const f32x4*>(As + a * 32 * LDK + kc * 8);
+        fa[a] = *reinterpret_cast<const f32x4*>(Ts + a_off[kc] + a * 32 * LDR);
 #pragma unroll
       for (int b = 0; b < TN; ++b)
-        fb[b] = *reinterpret_cast<const f32x4*>(Bs + b * 32 * LDK + kc * 8);
+        fb[b] = *reinterpret_cast<const f32x4*>(Ts + b_off[kc] + b * 32 * LDR);
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -216,7 +242,7 @@ __global__ __launch_bounds__(64 * WM * WN, (2 * (BM + BN) * LDK * 4 <= 80 * 1024
       if (CAN_PRE && kt + 1 == ktiles && pre_res) prefetch_residual<EROWS, BN, NT>(p, m0, n0, t, rpre);
       compute(buf);
       if (kt + 1 < ktiles) store_tile(buf ^ 1, 0);
-      __syncthreads();
+      if (!(OPT & 1) || kt + 1 < ktiles) __syncthreads();  // the direct epilogue does not reuse the LDS
     }
   } else {
     // tile t travels in register set t & 1: loaded at the top of step t - 2, written to LDS[t & 1] at the end of step t - 1
@@ -233,6 +259,10 @@ __global__ __launch_bounds__(64 * WM * WN, (2 * (BM + BN) * LDK * 4 <= 80 * 1024
     }
   }
 
+  if (OPT & 1) {
+    epilogue_direct<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, li, lh);
+    return;
+  }
   // ---- epilogue: accumulators -> LDS tile [EROWS][LDC] -> 16 B per lane, full rows coalesced; a tile taller than the
   // staging LDS goes in BM / EROWS passes (the waves owning the rows of a pass write, every thread stores).
   // D[row][col]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -440,7 +470,7 @@ constexpr int SPLITK_MAX_GRID = 384;
 // test / measurement knobs (ymk_debug_option): process-wide, read per launch, never set on the product path
 static std::atomic<int> g_splitk_force{-1};  // >= 0: that split-K candidate for every eligible launch (kernel tests)
 static std::atomic<int> g_no_splitk{0};      // 1: every launch through conv_igemm (A/B profiling, kernel tests)
-static std::atomic<int> g_conv_fast{3};      // ConvK::fast
+static std::atomic<int> g_conv_fast{27};     // ConvK::fast
 static std::atomic<int> g_conv_variant{0};   // conv_igemm schedule selector for A/B runs, see launch_wide()
 static std::atomic<int> g_prof_dump{0};      // 1: ymk_prof_end prints one line per launch to stderr
 static std::atomic<int> g_conv_split{0};     // 0: exact fp32 MFMA (the product path); 2 / 3: bf16-split operands, 3 / 6 MFMAs (ymk_conv_bf16.hip)
@@ -568,10 +598,25 @@ static void launch(hipStream_t s, ConvK& k) {
   k.ntiles_n = nt;
   if (MODE == 0 && (mt * nt < SPLITK_MAX_GRID || splitk_forced() >= 0) && !no_splitk() && try_splitk(s, k)) return;
   auto* e = conv_prof_open(s, k, BM, BN, mt * nt, 1);
-  hipLaunchKernelGGL((conv_igemm<BM, BN, WM, WN, MODE, PF>), dim3(mt * nt), dim3(64 * WM * WN), 0, s, k);
+  // ConvK::fast bits 2 / 4: direct epilogue (plain stores only; everywhere / ragged Cout); bit 3: swizzled K tiles
+  constexpr bool HAS_OPT = MODE == 0 && PF == 1;
+  constexpr bool HAS_SWZ = HAS_OPT && BM == 128 && BN == 64 && WM * WN == 8;
+  const bool direct = HAS_OPT && k.epi == EPI_STORE && ((k.fast & 4) || ((k.fast & 16) && !k.vec));
+  const bool swz = HAS_SWZ && (k.fast & 8);
+  const dim3 grid(mt * nt), block(64 * WM * WN);
+  if constexpr (HAS_SWZ) {
+    if (swz && direct) hipLaunchKernelGGL((conv_igemm<BM, BN, WM, WN, MODE, PF, 3>), grid, block, 0, s, k);
+    else if (swz) hipLaunchKernelGGL((conv_igemm<BM, BN, WM, WN, MODE, PF, 2>), grid, block, 0, s, k);
+  }
+  if constexpr (HAS_OPT) {
+    if (direct && !swz) hipLaunchKernelGGL((conv_igemm<BM, BN, WM, WN, MODE, PF, 1>), grid, block, 0, s, k);
+  }
+  if (!direct && !swz) hipLaunchKernelGGL((conv_igemm<BM, BN, WM, WN, MODE, PF>), grid, block, 0, s, k);
   if (e) YMK_HIP(hipEventRecord(e->second, s));
 }
 
+// Round 3: the 128 x 64 tile with swizzled K-tile rows (48 KB of LDS: three blocks per CU, six waves per SIMD) replaced the
+// 16-wave wide tile for Kpad <= 512 (conv2d below); accumulators of ragged-Cout launches go straight to global memory.
 // Schedules.  Measured on MI355X (tools/conv_sweep.py, random operands; profiles/r02_conv_sweep*.txt): the 128 x 128
 // tile with EIGHT waves (32 x 64 wave tiles, 4 waves per SIMD at 2 blocks per CU) beats the four-wave form of round 1
 // everywhere - +3..8 % on the K >= 512 layers of DBNet, +10 % on the K = 192 GEMMs of PARSeq, +30 % on the memory-bound
@@ -579,7 +624,7 @@ static void launch(hipStream_t s, ConvK& k) {
 // epilogue) and lose a little on the long-K layers; the 128 x 64 tile likewise gains from eight waves.  Interleaving the
 // MFMA order across accumulators, s_setprio around the MFMA cluster and a 256 x 128 tile changed nothing or lost.
 // conv_variant (ymk_debug_option) keeps the alternatives reachable for A/B runs:
-//   wide path (Cout > 64):  0 = by K (default)   1 = 4 waves (round 1)   2 = 16 waves   4 = 8 waves   5 = 8 waves, loads 2 K tiles ahead
+//   wide path (Cout > 64):  0 = by K (default)   1 = 4 waves (round 1)   2 = 16 waves   4 = 8 waves   5 = 8 waves, loads 2 K tiles ahead   8 = 128 x 64 tiles
 //   narrow path (128 x 64): 0 = 8 waves (default)   3 = 4 waves (round 1)   6 = 8 waves, loads 2 K tiles ahead
 static void launch_wide(hipStream_t s, ConvK& k) {
   switch (g_conv_variant.load(std::memory_order_relaxed)) {
@@ -587,6 +632,7 @@ static void launch_wide(hipStream_t s, ConvK& k) {
     case 2: launch<128, 128, 4, 4>(s, k); break;
     case 4: launch<128, 128, 4, 2>(s, k); break;
     case 5: launch<128, 128, 4, 2, 0, 2>(s, k); break;
+    case 8: launch<128, 64, 4, 2>(s, k); break;  // A/B runs: 64-wide tiles whatever Cout
     default:
       if (k.Kpad <= 512) launch<128, 128, 4, 4>(s, k);
       else launch<128, 128, 4, 2>(s, k);
@@ -602,7 +648,7 @@ static void launch_n64(hipStream_t s, ConvK& k) {
 }
 
 void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, const Tensor& out) {
-  ConvK k;
+  ConvK k{};
   k.in = in.p;
   k.w = w.w;
   k.scale = w.scale;
@@ -698,7 +744,11 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
     // a 128-wide N tile wastes (-Cout mod 128) columns of MFMA work: 25 % at Cout = 192 (the PARSeq-tiny projections
     // and FFN outputs).  64-wide tiles cover such a Cout exactly, at a slightly lower rate per tile.
     const int waste = (128 - w.cout % 128) % 128;
-    if (waste >= 48 && waste * 5 >= w.cout) launch_n64(s, k);
+    // short K (the 1x1 expansions, the ViT projections): the swizzled 128 x 64 tile runs three blocks per CU and beat the
+    // 16-wave 128 x 128 tile on every such shape - qkv 192->576 +13 %, 256->1024 +10 %, 128->512 +9 %, 64->256 +8 %,
+    // 512->2048 +5 %, level elsewhere (profiles/r03_conv_sweep_swizzled_tiles.txt); long K stays on the wide tile
+    const bool short_k = (k.fast & 8) && k.Kpad <= 512 && g_conv_variant.load(std::memory_order_relaxed) == 0;
+    if ((waste >= 48 && waste * 5 >= w.cout) || short_k) launch_n64(s, k);
     else launch_wide(s, k);
   } else {
     const long blocks64 = (long)((k.M + 127) / 128) * ((w.cout + 63) / 64);

@@ -27,7 +27,10 @@ struct ConvK {
   int vec;      // 1: Cout, leading dims and pointers allow 16 B epilogue accesses
   const int* row_group;   // optional (ConvArgs): row m -> group id ...
   const int* group_open;  // ... and the per-group "still needed" word; M tiles without a needed row return at once
-  int fast;     // bit 0: pointwise index shortcut, bit 1: residual prefetch (both on; ymk_debug_option("conv_fast") for A/B runs)
+  int fast;     // ymk_debug_option("conv_fast"), default 27: bit 0 pointwise index shortcut, bit 1 residual prefetch,
+                // bit 2 direct epilogue for every plain store (A/B runs; slower than the staged one where 16-byte stores
+                // are possible), bit 3 swizzled K tiles / three 128 x 64 blocks per CU, bit 4 direct epilogue for the
+                // launches that cannot store 16 bytes per lane (ragged Cout: the 7119-wide vocabulary head)
 };
 
 // true when some row of the block's M tile [m0, m0 + BM) is still needed (or no row predicate was given); block-uniform
@@ -195,6 +198,53 @@ __device__ __forceinline__ void epilogue_tile(const ConvK& p, const float* Cs, i
   }
 }
 
+// ---- epilogue straight from the accumulators (EPI_STORE): lane (li, lh) of a wave holds, for MFMA tile (a, b), register
+// r = D[row 32a + (r & 3) + 8 (r >> 2) + 4 lh][column 32b + li]; a store instruction therefore writes two output rows,
+// 128 contiguous bytes each.  Same arithmetic per element as epilogue_tile.  One instantiation per activation (the
+// activation switch sits outside the unrolled element loops: the erff expansion appears once per element, not five
+// functions per element).
+template <int ACT, int TM, int TN>
+__device__ __forceinline__ void epilogue_direct_act(const ConvK& p, const f32x16 (&acc)[TM][TN], int mw, int nw, int li, int lh) {
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int co = nw + 32 * b + li;
+    const bool cok = co < p.Cout;
+    const float sc = (p.scale && cok) ? p.scale[co] : 1.f;
+    const float bi = (p.bias && cok) ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const int mb = mw + 32 * a + 4 * lh;
+      const float* rp = p.res ? p.res + (size_t)mb * p.res_ld + co : nullptr;
+      float* op = p.out + (size_t)mb * p.out_ld + co;
+      float rr[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {  // the residual reads of a tile are issued together
+        const int dr = (r & 3) + 8 * (r >> 2);
+        rr[r] = (rp && cok && mb + dr < p.M) ? rp[(size_t)dr * p.res_ld] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        float v = acc[a][b][r] * sc + bi;
+        if (rp && !p.res_post) v += rr[r];
+        v = apply_act(v, ACT);
+        if (p.res_post) v += rr[r];
+        if (cok && mb + dr < p.M) op[(size_t)dr * p.out_ld] = v;
+      }
+    }
+  }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_direct(const ConvK& p, const f32x16 (&acc)[TM][TN], int mw, int nw, int li, int lh) {
+  switch (p.act) {  // block-uniform
+    case ACT_RELU: epilogue_direct_act<ACT_RELU, TM, TN>(p, acc, mw, nw, li, lh); break;
+    case ACT_SILU: epilogue_direct_act<ACT_SILU, TM, TN>(p, acc, mw, nw, li, lh); break;
+    case ACT_SIGMOID: epilogue_direct_act<ACT_SIGMOID, TM, TN>(p, acc, mw, nw, li, lh); break;
+    case ACT_GELU: epilogue_direct_act<ACT_GELU, TM, TN>(p, acc, mw, nw, li, lh); break;
+    default: epilogue_direct_act<ACT_NONE, TM, TN>(p, acc, mw, nw, li, lh); break;
+  }
+}
 
 // per-launch timing hooks (bench.py roofline leg), defined in ymk_conv.hip
 std::pair<hipEvent_t, hipEvent_t>* conv_prof_open(hipStream_t s, const ConvK& k, int BM, int BN, int grid, int ksplit);
