@@ -151,7 +151,8 @@ int ymk_prof_begin(void);
  *   "conv_fast" (27)     bit 0: index shortcut of 1x1 / stride-1 layers, bit 1: residual rows fetched ahead, bit 3: K-tile rows of the
  *                        128 x 64 tile XOR-swizzled instead of padded (48 KB of LDS: three blocks per CU) and that tile for every
  *                        launch with K <= 512, bit 4: accumulators of ragged-Cout launches stored straight from registers;
- *                        bit 2: that direct epilogue for every plain store (A/B runs).  3 = the round-2 kernels.  Every setting
+ *                        bit 2: that direct epilogue for every plain store (A/B runs); bit 5: persistent tile loop for the swizzled
+ *                        tile (ymk_conv_persist.hip: compiles, NOT yet run on hardware - off).  3 = the round-2 kernels.  Every setting
  *                        computes the same bits (tests/test_ops_gpu.py::test_conv_epilogue_variants_are_bit_identical).
  *   "dec_rows" (0)       samples per block of the fused greedy step: 0 = by row count, 1 / 2 / 4 forced (bit-identical results)
  *   "parseq_no_rowmax" (0)  1: the fused greedy loop writes every step's logits and arg-maxes them from memory (round-2 form);

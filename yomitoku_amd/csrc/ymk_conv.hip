@@ -39,20 +39,6 @@ namespace ymk {
 //            epilogue; a half-wave writes 128 contiguous bytes of an output row per store) - EPI_STORE launches only
 // OPT bit 1: K-tile rows of 32 floats with the 16-byte slots XOR-swizzled over row pairs instead of rows padded to 36:
 //            the 128 x 64 tile then takes 48 KB of LDS and THREE blocks share a CU
-constexpr int lds_row(int opt) { return (opt & 2) ? 32 : LDK; }
-constexpr int blocks_per_cu(int bm, int bn, int opt) {
-  const int bytes = 2 * (bm + bn) * lds_row(opt) * 4;
-  return 3 * bytes <= 160 * 1024 ? 3 : 2 * bytes <= 160 * 1024 ? 2 : 1;
-}
-// float offset of 16-byte slot `slot` (0..7) of K-tile row `row`.  Swizzled form: a pair of rows is one 256-byte line
-// (all 64 banks), slot index (row parity, slot) XOR (pair index mod 8): the 16 rows a ds_read_b128 phase touches at one
-// slot land in 16 distinct slots of the line, and so do the 2 rows x 8 slots of a ds_write_b128 phase
-template <int OPT>
-__device__ __forceinline__ int lds_slot(int row, int slot) {
-  if (OPT & 2) return (row >> 1) * 64 + ((((row & 1) << 3) | slot) ^ ((row >> 1) & 7)) * 4;
-  return row * LDK + slot * 4;
-}
-
 template <int BM, int BN, int WM, int WN, int MODE, int PF = 1, int OPT = 0>
 __global__ __launch_bounds__(64 * WM * WN, ((OPT & 2) ? blocks_per_cu(BM, BN, OPT) : 2 * (BM + BN) * LDK * 4 <= 80 * 1024 ? 2 : 1) * WM * WN / 4) void conv_igemm(ConvK p) {
   static_assert(PF == 1 || PF == 2, "prefetch distance 1 or 2");
@@ -597,12 +583,14 @@ static void launch(hipStream_t s, ConvK& k) {
   const int mt = (k.M + BM - 1) / BM, nt = (k.Cout + BN - 1) / BN;
   k.ntiles_n = nt;
   if (MODE == 0 && (mt * nt < SPLITK_MAX_GRID || splitk_forced() >= 0) && !no_splitk() && try_splitk(s, k)) return;
-  auto* e = conv_prof_open(s, k, BM, BN, mt * nt, 1);
-  // ConvK::fast bits 2 / 4: direct epilogue (plain stores only; everywhere / ragged Cout); bit 3: swizzled K tiles
+  // ConvK::fast bits 2 / 4: direct epilogue (plain stores only; everywhere / ragged Cout); bit 3: swizzled K tiles;
+  // bit 5 (opt-in, not yet measured): persistent tile loop for the swizzled tile (ymk_conv_persist.hip)
   constexpr bool HAS_OPT = MODE == 0 && PF == 1;
   constexpr bool HAS_SWZ = HAS_OPT && BM == 128 && BN == 64 && WM * WN == 8;
   const bool direct = HAS_OPT && k.epi == EPI_STORE && ((k.fast & 4) || ((k.fast & 16) && !k.vec));
   const bool swz = HAS_SWZ && (k.fast & 8);
+  if (swz && !direct && (k.fast & 32) && conv2d_persistent(s, k)) return;
+  auto* e = conv_prof_open(s, k, BM, BN, mt * nt, 1);
   const dim3 grid(mt * nt), block(64 * WM * WN);
   if constexpr (HAS_SWZ) {
     if (swz && direct) hipLaunchKernelGGL((conv_igemm<BM, BN, WM, WN, MODE, PF, 3>), grid, block, 0, s, k);

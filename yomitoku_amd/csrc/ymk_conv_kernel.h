@@ -30,7 +30,9 @@ struct ConvK {
   int fast;     // ymk_debug_option("conv_fast"), default 27: bit 0 pointwise index shortcut, bit 1 residual prefetch,
                 // bit 2 direct epilogue for every plain store (A/B runs; slower than the staged one where 16-byte stores
                 // are possible), bit 3 swizzled K tiles / three 128 x 64 blocks per CU, bit 4 direct epilogue for the
-                // launches that cannot store 16 bytes per lane (ragged Cout: the 7119-wide vocabulary head)
+                // launches that cannot store 16 bytes per lane (ragged Cout: the 7119-wide vocabulary head); bit 5 (off):
+                // persistent tile loop for the swizzled tile (ymk_conv_persist.hip, not yet run on hardware)
+  int ntiles;   // conv_igemm_persist only: M tiles x N tiles of the launch (last member: the other kernels' argument offsets stay)
 };
 
 // true when some row of the block's M tile [m0, m0 + BM) is still needed (or no row predicate was given); block-uniform
@@ -56,6 +58,21 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 constexpr int LDK = 36;  // padded K-tile row (floats)
+
+// ---- K-tile layout in LDS (conv_igemm OPT bit 1, conv_igemm_persist)
+constexpr int lds_row(int opt) { return (opt & 2) ? 32 : LDK; }
+constexpr int blocks_per_cu(int bm, int bn, int opt) {
+  const int bytes = 2 * (bm + bn) * lds_row(opt) * 4;
+  return 3 * bytes <= 160 * 1024 ? 3 : 2 * bytes <= 160 * 1024 ? 2 : 1;
+}
+// float offset of 16-byte slot `slot` (0..7) of K-tile row `row`.  Swizzled form: a pair of rows is one 256-byte line
+// (all 64 banks), slot index (row parity, slot) XOR (pair index mod 8): the 16 rows a ds_read_b128 phase touches at one
+// slot land in 16 distinct slots of the line, and so do the 2 rows x 8 slots of a ds_write_b128 phase
+template <int OPT>
+__device__ __forceinline__ int lds_slot(int row, int slot) {
+  if (OPT & 2) return (row >> 1) * 64 + ((((row & 1) << 3) | slot) ^ ((row >> 1) & 7)) * 4;
+  return row * LDK + slot * 4;
+}
 
 // A-operand gathers go through a raw buffer descriptor: padding taps and tail rows use an offset
 // beyond num_records, for which the hardware returns zeros - no branch, no select after the load,
@@ -88,7 +105,7 @@ __device__ __forceinline__ void prefetch_residual(const ConvK& p, int m0, int n0
   }
 }
 
-template <int BM, int BN, int NT, bool PRE = false>
+template <int BM, int BN, int NT, bool PRE = false, int UNROLL = 4>
 __device__ __forceinline__ void epilogue_tile(const ConvK& p, const float* Cs, int m0, int n0, int t, const float4* pre = nullptr) {
   constexpr int LDC = BN + 4;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -145,7 +162,7 @@ __device__ __forceinline__ void epilogue_tile(const ConvK& p, const float* Cs, i
       ab = co / cq_n;
       cq = co - ab * cq_n;
     }
-#pragma unroll(PRE ? EpiRows<BM, BN, NT>::NR : 4)
+#pragma unroll(PRE ? EpiRows<BM, BN, NT>::NR : UNROLL)
     for (int i = 0; i < EpiRows<BM, BN, NT>::NR; ++i) {
       const int row = r0 + RPP * i;
       const int m = m0 + row;
@@ -252,5 +269,8 @@ std::pair<hipEvent_t, hipEvent_t>* conv_prof_open(hipStream_t s, const ConvK& k,
 // bf16-split path (ymk_conv_bf16.hip): true when the launch was taken (ns = 2: hi/lo, 3 MFMAs per product tile;
 // ns = 3: hi/mid/lo, 6 MFMAs)
 bool conv2d_bf16_split(hipStream_t s, ConvK& k, const ConvW& w, int ns);
+
+// persistent tile loop over the swizzled 128 x 64 tile (ymk_conv_persist.hip; opt-in, conv_fast bit 5): true when taken
+bool conv2d_persistent(hipStream_t s, ConvK& k);
 
 }  // namespace ymk
