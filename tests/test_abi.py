@@ -33,3 +33,18 @@ def test_version_and_error_slot():
     h = lib.ymk_model_create(b"no-such-model", 0)
     assert not h
     assert lib.ymk_last_error()
+
+
+def test_debug_options_exist_and_their_documented_defaults_agree():
+    """ymk_debug_option keys the tools and tests use are known to the library (no GPU needed: they only set process-wide
+    switches), an unknown key is refused, and the default of "conv_fast" is the same number in the kernel source, the
+    header comment and the Python constant the tests reset it to."""
+    lib = _lib.load()
+    assert lib.ymk_debug_option(b"no_such_option", 1) != 0
+    for key, default in (("conv_fast", _lib.CONV_FAST_DEFAULT), ("conv_variant", 0), ("no_splitk", 0), ("splitk_force", -1),
+                         ("conv_split", 0), ("conv_split_tile", 0), ("prof_dump", 0), ("dec_rows", 0), ("parseq_no_rowmax", 0)):
+        assert lib.ymk_debug_option(key.encode(), default) == 0, key
+    src = open(os.path.join(ROOT, "yomitoku_amd", "csrc", "ymk_conv.hip")).read()
+    assert int(re.search(r"g_conv_fast\{(\d+)\}", src).group(1)) == _lib.CONV_FAST_DEFAULT
+    header = open(os.path.join(ROOT, "include", "ymk.h")).read()
+    assert int(re.search(r'"conv_fast" \((\d+)\)', header).group(1)) == _lib.CONV_FAST_DEFAULT
