@@ -1,4 +1,6 @@
 # direct epilogue / swizzled K tiles / staggered start: kernel sweep, bit-identity tests, model-level A/B of the serial conv pass
+# (record of the job behind profiles/r03_conv_sweep_epilogue_direct_swizzle.txt and _staggered_start.txt: the conv_stagger_* options it
+# sweeps were removed from the library after it showed no effect, and `conv_fast` 3 was the default at the time)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=gpurun_out/r03e; rm -rf $O; mkdir -p $O
 VARIANTS="0,0/7,0/11,0/15,2/7,4/7,8/7,8/15" REPS=5 timeout 150 python tools/conv_sweep.py > $O/sweep_epilogue.txt 2> $O/err1.log || tail -5 $O/err1.log
