@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import torch
 
-from . import _lib
+from yomitoku_amd import _lib
 
 ACT = {"none": 0, "relu": 1, "silu": 2, "sigmoid": 3, "gelu": 4}
 

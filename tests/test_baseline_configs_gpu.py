@@ -1,5 +1,10 @@
 """Parity at the configurations BASELINE.json names ("Parity at the configs BASELINE names"):
 
+  configs[0]  OCR with the --lite configs (cli/main.py:505-520; demo/simple_ocr.py) on the reference's OWN sample images -
+              demo/sample_text.jpg (91 x 38: the INTER_AREA UP-scale branch of the detector pre-processing, a one-line
+              page) and tests/data/test.jpg (596 x 842) - kept as tests/golden/{sample_text,test_page}.jpg: product vs the
+              oracle chain, detector input and probability map within tolerance, every discrete stage on the same upstream
+              tensor, words (points, strings, directions) equal;
   configs[1]  DBNet, batch 8 of 1600 x 1200 pages (3 x 1600 x 1184 each): one page against the oracle, every page against
               its own batch-1 map (to 1e-5: at batch 1 the grid-starved 1/32-scale layers take the split-K kernel, whose
               partial sums are added in another order than conv_igemm's k-ordered chain);
@@ -237,3 +242,110 @@ def test_whole_page_schema_vs_oracle_chain(dev, page_hw):
     if page_hw == (1000, 1400):  # the layout net finds table boxes on this page and at least one keeps rows AND columns
         assert len(lay.tables) >= 1 and len(got.tables) >= 1 and sum(len(t.cells) for t in got.tables) >= 1
     print("whole page: words", len(got.words), "paragraphs", len(got.paragraphs), "tables", len(got.tables), "figures", len(got.figures))
+
+
+def _sample(name):
+    """(BGR page through the product's loader, the same file decoded independently) of tests/golden/<name>."""
+    import os
+
+    from PIL import Image
+
+    from yomitoku_amd.data.functions import load_image
+
+    path = os.path.join(os.path.dirname(__file__), "golden", name)
+    (img,) = load_image(path)
+    ref_img = np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+    assert np.array_equal(img, ref_img)
+    return img, ref_img
+
+
+LITE_OCR = {"text_detector": {"from_pretrained": False},
+            "text_recognizer": {"model_name": "parseq-tiny-dynw-v4", "from_pretrained": False, "dynamic_width": True,
+                                "batch_bucketing": True, "source_downscale": True}}
+
+
+def test_ocr_lite_on_the_reference_test_page(dev):
+    """BASELINE.json configs[0] on tests/data/test.jpg (596 x 842): OCR(--lite configs) against the oracle chain.  The
+    reference decodes with Pillow and hands BGR to OCR (data/functions.py:57-77); the oracle side decodes the file on its
+    own, the product side goes through yomitoku_amd.data.load_image."""
+    from oracle import pipeline as op
+    from oracle.dbnet import dbnet_forward
+    from oracle.parseq import PRESETS, make_cfg
+    from oracle.preprocess import detector_preprocess
+    from tests.test_pipeline_gpu import _assert_same_schema
+    from yomitoku_amd import OCR
+    from yomitoku_amd.document_analyzer import ocr_aggregate
+    from yomitoku_amd.schemas import OCRSchema, TextDetectorSchema, TextRecognizerSchema
+    from yomitoku_amd.utils.synth import dbnet_state_dict, parseq_state_dict
+
+    img, ref_img = _sample("test_page.jpg")
+    ocr = OCR(configs=LITE_OCR, device="cuda:0")
+    # seed 8 / bias -1.5: the seeded detector finds ~90 boxes on this page, every one a valid crop (most seeds find none)
+    sds = {"det": dbnet_state_dict(8, out_bias=-1.5), "rec": parseq_state_dict(1235, eos_bias=6.0)}
+    ocr.detector.model.load_state_dict(sds["det"])
+    ocr.recognizer.model.load_state_dict(sds["rec"])
+    got, _ = ocr(img)
+
+    det = ocr.detector
+    t = det.preprocess(img)
+    ref_t = detector_preprocess(ref_img)
+    assert tuple(t.shape) == tuple(ref_t.shape) == (1, 3, 1600, 1120)
+    assert (t.cpu() - ref_t).abs().max().item() < 2e-5
+    prob = det.model(t)["binary"].cpu()
+    assert (prob - dbnet_forward(sds["det"], ref_t)["binary"]).abs().max().item() < 1e-3
+    _, quads, det_scores = op.detect(sds["det"], ref_img, prob=prob)
+    assert len(quads) >= 40, len(quads)
+    ocfg = make_cfg(**PRESETS["parseq-tiny-dynw-v4"])
+    contents, rec_scores, directions = op.recognize(sds["rec"], ocfg, ref_img, quads, ocr.recognizer.charset, dynamic_width=True,
+                                                    batch_bucketing=True, width_budget=8000, max_batch_size=64, batch_size=10,
+                                                    source_downscale=True)
+    want = OCRSchema(words=ocr_aggregate(TextDetectorSchema(points=quads, scores=det_scores),
+                                         TextRecognizerSchema(contents=contents, scores=rec_scores, points=quads, directions=directions)))
+    _assert_same_schema(want.model_dump(), got.model_dump(), score_rtol=1e-3)
+    assert sum(len(w.content) for w in got.words) > 0
+    print("test_page.jpg: words", len(got.words), [w.content for w in got.words[:3]])
+
+
+def test_ocr_lite_on_the_reference_sample_text(dev):
+    """BASELINE.json configs[0] proper: demo/sample_text.jpg, 91 x 38 - the detector pre-processing scales it UP by 16.8
+    (resize_shortest_edge, data/functions.py:196-227: the INTER_AREA branch no other test image reaches) and the page is one
+    text line.  A seeded detector's blobs shrink to points when its 640 x 1568 map is scaled back to 38 x 91 (the reference
+    hands OpenCV an empty dsize for those and raises; the product reports them as empty strings), so the
+    chain is checked in its two halves: detector stage on the real image (input tensor, map, boxes on the same map), and the
+    recogniser on the real image with the line's own quad - what a trained detector returns for a one-line page."""
+    from oracle import pipeline as op
+    from oracle.dbnet import dbnet_forward
+    from oracle.parseq import PRESETS, make_cfg
+    from oracle.preprocess import detector_preprocess
+    from yomitoku_amd import OCR
+    from yomitoku_amd.utils.synth import dbnet_state_dict, parseq_state_dict
+
+    img, ref_img = _sample("sample_text.jpg")
+    assert img.shape == (38, 91, 3)
+    ocr = OCR(configs=LITE_OCR, device="cuda:0")
+    sds = {"det": dbnet_state_dict(9, out_bias=-0.5), "rec": parseq_state_dict(1235, eos_bias=6.0)}
+    ocr.detector.model.load_state_dict(sds["det"])
+    ocr.recognizer.model.load_state_dict(sds["rec"])
+    det, rec = ocr.detector, ocr.recognizer
+    t = det.preprocess(img)
+    ref_t = detector_preprocess(ref_img)
+    assert tuple(t.shape) == tuple(ref_t.shape) == (1, 3, 640, 1568)
+    assert (t.cpu() - ref_t).abs().max().item() < 2e-5
+    prob = det.model(t)["binary"]
+    assert (prob.cpu() - dbnet_forward(sds["det"], ref_t)["binary"]).abs().max().item() < 1e-3
+    res, _ = det(img)
+    _, quads, det_scores = op.detect(sds["det"], ref_img, prob=prob.cpu())
+    assert len(quads) >= 1 and res.points == quads
+    assert np.allclose(res.scores, det_scores, atol=1e-9)
+    words, _ = ocr(img)  # degenerate boxes must come back as aligned placeholders, not as an exception
+    assert [w.points for w in words.words] == quads
+
+    line = [[[0, 0], [90, 0], [90, 37], [0, 37]], [[3, 4], [60, 4], [60, 33], [3, 33]], [[30, 2], [88, 6], [86, 36], [28, 30]]]
+    got, _ = rec(img, line)
+    ocfg = make_cfg(**PRESETS["parseq-tiny-dynw-v4"])
+    contents, scores, directions = op.recognize(sds["rec"], ocfg, ref_img, line, rec.charset, dynamic_width=True, batch_bucketing=True,
+                                                width_budget=8000, max_batch_size=64, batch_size=10, source_downscale=True)
+    assert got.contents == contents and got.directions == directions and got.points == line
+    assert np.allclose(got.scores, scores, rtol=1e-3, atol=1e-6)
+    assert any(len(c) > 0 for c in contents)
+    print("sample_text.jpg: boxes", len(quads), "line ->", contents)

@@ -21,7 +21,7 @@ def _close(a, b, tol=TOL):
 
 def test_gemm_identity_asymmetric(dev):
     """A = I against an asymmetric B catches a transposed C write (guide rule 16)."""
-    from yomitoku_amd import hipops
+    from tests import hipops
 
     c = 64
     x = torch.zeros(1, c, 8, 8)
@@ -69,7 +69,8 @@ RESET = (("splitk_force", -1), ("no_splitk", 0), ("conv_variant", 0), ("conv_fas
 @pytest.mark.parametrize("route", ROUTES, ids=[r[0] for r in ROUTES])
 @pytest.mark.parametrize("case", CASES)
 def test_conv2d_matches_torch(dev, case, route):
-    from yomitoku_amd import _lib, hipops
+    from yomitoku_amd import _lib
+    from tests import hipops
 
     try:
         for key, val in route[1].items():
@@ -87,7 +88,8 @@ def test_conv_epilogue_variants_are_bit_identical(dev, case, epilogue):
     """The direct epilogue and the swizzled K-tile layout change where values travel, not what is computed: every output
     bit under the library's default (swizzled 128 x 64 tiles, direct epilogue for ragged Cout) equals the one under each
     other setting, with and without residual, for every activation (the last cases have enough blocks for the wide tiles)."""
-    from yomitoku_amd import _lib, hipops
+    from yomitoku_amd import _lib
+    from tests import hipops
 
     n, cin, h, w, cout, k, stride, pad, dil = case
     g = torch.Generator().manual_seed(11)
@@ -121,7 +123,8 @@ def test_conv_epilogue_variants_are_bit_identical(dev, case, epilogue):
 def test_persistent_tile_loop_is_bit_identical(dev, case):
     """The persistent tile loop (a block walks a sequence of 128 x 64 tiles, the next tile's first loads issued before this
     tile's epilogue) against the one-tile-per-block kernel: same K order, same epilogue - every output bit."""
-    from yomitoku_amd import _lib, hipops
+    from yomitoku_amd import _lib
+    from tests import hipops
 
     n, cin, h, w, cout, k, stride, pad, dil = case
     g = torch.Generator().manual_seed(13)
@@ -157,7 +160,7 @@ def _conv_case(dev, case, hipops):
 
 
 def test_stem_conv7x7_tap4(dev):
-    from yomitoku_amd import hipops
+    from tests import hipops
 
     g = torch.Generator().manual_seed(7)
     x = torch.randn(2, 3, 64, 96, generator=g)
@@ -167,7 +170,7 @@ def test_stem_conv7x7_tap4(dev):
 
 
 def test_conv3x3_stem_tap4_s2(dev):
-    from yomitoku_amd import hipops
+    from tests import hipops
 
     g = torch.Generator().manual_seed(8)
     x = torch.randn(1, 3, 40, 40, generator=g)
@@ -178,7 +181,7 @@ def test_conv3x3_stem_tap4_s2(dev):
 
 @pytest.mark.parametrize("act", ["silu", "sigmoid", "gelu"])
 def test_conv_activations(dev, act):
-    from yomitoku_amd import hipops
+    from tests import hipops
 
     g = torch.Generator().manual_seed(9)
     x = torch.randn(1, 64, 12, 12, generator=g)
@@ -189,7 +192,7 @@ def test_conv_activations(dev, act):
 
 
 def test_maxpool(dev):
-    from yomitoku_amd import hipops
+    from tests import hipops
 
     x = torch.randn(2, 64, 33, 47, generator=torch.Generator().manual_seed(1))
     _close(hipops.maxpool3x3s2(x.to(dev)), F.max_pool2d(x, 3, 2, 1), 0.0)
@@ -197,7 +200,7 @@ def test_maxpool(dev):
 
 @pytest.mark.parametrize("shape,size", [((1, 64, 10, 14), (20, 28)), ((2, 64, 7, 9), (28, 36)), ((1, 256, 9, 12), (18, 25))])
 def test_bilinear(dev, shape, size):
-    from yomitoku_amd import hipops
+    from tests import hipops
 
     g = torch.Generator().manual_seed(3)
     x = torch.randn(*shape, generator=g)

@@ -15,7 +15,7 @@ def _close(a, b, tol):
 
 @pytest.mark.parametrize("rows,d,eps", [(7, 192, 1e-6), (130, 512, 1e-5), (33, 768, 1e-6), (5, 256, 1e-5)])
 def test_layernorm(dev, rows, d, eps):
-    from yomitoku_amd import hipops
+    from tests import hipops
 
     g = torch.Generator().manual_seed(d)
     x = torch.randn(rows, d, generator=g) * 3 + 1
@@ -41,7 +41,7 @@ def _ref_attn(q, k, v, heads, mask=None, kpm=None):
                                               (2, 6, 32, 800, 800), (2, 8, 32, 101, 37), (1, 8, 32, 300, 300),
                                               (2, 8, 48, 100, 100), (1, 8, 48, 77, 131)])  # 48: parseq-small (padded to 64 in LDS)
 def test_flash_attention(dev, b, heads, hd, lq, lk):
-    from yomitoku_amd import hipops
+    from tests import hipops
 
     g = torch.Generator().manual_seed(lq * 7 + hd)
     d = heads * hd
@@ -52,7 +52,7 @@ def test_flash_attention(dev, b, heads, hd, lq, lk):
 
 @pytest.mark.parametrize("b,heads,hd,lq,lk", [(3, 6, 32, 1, 9), (2, 8, 64, 101, 18), (4, 6, 32, 1, 736), (2, 8, 96, 101, 101)])
 def test_small_attention_with_masks(dev, b, heads, hd, lq, lk):
-    from yomitoku_amd import hipops
+    from tests import hipops
 
     g = torch.Generator().manual_seed(lk)
     d = heads * hd

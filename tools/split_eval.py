@@ -1,6 +1,6 @@
-"""How far do the nets' outputs move when the convolutions run with bf16-split operands (ymk_conv_bf16.hip) instead of
+"""How far do the nets' outputs move when the convolutions run with split operands (ymk_conv_split.hip) instead of
 exact fp32 MFMA?  The question BASELINE.json's tolerance asks: probability maps and logits within 1e-3 of the fp32 CPU
-path, discrete outputs unchanged.  For conv_split in (0, 3, 2): DBNet at the full page size (vs the oracle and vs the fp32
+path, discrete outputs unchanged.  For conv_split in SPLITS (env, default 0,3,2,16; 16 = two scaled fp16 planes): DBNet at the full page size (vs the oracle and vs the fp32
 kernel), the reference-class goldens of PARSeq / RT-DETR, a wave-sized grouped PARSeq forward, an RT-DETR batch, and a
 whole DocumentAnalyzer page (strings / boxes / order compared field by field).  Prints one JSON document."""
 import ast
@@ -82,7 +82,7 @@ def main():
                     "text_recognizer": {"model_name": "parseq-tiny-dynw-v4", "from_pretrained": False, "dynamic_width": True, "batch_bucketing": True, "source_downscale": True}},
             "layout_analyzer": {"layout_parser": {"from_pretrained": False}, "table_structure_recognizer": {"from_pretrained": False}}}
     base = {}
-    for split in (0, 3, 2):
+    for split in [int(v) for v in os.environ.get("SPLITS", "0,3,2,16").split(",")]:
         _lib.debug_option("conv_split", split)
         r = {}
         # DBNet

@@ -1,5 +1,5 @@
-"""Discrete outputs of whole pages with the bf16-split convolutions on the detector and the two RT-DETRv2 nets (recogniser
-exact) against the exact-fp32 run of the same analyzer: every string / box / order / id leaf of the DocumentAnalyzerSchemas
+"""Discrete outputs of whole pages with split-operand convolutions (SPLIT env: 2 / 3 = bf16 planes, 16 = two scaled fp16
+planes, the default) on the detector and the two RT-DETRv2 nets (recogniser exact unless ALL=1) against the exact-fp32 run of the same analyzer: every string / box / order / id leaf of the DocumentAnalyzerSchemas
 of N synthetic pages, through DocumentAnalyzer.serve.  Prints one JSON line."""
 import json
 import os
@@ -29,16 +29,29 @@ def main():
     an.layout.table_structure_recognizer.model.load_state_dict(rtdetr_state_dict(1241, num_classes=3, score_bias=-1.0))
     pages = [synthetic_page_with_truth(100 + i, *((1600, 1200) if i % 3 else (1200, 1600)))[0] for i in range(n)]
     base = [r.model_dump() for r in an.serve(pages)]
-    nets = (an.text_detector.model, an.layout.layout_parser.model, an.layout.table_structure_recognizer.model)
+    code = int(os.environ.get("SPLIT", "16"))
+    nets = [an.text_detector.model, an.layout.layout_parser.model, an.layout.table_structure_recognizer.model]
+    if os.environ.get("ALL") == "1":
+        nets.append(an.text_recognizer.model)
     for m in nets:
-        m.set_conv_split(2)
+        m.set_conv_split(code)
     split = [r.model_dump() for r in an.serve(pages)]
     for m in nets:
         m.set_conv_split(0)
     again = [r.model_dump() for r in an.serve(pages)]
-    out = {"pages": n, "words": sum(len(d["words"]) for d in base), "tables": sum(len(d["tables"]) for d in base),
+    arms = [("split_det_layout_table_vs_fp32", split), ("fp32_repeat_vs_fp32", again)]
+    if os.environ.get("CONTROL") == "1":
+        # the yardstick: EXACT fp32 products summed in another order (every convolution through the split-K kernel, which adds
+        # the K tiles of a row in four interleaved chains) - what any second fp32 implementation differs by
+        from yomitoku_amd import _lib
+        _lib.debug_option("splitk_force", 0)
+        try:
+            arms.append(("exact_fp32_other_summation_order_vs_fp32", [r.model_dump() for r in an.serve(pages)]))
+        finally:
+            _lib.debug_option("splitk_force", -1)
+    out = {"conv_split": code, "nets": "all four" if len(nets) == 4 else "detector + layout + table", "pages": n, "words": sum(len(d["words"]) for d in base), "tables": sum(len(d["tables"]) for d in base),
            "paragraphs": sum(len(d["paragraphs"]) for d in base)}
-    for label, other in (("split_det_layout_table_vs_fp32", split), ("fp32_repeat_vs_fp32", again)):
+    for label, other in arms:
         st = {"discrete": 0, "leaves": 0, "float_rel": 0.0}
         pages_diff = 0
         for a, b in zip(other, base):

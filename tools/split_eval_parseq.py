@@ -51,17 +51,18 @@ def main():
     for name, (sd, preset, over, xs) in cases.items():
         ocfg, net = _net(dev, sd, preset, **over)
         res = {}
-        for label, split, enc in (("fp32", 0, -1), ("encoder_2_planes", 0, 2), ("all_2_planes", 2, -1), ("encoder_3_planes", 0, 3)):
+        for label, split, enc in (("fp32", 0, -1), ("encoder_2_planes", 0, 2), ("all_2_planes", 2, -1), ("encoder_3_planes", 0, 3),
+                                  ("encoder_f16x2", 0, 16), ("all_f16x2", 16, -1)):
             net.set_conv_split(split)
             net.set_param("conv_split_encoder", enc)
             run(net, xs)  # shapes seen once
             res[label] = run(net, xs)
         r = {"lines": int(res["fp32"][0].shape[0]), "forward_ms": {k: round(v[3] * 1e3, 2) for k, v in res.items()}}
-        for k in ("encoder_2_planes", "all_2_planes", "encoder_3_planes"):
+        for k in ("encoder_2_planes", "all_2_planes", "encoder_3_planes", "encoder_f16x2", "all_f16x2"):
             r[k + "_vs_fp32_kernel"] = compare(res[k], res["fp32"], xs)
         # two small groups against the CPU oracle (fp32 PyTorch)
         small = sorted(range(len(xs)), key=lambda g: xs[g].shape[0] * xs[g].shape[3])[:2]
-        for k in ("fp32", "encoder_2_planes"):
+        for k in ("fp32", "encoder_2_planes", "all_f16x2"):
             worst = 0.0
             for g in small:
                 row = sum(x.shape[0] for x in xs[:g])

@@ -20,7 +20,7 @@ double prof_bytes();
 bool conv_debug_option(const std::string& key, int value);
 bool parseq_debug_option(const std::string& key, int value);
 bool decstep_debug_option(const std::string& key, int value);
-bool conv_bf16_debug_option(const std::string& key, int value);
+bool conv_split_debug_option(const std::string& key, int value);
 }  // namespace ymk
 
 struct ymk_model {
@@ -169,7 +169,7 @@ int ymk_debug_option(const char* key, int value) {
   YMK_CHECK(key != nullptr, "null key");
   const std::string k(key);
   YMK_CHECK(ymk::conv_debug_option(k, value) || ymk::parseq_debug_option(k, value) || ymk::decstep_debug_option(k, value) ||
-                ymk::conv_bf16_debug_option(k, value),
+                ymk::conv_split_debug_option(k, value),
             "unknown debug option: " + k);
   YMK_API_END
 }
@@ -210,7 +210,6 @@ int ymk_op_conv2d(const float* x_dev, int n, int h, int w, int c, const float* w
   std::vector<float> panel;
   pack_conv_weight(w_host_oihw, cout, cin, kh, kw, tap4 != 0, panel, cw.kpad, cw.ctiles);
   cw.w = pool.upload(panel);
-  ymk::make_split_panels(pool, cw);
   if (scale_host) cw.scale = pool.upload(scale_host, cout);
   if (bias_host) cw.bias = pool.upload(bias_host, cout);
   Tensor in{const_cast<float*>(x_dev), n, h, w, c, c};
@@ -223,6 +222,8 @@ int ymk_op_conv2d(const float* x_dev, int n, int h, int w, int c, const float* w
   a.dil = dil;
   a.act = act;
   a.res = res_dev ? &res : nullptr;
+  SplitCtxOwner split_ctx;  // split copies of this call's panel live and die with it
+  ConvSplitScope scope(-1, split_ctx.get());
   conv2d((hipStream_t)stream, in, cw, a, out);
   YMK_HIP(hipStreamSynchronize((hipStream_t)stream));  // pool frees the panel on return
   YMK_API_END

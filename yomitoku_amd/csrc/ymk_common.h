@@ -82,9 +82,6 @@ struct ConvW {
   float* w = nullptr;      // [cout][kpad] device
   float* scale = nullptr;  // [cout] or null (folded BN gamma/sqrt(var+eps))
   float* bias = nullptr;   // [cout] or null
-  // the same panel split into bf16 planes, [cout^128][kpad / 32][planes][32] (ymk_conv_bf16.hip): 2 planes (hi, lo), 3 planes
-  const unsigned short* w2 = nullptr;
-  const unsigned short* w3 = nullptr;
   int cout = 0, cin = 0, kh = 1, kw = 1;
   int kpad = 0, ctiles = 0, mode = 0;
 };
@@ -108,15 +105,30 @@ struct ConvArgs {
   const int* group_open = nullptr;
 };
 
-// Operand precision of the calling thread's conv2d / gemm launches while the scope lives: 0 = exact fp32 MFMA, 2 / 3 =
-// bf16-split operands (ymk_conv_bf16.hip).  A model's forward opens one with its "conv_split" parameter; without a scope
-// the process-wide ymk_debug_option("conv_split") applies.
+// Split-operand convolutions (ymk_conv_split.hip).  "conv_split" codes: 0 = exact fp32 MFMA; 2 / 3 = operands cut into
+// 2 / 3 bf16 planes (3 / 6 MFMAs per product tile); 16 = two fp16 planes of the operands scaled by a power of two
+// (per tensor for the activations, from a max|x| pass; per output channel for the weights): 3 MFMAs, products good to
+// 2^-21 - fp32 grade for every K >= 64, where the fp32 accumulation's own rounding is the larger term.
+constexpr int SPLIT_F16X2 = 16;
+// Device-side state of that path for ONE model (one host thread, one stream at a time): the split copies of the weight
+// panels, built the first time a (panel, code) pair is used, and the two max|x| words the launches alternate between.
+class SplitCtx;
+struct SplitCtxOwner {
+  SplitCtx* get();
+  ~SplitCtxOwner();
+ private:
+  SplitCtx* p_ = nullptr;
+};
+// Operand precision of the calling thread's conv2d / gemm launches while the scope lives.  A model's forward opens one with
+// its "conv_split" parameter and its SplitCtx; a nested scope without a context keeps the enclosing one; split < 0 follows
+// the process-wide ymk_debug_option("conv_split").  Without a context the split path is not taken.
 class ConvSplitScope {
  public:
-  explicit ConvSplitScope(int split);
+  explicit ConvSplitScope(int split, SplitCtx* ctx = nullptr);
   ~ConvSplitScope();
  private:
   int prev_;
+  SplitCtx* prev_ctx_;
 };
 
 // out must be pre-shaped (n, oh, ow, cout[, ld]); for EPI_DECONV2X2 out is (n, 2h, 2w, cout/4).
@@ -190,9 +202,6 @@ class DevicePool {
   size_t bytes_ = 0;
 };
 
-// bf16-split copies of a packed fp32 panel (c.w2 / c.w3), built on the device; call after c.w, c.kpad, c.cout are set
-void make_split_panels(DevicePool& pool, ConvW& c);
-
 // conv (+ optional BatchNorm folded to scale/bias) from a state-dict
 ConvW make_conv(DevicePool& pool, const WeightStore& ws, const std::string& conv_prefix,
                 const std::string& bn_prefix /* "" = none */, bool tap4 = false, float bn_eps = 1e-5f);
@@ -219,6 +228,7 @@ class Model {
   bool finalized = false;
   // "conv_split" parameter (ymk_model_set_param; may be changed between forwards): operand precision of this model's convs
   int conv_split() const { return (int)param("conv_split", -1); }
+  SplitCtxOwner split_ctx;
 };
 
 Model* create_dbnet();

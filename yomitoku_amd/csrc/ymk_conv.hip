@@ -459,12 +459,19 @@ static std::atomic<int> g_no_splitk{0};      // 1: every launch through conv_ige
 static std::atomic<int> g_conv_fast{27};     // ConvK::fast
 static std::atomic<int> g_conv_variant{0};   // conv_igemm schedule selector for A/B runs, see launch_wide()
 static std::atomic<int> g_prof_dump{0};      // 1: ymk_prof_end prints one line per launch to stderr
-static std::atomic<int> g_conv_split{0};     // 0: exact fp32 MFMA (the product path); 2 / 3: bf16-split operands, 3 / 6 MFMAs (ymk_conv_bf16.hip)
+static std::atomic<int> g_conv_split{0};     // 0: exact fp32 MFMA (the product path); 2 / 3 / 16: split operands (ymk_conv_split.hip)
 static int splitk_forced() { return g_splitk_force.load(std::memory_order_relaxed); }
 static bool no_splitk() { return g_no_splitk.load(std::memory_order_relaxed) != 0; }
 static thread_local int t_conv_split = -1;  // >= 0: set by a ConvSplitScope on this thread (a model's own parameter)
-ConvSplitScope::ConvSplitScope(int split) : prev_(t_conv_split) { t_conv_split = split; }
-ConvSplitScope::~ConvSplitScope() { t_conv_split = prev_; }
+static thread_local SplitCtx* t_split_ctx = nullptr;
+ConvSplitScope::ConvSplitScope(int split, SplitCtx* ctx) : prev_(t_conv_split), prev_ctx_(t_split_ctx) {
+  t_conv_split = split;
+  if (ctx) t_split_ctx = ctx;
+}
+ConvSplitScope::~ConvSplitScope() {
+  t_conv_split = prev_;
+  t_split_ctx = prev_ctx_;
+}
 
 bool conv_debug_option(const std::string& key, int value) {
   if (key == "splitk_force") g_splitk_force = value;
@@ -712,9 +719,9 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
     YMK_HIP(hipGetLastError());
     return;
   }
-  {  // opt-in: bf16-split operands with fp32 accumulation for the launches that fill the chip (measurement / evaluation)
+  {  // split operands (bf16 / fp16 planes) with fp32 accumulation for the launches that fill the chip (measurement / evaluation)
     const int split = t_conv_split >= 0 ? t_conv_split : g_conv_split.load(std::memory_order_relaxed);
-    if (split != 0 && a.row_group == nullptr && conv2d_bf16_split(s, k, w, split)) return;
+    if (split != 0 && a.row_group == nullptr && t_split_ctx != nullptr && conv2d_split(s, k, w, split, t_split_ctx)) return;
   }
   // tile selection: wide tiles when there is enough work to fill 256 CUs x 2 blocks
   const long blocks128 = (long)((k.M + 127) / 128) * ((w.cout + 127) / 128);

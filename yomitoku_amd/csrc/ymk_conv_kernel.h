@@ -1,5 +1,5 @@
-// Device-side pieces shared by the implicit-GEMM convolution kernels (ymk_conv.hip: exact fp32 MFMA; ymk_conv_bf16.hip:
-// bf16-split operands, fp32 accumulate): the launch record, the row predicate and the epilogue.
+// Device-side pieces shared by the implicit-GEMM convolution kernels (ymk_conv.hip: exact fp32 MFMA; ymk_conv_split.hip:
+// bf16 / fp16 split operands, fp32 accumulate): the launch record, the row predicate and the epilogue.
 #pragma once
 #include <utility>
 
@@ -32,7 +32,8 @@ struct ConvK {
                 // are possible), bit 3 swizzled K tiles / three 128 x 64 blocks per CU, bit 4 direct epilogue for the
                 // launches that cannot store 16 bytes per lane (ragged Cout: the 7119-wide vocabulary head); bit 5 (off):
                 // persistent tile loop for the swizzled tile (ymk_conv_persist.hip, not yet run on hardware)
-  int ntiles;   // conv_igemm_persist only: M tiles x N tiles of the launch (last member: the other kernels' argument offsets stay)
+  int ntiles;   // conv_igemm_persist only: M tiles x N tiles of the launch
+  const unsigned* amax;  // fp16-split kernels only: bits of max|x| over the input view (ymk_conv_split.hip)
 };
 
 // true when some row of the block's M tile [m0, m0 + BM) is still needed (or no row predicate was given); block-uniform
@@ -266,9 +267,9 @@ __device__ __forceinline__ void epilogue_direct(const ConvK& p, const f32x16 (&a
 // per-launch timing hooks (bench.py roofline leg), defined in ymk_conv.hip
 std::pair<hipEvent_t, hipEvent_t>* conv_prof_open(hipStream_t s, const ConvK& k, int BM, int BN, int grid, int ksplit);
 
-// bf16-split path (ymk_conv_bf16.hip): true when the launch was taken (ns = 2: hi/lo, 3 MFMAs per product tile;
-// ns = 3: hi/mid/lo, 6 MFMAs)
-bool conv2d_bf16_split(hipStream_t s, ConvK& k, const ConvW& w, int ns);
+// split-operand path (ymk_conv_split.hip): true when the launch was taken.  code 2 / 3: bf16 planes (3 / 6 MFMAs per
+// product tile), SPLIT_F16X2: two scaled fp16 planes (3 MFMAs)
+bool conv2d_split(hipStream_t s, ConvK& k, const ConvW& w, int code, SplitCtx* ctx);
 
 // persistent tile loop over the swizzled 128 x 64 tile (ymk_conv_persist.hip; opt-in, conv_fast bit 5): true when taken
 bool conv2d_persistent(hipStream_t s, ConvK& k);

@@ -1,0 +1,651 @@
+// Implicit-GEMM convolution with SPLIT operands and fp32 accumulation (gfx950), the alternative to the exact fp32-MFMA
+// kernel of ymk_conv.hip for the same layers (models/dbnet_plus.py:33-38,56-127; rtdetr_backbone.py;
+// parseq_transformer.py): same GEMM view, same gathers, same epilogue.
+//
+// Why: v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (157 TFLOP/s); the 16-bit MFMAs are 16 x faster.  An fp32 value
+// splits exactly into short pieces (round-to-nearest at every cut, remainders exact in fp32), so a product is a sum of
+// short x short products, each exact in fp32:
+//   bf16, 3 planes, 6 MFMAs  x_h y_h + (x_h y_m + x_m y_h) + (x_m y_m + x_h y_l + x_l y_h)   dropped terms <= 2^-23 |xy|
+//   bf16, 2 planes, 3 MFMAs  x_h y_h + (x_h y_l + x_l y_h)                                   dropped terms <= 2^-15 |xy|
+//   fp16, 2 planes, 3 MFMAs  the same three terms on 11-bit pieces                           dropped terms <= 2^-21 |xy|
+// fp16 pieces carry 22 of the 24 significand bits in the same 3 MFMAs that two bf16 planes need (16 bits), i.e. fp32-grade
+// products at 16 / 3 = 5.3 x the fp32 matrix rate: for K >= 64 the fp32 accumulation's own rounding (2^-24 of a partial sum
+// that is ~sqrt(K) products large) exceeds the 2^-21 per product.  What fp16 lacks is range, so the operands are scaled by
+// powers of two (exact): the activations by ONE scale per launch that puts max|x| of the input view into [2^14, 2^15) -
+// a pass over the input (k_absmax) ahead of the convolution, its result read by the kernel from device memory, no host
+// round trip -, the weights per output channel at panel-build time (row maximum into [2^14, 2^15); the inverse goes into the
+// epilogue's per-channel scale).  Elements more than 2^18 below the tensor's maximum lose low-plane bits gradually (fp16
+// subnormals); nothing overflows.  Accumulation is fp32 inside the MFMA (not an fmaf chain in k order: results agree
+// with the fp32 kernel to rounding, not bit for bit).
+//
+// Data path: activations stay fp32 in HBM; a thread splits the 4 floats it stages into NS x 4 halves on the way to LDS
+// (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32).  Weights are split once per (panel, format), the first time a launch asks, into
+// panels [Cout^128][K tiles][NS][32], so a K tile's B rows are copied to LDS verbatim.  LDS row = NS x 64 B + 16 B pad
+// (conflict-free ds_read_b128: row stride 36 or 52 dwords = 4 x odd), one ds_read_b128 per (32-row tile, plane, 16-k
+// step) feeds v_mfma_f32_32x32x16_{bf16,f16}: lane l holds row l & 31, k = 8 (l >> 5) .. + 7 of the step, for A and B alike.
+#include <atomic>
+#include <string>
+#include <type_traits>
+#include <unordered_map>
+
+#include "ymk_conv_kernel.h"
+
+namespace ymk {
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// FMT 0: bf16 pieces, 1: fp16 pieces of the scaled operand
+template <int FMT> struct Half;
+template <> struct Half<0> { typedef bf16x2_t v2; typedef bf16x8_t v8; };
+template <> struct Half<1> { typedef f16x2_t v2; typedef f16x8_t v8; };
+
+template <int FMT>
+__device__ __forceinline__ f32x16 mfma16(const typename Half<FMT>::v8 a, const typename Half<FMT>::v8 b, const f32x16 c) {
+  if constexpr (FMT == 0) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// 4 floats (times sa, a power of two: exact) -> NS planes of 4 halves (8 B each)
+template <int FMT, int NS>
+__device__ __forceinline__ void split4(const f32x4 v, float sa, uint2* planes) {
+  typedef typename Half<FMT>::v2 h2;
+  f32x2_t a = {v.x, v.y}, b = {v.z, v.w};
+  if (FMT == 1) {
+    a *= sa;
+    b *= sa;
+  }
+#pragma unroll
+  for (int pl = 0; pl < NS; ++pl) {
+    const h2 pa = __builtin_convertvector(a, h2), pb = __builtin_convertvector(b, h2);
+    planes[pl].x = __builtin_bit_cast(unsigned, pa);
+    planes[pl].y = __builtin_bit_cast(unsigned, pb);
+    if (pl + 1 < NS) {
+      a -= __builtin_convertvector(pa, f32x2_t);  // exact: the remainder of a round-to-nearest cut fits fp32
+      b -= __builtin_convertvector(pb, f32x2_t);
+    }
+  }
+}
+
+// max|x| bits -> {sa, 1 / sa}, sa the power of two that puts max|x| into [2^14, 2^15); both kept normal whatever the input
+__device__ __forceinline__ float2 f16_scales(unsigned amax_bits) {
+  int e = (int)(amax_bits >> 23);  // biased exponent, 0 .. 255
+  e = e < 27 ? 27 : (e > 227 ? 227 : e);
+  float2 r;
+  r.x = __uint_as_float((unsigned)(268 - e) << 23);  // 2^(14 - (e - 127))
+  r.y = __uint_as_float((unsigned)(e - 14) << 23);
+  return r;
+}
+
+// blocks of this shape a CU's 160 KB of LDS holds (at most 2 are asked for) -> minimum waves per SIMD for the register allocator
+template <int BM, int BN, int WM, int WN, int NS, int KS>
+constexpr int bf16_waves_per_simd() {
+  constexpr int lds = 2 * (BM + BN) * (KS * NS * 64 + 16);
+  constexpr int blocks = 2 * lds <= 160 * 1024 ? 2 : 1;
+  return blocks * 64 * WM * WN / 256;
+}
+
+// KS: 32-k tiles per LDS stage (a stage = one barrier interval: KS = 2 halves the barriers per k and doubles the MFMAs a wave
+// issues between them); PF: stages the global loads run ahead of the MFMAs (2 = two register sets, as conv_igemm's PF).
+template <int BM, int BN, int WM, int WN, int NS, int KS, int PF, int FMT>
+__global__ __launch_bounds__(64 * WM * WN, (bf16_waves_per_simd<BM, BN, WM, WN, NS, KS>())) void conv_igemm_split(ConvK p, const uint4* __restrict__ wsplit) {
+  typedef typename Half<FMT>::v8 h8;
+  static_assert(PF >= 1 && PF <= 3, "prefetch: 1 = one stage ahead, 2 = two ahead, 3 = two ahead with the LDS stores threaded through the MFMAs");
+  constexpr int NSET = PF == 1 ? 1 : 2;  // register sets of staged loads
+  constexpr int NT = 64 * WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int TILEB = NS * 64;               // bytes of one 32-k tile of a row: NS planes of 32 bf16
+  constexpr int ROWB = KS * TILEB + 16;        // bytes of an LDS row: KS tiles + pad (row stride = 4 x odd dwords)
+  constexpr int STAGE_B = (BM + BN) * ROWB;    // bytes of one stage
+  constexpr int RPP = NT / 8;                  // A rows staged per pass (8 threads x 16 B of fp32 per 32-k row)
+  constexpr int APASS = BM / RPP;
+  static_assert(BM % RPP == 0, "tile rows must divide by the staging pass");
+  constexpr int PPR = NS * 4;                  // 16 B pieces of a B row per 32-k tile
+  constexpr int BPASS = (BN * PPR + NT - 1) / NT;
+  constexpr int LDC = BN + 4;
+  constexpr int ECAP = 2 * STAGE_B / 4 / LDC;  // rows of the fp32 output tile the two stages can hold
+  constexpr int EROWS = ECAP >= BM ? BM : (ECAP >= BM / 2 ? BM / 2 : BM / 4);  // rows per epilogue pass: divides BM
+  static_assert(EROWS >= WTM && EROWS % WTM == 0 && EROWS <= ECAP, "an epilogue pass must hold whole wave tiles");
+  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE_B];
+
+  const int t = threadIdx.x;
+  float sa = 1.f, inv_sa = 1.f;
+  if (FMT == 1) {
+    const float2 sc = f16_scales(*p.amax);
+    sa = sc.x;
+    inv_sa = sc.y;
+  }
+  int tile;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = tile / p.ntiles_n, tile_n = tile - tile_m * p.ntiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (!tile_needed<BM, NT>(p, m0, t)) return;
+
+  const int colq = t & 7, rowb = t >> 3;
+  int pixb[APASS], ih0[APASS], iw0[APASS];
+  const bool pointwise = (p.fast & 1) && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.stride_w == 1 && p.pad == 0;
+#pragma unroll
+  for (int i = 0; i < APASS; ++i) {
+    const int m = m0 + rowb + RPP * i;
+    if (m < p.M && pointwise) {
+      pixb[i] = m;
+      ih0[i] = 0;
+      iw0[i] = 0;
+    } else if (m < p.M) {
+      const int ohw = p.OH * p.OW;
+      const int n = m / ohw, rem = m - n * ohw;
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      pixb[i] = n * p.H * p.W;
+      ih0[i] = oh * p.stride - p.pad;
+      iw0[i] = ow * p.stride_w - p.pad;
+    } else {
+      pixb[i] = 0;
+      ih0[i] = -(1 << 20);
+      iw0[i] = 0;
+    }
+  }
+  const int ktiles = p.Kpad >> 5;   // a multiple of KS (the launcher checks)
+  const int nstages = ktiles / KS;
+  // B pieces of this thread: piece q = t + NT * j of the tile's BN x PPR, row-major
+  const uint4* wsrc[BPASS];
+  int boff[BPASS];  // byte offset inside the B half of a stage, or -1 past the tile
+#pragma unroll
+  for (int j = 0; j < BPASS; ++j) {
+    const int q = t + NT * j;
+    const int row = q / PPR, piece = q - row * PPR;
+    const bool ok = q < BN * PPR;
+    wsrc[j] = wsplit + ((size_t)(n0 + (ok ? row : 0)) * ktiles) * PPR + piece;
+    boff[j] = ok ? row * ROWB + piece * 16 : -1;
+  }
+
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+  f32x4 ra[NSET][KS][APASS];
+  uint4 rb[NSET][KS][BPASS];
+  int cur_kh = 0, cur_kw = 0, cur_cc = 0;
+  unsigned voff[APASS];
+#pragma unroll
+  for (int i = 0; i < APASS; ++i) voff[i] = OOB_OFFSET;
+
+  // stage st (K tiles st * KS .. + KS - 1) -> register set `set`; the tap cursor walks K tile by K tile
+  auto load_stage = [&](int st, int set) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (cur_cc == 0) {  // wave-uniform: a new filter tap
+        const int dh = cur_kh * p.dil, dw = cur_kw * p.dil;
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+          const int ih = ih0[i] + dh, iw = iw0[i] + dw;
+          const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+          const unsigned off = ((unsigned)(pixb[i] + ih * p.W + iw) * (unsigned)p.in_ld + (unsigned)(colq * 4)) * 4u;
+          voff[i] = ok ? off : OOB_OFFSET;
+        }
+      }
+      const bool chan_ok = cur_cc * 32 + colq * 4 < p.C;
+      const int soff = cur_cc * 128;
+#pragma unroll
+      for (int i = 0; i < APASS; ++i) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(chan_ok ? voff[i] : OOB_OFFSET), soff, 0);
+        ra[set][ks][i] = __builtin_bit_cast(f32x4, v);
+      }
+      if (++cur_cc == p.ctiles) {
+        cur_cc = 0;
+        if (++cur_kw == p.KW) {
+          cur_kw = 0;
+          ++cur_kh;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < BPASS; ++j) rb[set][ks][j] = wsrc[j][(size_t)(st * KS + ks) * PPR];
+    }
+  };
+
+  auto store_stage = [&](int buf, int set) {
+    char* As = lds + buf * STAGE_B;
+    char* Bs = As + BM * ROWB;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int i = 0; i < APASS; ++i) {
+        uint2 pl[NS];
+        split4<FMT, NS>(ra[set][ks][i], sa, pl);
+        char* row = As + (rowb + RPP * i) * ROWB + ks * TILEB + colq * 8;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) *reinterpret_cast<uint2*>(row + q * 64) = pl[q];
+      }
+#pragma unroll
+      for (int j = 0; j < BPASS; ++j)
+        if (boff[j] >= 0) *reinterpret_cast<uint4*>(Bs + boff[j] + ks * TILEB) = rb[set][ks][j];
+    }
+  };
+
+  const int wv = t >> 6, lane = t & 63;
+  const int wm = wv / WN, wn = wv - wm * WN;
+  const int li = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // product terms, smallest first: (A plane, B plane)
+  constexpr int NTERM = NS == 3 ? 6 : 3;
+  constexpr int TA[6] = {NS - 1, 0, 1, 1, 0, 0};
+  constexpr int TB[6] = {0, NS - 1, 1, 0, 1, 0};
+  constexpr int T0 = NS == 3 ? 0 : 3;
+
+  auto compute = [&](int buf) {
+    const char* As = lds + buf * STAGE_B + (wm * WTM + li) * ROWB + lh * 16;
+    const char* Bs = lds + buf * STAGE_B + BM * ROWB + (wn * WTN + li) * ROWB + lh * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {  // two 16-k steps per 32-k tile
+        h8 fa[TM][NS], fb[TN][NS];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int q = 0; q < NS; ++q) fa[a][q] = *reinterpret_cast<const h8*>(As + a * 32 * ROWB + ks * TILEB + q * 64 + s * 32);
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+          for (int q = 0; q < NS; ++q) fb[b][q] = *reinterpret_cast<const h8*>(Bs + b * 32 * ROWB + ks * TILEB + q * 64 + s * 32);
+        // term-major: consecutive MFMAs go to different accumulators whenever a wave owns more than one 32 x 32 tile
+#pragma unroll
+        for (int tm = 0; tm < NTERM; ++tm)
+#pragma unroll
+          for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+              acc[a][b] = mfma16<FMT>(fa[a][TA[T0 + tm]], fb[b][TB[T0 + tm]], acc[a][b]);
+      }
+  };
+
+  // PF == 3: the same MFMAs with the next stage's conversion + LDS stores slotted between them, one chunk (one A pass: split
+  // + NS ds_write_b64, or one B piece: ds_write_b128) every `stride` MFMAs, pinned by scheduling fences.  A wave issues in
+  // order and an MFMA occupies the matrix pipe for 32 cycles: the few VALU / DS instructions behind it ride in its shadow
+  // instead of forming a separate phase between the last MFMA and the barrier (the staged data was loaded a whole stage
+  // earlier, so no chunk waits on memory).
+  auto compute_store = [&](int buf, int sbuf, int set, auto do_store) {
+    constexpr bool STORE = decltype(do_store)::value;
+    const char* As = lds + buf * STAGE_B + (wm * WTM + li) * ROWB + lh * 16;
+    const char* Bs = lds + buf * STAGE_B + BM * ROWB + (wn * WTN + li) * ROWB + lh * 16;
+    char* SA = lds + sbuf * STAGE_B;
+    char* SB = SA + BM * ROWB;
+    constexpr int NCH = KS * (APASS + BPASS);
+    constexpr int NM = KS * 2 * NTERM * TM * TN;
+    constexpr int STRIDE = NM / NCH > 0 ? NM / NCH : 1;
+    auto chunk = [&](int c) {
+      const int ks = c / (APASS + BPASS), r = c - ks * (APASS + BPASS);
+      if (r < APASS) {
+        uint2 pl[NS];
+        split4<FMT, NS>(ra[set][ks][r], sa, pl);
+        char* row = SA + (rowb + RPP * r) * ROWB + ks * TILEB + colq * 8;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) *reinterpret_cast<uint2*>(row + q * 64) = pl[q];
+      } else {
+        const int j = r - APASS;
+        if (boff[j] >= 0) *reinterpret_cast<uint4*>(SB + boff[j] + ks * TILEB) = rb[set][ks][j];
+      }
+    };
+    int mi = 0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        h8 fa[TM][NS], fb[TN][NS];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int q = 0; q < NS; ++q) fa[a][q] = *reinterpret_cast<const h8*>(As + a * 32 * ROWB + ks * TILEB + q * 64 + s * 32);
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+          for (int q = 0; q < NS; ++q) fb[b][q] = *reinterpret_cast<const h8*>(Bs + b * 32 * ROWB + ks * TILEB + q * 64 + s * 32);
+#pragma unroll
+        for (int tm = 0; tm < NTERM; ++tm)
+#pragma unroll
+          for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+              acc[a][b] = mfma16<FMT>(fa[a][TA[T0 + tm]], fb[b][TB[T0 + tm]], acc[a][b]);
+              if (STORE && mi % STRIDE == STRIDE - 1 && mi / STRIDE < NCH) {
+                __builtin_amdgcn_sched_barrier(0);
+                chunk(mi / STRIDE);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+              ++mi;
+            }
+      }
+    if (STORE) {
+#pragma unroll
+      for (int c = NM / STRIDE; c < NCH; ++c) chunk(c);  // more chunks than MFMA slots (short stages): the rest at the end
+    }
+  };
+
+  load_stage(0, 0);
+  store_stage(0, 0);
+  if (PF >= 2 && nstages > 1) load_stage(1, 1);
+  __syncthreads();
+  if (PF == 3) {
+    for (int st = 0; st < nstages; st += 2) {
+      if (st + 2 < nstages) load_stage(st + 2, 0);
+      if (st + 1 < nstages) compute_store(0, 1, NSET - 1, std::true_type{});
+      else compute_store(0, 1, NSET - 1, std::false_type{});
+      __syncthreads();
+      if (st + 1 >= nstages) break;
+      if (st + 3 < nstages) load_stage(st + 3, NSET - 1);
+      if (st + 2 < nstages) compute_store(1, 0, 0, std::true_type{});
+      else compute_store(1, 0, 0, std::false_type{});
+      __syncthreads();
+    }
+  } else if (PF == 1) {
+    for (int st = 0; st < nstages; ++st) {
+      const int buf = st & 1;
+      if (st + 1 < nstages) load_stage(st + 1, 0);
+      compute(buf);
+      if (st + 1 < nstages) store_stage(buf ^ 1, 0);
+      __syncthreads();
+    }
+  } else {
+    // stage s travels in register set s & 1: loaded at the top of step s - 2, written to LDS[s & 1] at the end of step s - 1
+    for (int st = 0; st < nstages; st += 2) {
+      if (st + 2 < nstages) load_stage(st + 2, 0);
+      compute(0);
+      if (st + 1 < nstages) store_stage(1, NSET - 1);
+      __syncthreads();
+      if (st + 1 >= nstages) break;
+      if (st + 3 < nstages) load_stage(st + 3, NSET - 1);
+      compute(1);
+      if (st + 2 < nstages) store_stage(0, 0);
+      __syncthreads();
+    }
+  }
+
+  float* Cs = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int e0 = 0; e0 < BM; e0 += EROWS) {
+    if (e0 > 0) __syncthreads();
+    if (wm * WTM >= e0 && wm * WTM < e0 + EROWS) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = wm * WTM - e0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            Cs[row * LDC + wn * WTN + b * 32 + li] = FMT == 1 ? acc[a][b][r] * inv_sa : acc[a][b][r];
+          }
+    }
+    __syncthreads();
+    epilogue_tile<EROWS, BN, NT>(p, Cs, m0 + e0, n0, t);
+  }
+}
+
+// ---- fp32 panel [rows][kpad] -> split panel [rows][kpad / 32][NS][32] halves (once per panel and format)
+template <int NS>
+__global__ void k_split_panel(const float* __restrict__ w, unsigned short* __restrict__ out, size_t n_elems, int kpad) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_elems) return;
+  const size_t row = i / kpad;
+  const int k = (int)(i - row * kpad), kt = k >> 5, kk = k & 31;
+  float r = w[i];
+#pragma unroll
+  for (int pl = 0; pl < NS; ++pl) {
+    const __bf16 h = (__bf16)r;
+    out[((row * (kpad >> 5) + kt) * NS + pl) * 32 + kk] = __builtin_bit_cast(unsigned short, h);
+    r -= (float)h;
+  }
+}
+
+// fp16 form: one block per panel row.  The row is scaled by the power of two that puts its largest |w| into [2^14, 2^15);
+// scale_out[row] = (BatchNorm scale of the channel, or 1) / that power - what the epilogue multiplies the accumulators by.
+__global__ void k_split_panel_f16(const float* __restrict__ w, unsigned short* __restrict__ out, int kpad, const float* __restrict__ scale,
+                                  int cout, float* __restrict__ scale_out) {
+  __shared__ unsigned red[4];
+  const int row = blockIdx.x, t = threadIdx.x;
+  const float* wr = w + (size_t)row * kpad;
+  unsigned m = 0;
+  for (int k = t; k < kpad; k += 256) m = max(m, __float_as_uint(fabsf(wr[k])));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((t & 63) == 0) red[t >> 6] = m;
+  __syncthreads();
+  m = max(max(red[0], red[1]), max(red[2], red[3]));
+  const float2 sc = f16_scales(m);
+  for (int k = t; k < kpad; k += 256) {
+    const int kt = k >> 5, kk = k & 31;
+    float r = wr[k] * sc.x;
+    const _Float16 h = (_Float16)r;
+    r -= (float)h;
+    const _Float16 l = (_Float16)r;
+    unsigned short* o = out + (((size_t)row * (kpad >> 5) + kt) * 2) * 32 + kk;
+    o[0] = __builtin_bit_cast(unsigned short, h);
+    o[32] = __builtin_bit_cast(unsigned short, l);
+  }
+  if (t == 0 && row < cout) scale_out[row] = (scale ? scale[row] : 1.f) * sc.y;
+}
+
+// ---- max|x| over an NHWC view (pixels x c floats, pixel stride ld; c, ld multiples of 4) -> atomicMax of the fp32 bit
+// patterns into *slot (zero before the launch); the launch also clears *next, the word the following launch will use
+__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ in, size_t items, int c4, int ld, unsigned* __restrict__ slot,
+                                                unsigned* __restrict__ next) {
+  __shared__ unsigned red[4];
+  const int t = threadIdx.x;
+  if (blockIdx.x == 0 && t == 0) *next = 0u;
+  unsigned m = 0;
+  const size_t stride = (size_t)gridDim.x * 256;
+  auto fold = [&](const float4 v) {
+    m = max(max(m, __float_as_uint(fabsf(v.x))), max(__float_as_uint(fabsf(v.y)), max(__float_as_uint(fabsf(v.z)), __float_as_uint(fabsf(v.w)))));
+  };
+  size_t i = (size_t)blockIdx.x * 256 + t;
+  if (ld == c4 * 4) {  // contiguous view
+    const float4* p = reinterpret_cast<const float4*>(in);
+    for (; i + 3 * stride < items; i += 4 * stride) {  // four loads in flight per thread
+      const float4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+      fold(a);
+      fold(b);
+      fold(c);
+      fold(d);
+    }
+    for (; i < items; i += stride) fold(p[i]);
+  } else {
+    for (; i < items; i += stride) {
+      const size_t pix = i / (unsigned)c4;
+      const int q = (int)(i - pix * (unsigned)c4);
+      fold(*reinterpret_cast<const float4*>(in + pix * ld + q * 4));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((t & 63) == 0) red[t >> 6] = m;
+  __syncthreads();
+  if (t == 0) atomicMax(slot, max(max(red[0], red[1]), max(red[2], red[3])));
+}
+
+// ---- per-model state
+class SplitCtx {
+ public:
+  struct Panels {
+    void* planes = nullptr;
+    float* scale = nullptr;  // fp16 form only: the epilogue's per-channel scale with the row's power of two taken back out
+  };
+  ~SplitCtx() {
+    for (void* q : allocs_) (void)hipFree(q);
+  }
+  // split copy of panel w for `code`, built on stream s the first time it is asked for
+  const Panels& panels(hipStream_t s, const ConvW& w, int code) {
+    const Key key{w.w, code};
+    auto it = cache_.find(key);
+    if (it != cache_.end()) return it->second;
+    const int ns = code == 3 ? 3 : 2;
+    const size_t rows = (size_t)((w.cout + 255) / 256 * 256), real = (size_t)((w.cout + 127) / 128 * 128), n = real * w.kpad;
+    Panels pn;
+    pn.planes = alloc(rows * w.kpad * ns * 2);  // rows padded to 256: the 256-wide tile reads whole tiles
+    YMK_HIP(hipMemsetAsync(pn.planes, 0, rows * w.kpad * ns * 2, s));
+    if (code == SPLIT_F16X2) {
+      pn.scale = reinterpret_cast<float*>(alloc(real * sizeof(float)));
+      hipLaunchKernelGGL(k_split_panel_f16, dim3((unsigned)real), dim3(256), 0, s, w.w, reinterpret_cast<unsigned short*>(pn.planes), w.kpad,
+                         w.scale, w.cout, pn.scale);
+    } else {
+      const int blocks = (int)((n + 255) / 256);
+      if (ns == 2) hipLaunchKernelGGL(k_split_panel<2>, dim3(blocks), dim3(256), 0, s, w.w, reinterpret_cast<unsigned short*>(pn.planes), n, w.kpad);
+      else hipLaunchKernelGGL(k_split_panel<3>, dim3(blocks), dim3(256), 0, s, w.w, reinterpret_cast<unsigned short*>(pn.planes), n, w.kpad);
+    }
+    YMK_HIP(hipGetLastError());
+    return cache_.emplace(key, pn).first->second;
+  }
+  // max|x| of the input view of launch k, on stream s; returns the device word the convolution kernel reads
+  const unsigned* absmax(hipStream_t s, const ConvK& k) {
+    if (!slots_) {
+      slots_ = reinterpret_cast<unsigned*>(alloc(2 * sizeof(unsigned)));
+      YMK_HIP(hipMemset(slots_, 0, 2 * sizeof(unsigned)));
+    }
+    // the two words alternate along ONE stream (each launch clears the other word for its successor); a context that
+    // moves to another stream waits for the old one first
+    if (have_stream_ && s != stream_) YMK_HIP(hipStreamSynchronize(stream_));
+    stream_ = s;
+    have_stream_ = true;
+    const size_t pixels = (size_t)(k.in_bytes / 4 - k.C) / k.in_ld + 1;
+    const size_t items = pixels * (size_t)(k.C / 4);
+    const int blocks = (int)std::min<size_t>(1024, (items + 1023) / 1024);
+    unsigned* cur = slots_ + parity_;
+    hipLaunchKernelGGL(k_absmax, dim3(blocks), dim3(256), 0, s, k.in, items, k.C / 4, k.in_ld, cur, slots_ + (parity_ ^ 1));
+    parity_ ^= 1;
+    return cur;
+  }
+
+ private:
+  struct Key {
+    const float* w;
+    int code;
+    bool operator==(const Key& o) const { return w == o.w && code == o.code; }
+  };
+  struct KeyHash {
+    size_t operator()(const Key& k) const { return std::hash<const void*>()(k.w) * 31 + (size_t)k.code; }
+  };
+  void* alloc(size_t bytes) {
+    void* q = nullptr;
+    YMK_HIP(hipMalloc(&q, bytes ? bytes : 4));
+    allocs_.push_back(q);
+    return q;
+  }
+  std::unordered_map<Key, Panels, KeyHash> cache_;
+  std::vector<void*> allocs_;
+  unsigned* slots_ = nullptr;
+  int parity_ = 0;
+  hipStream_t stream_ = nullptr;
+  bool have_stream_ = false;
+};
+
+SplitCtx* SplitCtxOwner::get() {
+  if (!p_) p_ = new SplitCtx();
+  return p_;
+}
+SplitCtxOwner::~SplitCtxOwner() { delete p_; }
+
+template <int FMT, int BM, int BN, int WM, int WN, int NS, int KS = 1, int PF = 1>
+static void launch_split(hipStream_t s, ConvK& k, const void* wsplit, SplitCtx* ctx = nullptr) {
+  if (KS > 1 && (k.Kpad >> 5) % KS != 0) {  // a stage holds KS whole K tiles: odd tile counts take the one-tile form
+    launch_split<FMT, BM, BN, WM, WN, NS, 1, PF>(s, k, wsplit, ctx);
+    return;
+  }
+  const int mt = (k.M + BM - 1) / BM, nt = (k.Cout + BN - 1) / BN;
+  k.ntiles_n = nt;
+  auto* e = conv_prof_open(s, k, BM, BN, mt * nt, (FMT ? 160 : 10 * NS));
+  if (FMT == 1) k.amax = ctx->absmax(s, k);  // inside the timed span: the pass is part of the layer's cost
+  hipLaunchKernelGGL((conv_igemm_split<BM, BN, WM, WN, NS, KS, PF, FMT>), dim3(mt * nt), dim3(64 * WM * WN), 0, s, k,
+                     reinterpret_cast<const uint4*>(wsplit));
+  if (e) YMK_HIP(hipEventRecord(e->second, s));
+}
+
+// tile shapes, ymk_debug_option("conv_split_tile", v): 0 = the measured best per format (profiles/
+// r03_conv_sweep_bf16_split*.txt); for A/B runs
+//   1 = 128 x 64, 8 waves          2 = 256 x 128, 16 waves        3 = 128 x 128, 16 waves        4 = 128 x 128, 8 waves
+//   5 = 128 x 128, 16 waves, 64-k stages              6 = the same, loads two stages ahead
+//   7 = 128 x 128, 8 waves, 64-k stages, two ahead    8 = 256 x 128, 16 waves, 32-k stages, two ahead
+//   9 = 128 x 128, 8 waves, 32-k stages, two ahead   10 = 128 x 128, 16 waves, 32-k stages, two ahead
+//   11 = 256 x 256, 16 waves (64 x 64 per wave), two planes
+//   12 / 13 / 14 = 128 x 128 x 16 waves / 256 x 128 x 16 waves / 128 x 128 x 8 waves with the stores threaded through the MFMAs
+// (bf16 only; the fp16 form keeps the shapes that won there: 0 / 3 = 128 x 128 x 16 waves, 1 = 128 x 64, 2 = 256 x 128, 11)
+static std::atomic<int> g_split_tile{0};
+bool conv_split_debug_option(const std::string& key, int value) {
+  if (key != "conv_split_tile") return false;
+  g_split_tile = value;
+  return true;
+}
+
+template <int NS>
+static void dispatch_bf16(hipStream_t s, ConvK& k, const void* ws, int tile, bool narrow) {
+  if (narrow) {
+    launch_split<0, 128, 64, 4, 2, NS>(s, k, ws);
+    return;
+  }
+  switch (tile) {
+    case 2: launch_split<0, 256, 128, 4, 4, NS>(s, k, ws); break;
+    case 4: launch_split<0, 128, 128, 4, 2, NS>(s, k, ws); break;
+    // 64-k stages of three planes do not fit the CU's LDS (205 KB): those selectors keep 32-k stages there
+    case 5: launch_split<0, 128, 128, 4, 4, NS, NS == 2 ? 2 : 1, 1>(s, k, ws); break;
+    case 6: launch_split<0, 128, 128, 4, 4, NS, NS == 2 ? 2 : 1, 2>(s, k, ws); break;
+    case 7: launch_split<0, 128, 128, 4, 2, NS, NS == 2 ? 2 : 1, 2>(s, k, ws); break;
+    case 8: launch_split<0, 256, 128, 4, 4, NS, 1, 2>(s, k, ws); break;
+    case 9: launch_split<0, 128, 128, 4, 2, NS, 1, 2>(s, k, ws); break;
+    case 10: launch_split<0, 128, 128, 4, 4, NS, 1, 2>(s, k, ws); break;
+    case 12: launch_split<0, 128, 128, 4, 4, NS, 1, 3>(s, k, ws); break;
+    case 13: launch_split<0, 256, 128, 4, 4, NS, 1, 3>(s, k, ws); break;
+    case 14: launch_split<0, 128, 128, 4, 2, NS, 1, 3>(s, k, ws); break;
+    case 11:  // 256 x 256, 16 waves of 64 x 64 (two planes only: three do not fit the LDS); Cout < 256 keeps 128-wide tiles
+      if (NS == 2 && k.Cout >= 256) launch_split<0, 256, 256, 4, 4, 2>(s, k, ws);
+      else launch_split<0, 128, 128, 4, 4, NS>(s, k, ws);
+      break;
+    default: launch_split<0, 128, 128, 4, 4, NS>(s, k, ws); break;
+  }
+}
+
+static void dispatch_f16(hipStream_t s, ConvK& k, const void* ws, int tile, bool narrow, SplitCtx* ctx) {
+  if (narrow) {
+    launch_split<1, 128, 64, 4, 2, 2>(s, k, ws, ctx);
+    return;
+  }
+  switch (tile) {
+    case 2: launch_split<1, 256, 128, 4, 4, 2>(s, k, ws, ctx); break;
+    case 4: launch_split<1, 128, 128, 4, 2, 2>(s, k, ws, ctx); break;
+    case 11:
+      if (k.Cout >= 256) launch_split<1, 256, 256, 4, 4, 2>(s, k, ws, ctx);
+      else launch_split<1, 128, 128, 4, 4, 2>(s, k, ws, ctx);
+      break;
+    default: launch_split<1, 128, 128, 4, 4, 2>(s, k, ws, ctx); break;
+  }
+}
+
+bool conv2d_split(hipStream_t s, ConvK& k, const ConvW& w, int code, SplitCtx* ctx) {
+  if (w.mode != 0 || ctx == nullptr || (code != 2 && code != 3 && code != SPLIT_F16X2)) return false;  // 4-channel stems keep the fp32 kernel
+  const long blocks128 = (long)((k.M + 127) / 128) * ((w.cout + 127) / 128);
+  if (blocks128 < 256) return false;  // grid-starved launches keep the fp32 paths (split-K / small tiles)
+  const SplitCtx::Panels& pn = ctx->panels(s, w, code);
+  int tile = g_split_tile.load(std::memory_order_relaxed);
+  if (tile == 0) tile = code == 3 ? 2 : 3;
+  const bool narrow = w.cout <= 64 || tile == 1;
+  if (code == SPLIT_F16X2) {
+    k.scale = pn.scale;
+    dispatch_f16(s, k, pn.planes, tile, narrow, ctx);
+  } else if (code == 2) {
+    dispatch_bf16<2>(s, k, pn.planes, tile, narrow);
+  } else {
+    dispatch_bf16<3>(s, k, pn.planes, tile, narrow);
+  }
+  YMK_HIP(hipGetLastError());
+  return true;
+}
+
+}  // namespace ymk

@@ -99,7 +99,7 @@ class DBNetModel : public Model {
   // x: device NCHW fp32 [n][3][h][w] (h, w multiples of 32); prob: device [n][1][h][w]
   void forward(const float* x_nchw, int n, int h, int w, float* prob, hipStream_t s) {
     YMK_CHECK(finalized, "model not finalized");
-    ConvSplitScope split_scope(conv_split());
+    ConvSplitScope split_scope(conv_split(), split_ctx.get());
     YMK_CHECK(n > 0 && h % 32 == 0 && w % 32 == 0 && h >= 32 && w >= 32, "dbnet input must be a multiple of 32");
     const uint64_t key = ((uint64_t)n << 40) | ((uint64_t)h << 20) | (uint64_t)w;
     if (key != shape_key_) {

@@ -199,7 +199,7 @@ class ParseqModel : public Model {
   // out_len[g] / ar_steps[g]: rows valid per sample / greedy steps of group g as its own loop would have run them.
   void forward_groups(const PGroup* groups, int ng, float* logits, int* out_len, int* ar_steps, hipStream_t s) {
     YMK_CHECK(finalized, "model not finalized");
-    ConvSplitScope split_scope(conv_split());
+    ConvSplitScope split_scope(conv_split(), split_ctx.get());
     YMK_CHECK(ng > 0, "parseq: no mini-batch");
     uint64_t key = 1469598103934665603ull;
     for (int g = 0; g < ng; ++g) {

@@ -70,7 +70,6 @@ class RtdetrModel : public Model {
     std::vector<float> panel;
     pack_conv_weight(k.data(), co, ci, 3, 3, false, panel, c.kpad, c.ctiles);
     c.w = pool.upload(panel);
-    make_split_panels(pool, c);
     c.bias = pool.upload(bias);
     return c;
   }
@@ -188,7 +187,7 @@ class RtdetrModel : public Model {
   // x: device fp32 [B][3][H][W]; logits: [B][nq][nc]; boxes: [B][nq][4] (cxcywh in [0,1])
   void forward(const float* x, int B, int H, int W, float* logits, float* boxes, hipStream_t s) {
     YMK_CHECK(finalized, "model not finalized");
-    ConvSplitScope split_scope(conv_split());
+    ConvSplitScope split_scope(conv_split(), split_ctx.get());
     YMK_CHECK(B > 0 && H % 32 == 0 && W % 32 == 0, "rtdetr input must be a multiple of 32");
     const int tok = (H / 8) * (W / 8) + (H / 16) * (W / 16) + (H / 32) * (W / 32);
     YMK_CHECK(tok == ntok_, "input size does not match the checkpoint's anchors (eval_spatial_size)");

@@ -93,7 +93,6 @@ ConvW make_conv(DevicePool& pool, const WeightStore& ws, const std::string& conv
   pack_conv_weight(w.data.data(), c.cout, c.cin, c.kh, c.kw, tap4, panel, c.kpad, c.ctiles);
   if (tap4) c.cin = 4;
   c.w = pool.upload(panel);
-  make_split_panels(pool, c);
   std::vector<float> scale, bias;
   const bool has_cb = ws.has(conv_prefix + ".bias");
   if (!bn_prefix.empty()) {
@@ -128,7 +127,6 @@ ConvW make_linear_raw(DevicePool& pool, const float* w_out_in, const float* bias
   std::vector<float> panel;
   pack_conv_weight(w_out_in, out, in, 1, 1, false, panel, c.kpad, c.ctiles);
   c.w = pool.upload(panel);
-  make_split_panels(pool, c);
   if (bias) c.bias = pool.upload(bias, out);
   return c;
 }

@@ -5,6 +5,7 @@ package (there is no fallback rasteriser)."""
 
 from __future__ import annotations
 
+import contextlib
 from pathlib import Path
 
 import numpy as np
@@ -41,31 +42,30 @@ def _check_path(path, want_pdf: bool) -> Path:
     return path
 
 
-def load_image(image_path: str):
-    """Open an image file -> list of BGR pages (one, or every frame of a multi-page TIFF), data/functions.py:33-79."""
+def _decode(path: Path):
+    """Pillow handle of an image file; anything Pillow cannot open is the reference's ValueError."""
     from PIL import Image
 
-    path = _check_path(image_path, want_pdf=False)
-    ext = path.suffix[1:].lower()
     try:
-        img = Image.open(path)
+        return Image.open(path)
     except Exception:
         raise ValueError("Invalid image data.")
-    pages = []
-    if ext in ("tif", "tiff"):
-        try:
-            while True:
-                arr = np.array(img.copy().convert("RGB"))
-                validate_image(arr)
-                pages.append(arr[:, :, ::-1])
-                img.seek(img.tell() + 1)
-        except EOFError:
-            pass
-    else:
-        arr = np.array(img.convert("RGB"))
-        validate_image(arr)
-        pages.append(arr[:, :, ::-1])
-    return pages
+
+
+def _page_from_frame(frame) -> np.ndarray:
+    rgb = np.array(frame.convert("RGB"))  # a writable copy, as the reference hands out
+    validate_image(rgb)
+    return rgb[:, :, ::-1]  # BGR view, as every module expects its input
+
+
+def load_image(image_path: str):
+    """Image file -> list of BGR pages: one, or every frame of a multi-page TIFF (contract of data/functions.py:33-79)."""
+    from PIL import ImageSequence
+
+    path = _check_path(image_path, want_pdf=False)
+    with _decode(path) as img:
+        multi_frame = path.suffix.lower() in (".tif", ".tiff")
+        return [_page_from_frame(f) for f in (ImageSequence.Iterator(img) if multi_frame else (img,))]
 
 
 def _pdfium():
@@ -78,59 +78,50 @@ def _pdfium():
 
 
 class PdfPageIterator:
-    """Lazy page-by-page rendering of a PDF (data/functions.py:82-160): len(), integer / slice indexing, iteration;
-    every page is rendered at `dpi` and returned as a BGR array."""
+    """Pages of a PDF rendered on demand, one at a time (contract of data/functions.py:82-160): len(), integer / slice
+    indexing, iteration; a page is rasterised at `dpi` and returned as a BGR array.  The document is opened per request and
+    closed when the request is served, so a thousand-page file never sits in memory."""
 
     def __init__(self, pdf_path, dpi: int = 200):
         self._pdf_path = Path(pdf_path)
-        self._dpi = dpi
-        pdfium = _pdfium()
-        try:
-            doc = pdfium.PdfDocument(self._pdf_path)
+        self._zoom = dpi / 72
+        _pdfium()
+        with self._document() as doc:
             self.total_pages = len(doc)
-            doc.close()
+
+    @contextlib.contextmanager
+    def _document(self):
+        try:
+            doc = _pdfium().PdfDocument(self._pdf_path)
         except Exception as e:
-            raise ValueError(f"Failed to open the PDF file: {pdf_path}") from e
+            raise ValueError(f"Failed to open the PDF file: {self._pdf_path}") from e
+        try:
+            yield doc
+        finally:
+            doc.close()
+
+    def _rasterise(self, numbers):
+        """Generator over the BGR rasters of the given page numbers (one open document for the whole request)."""
+        with self._document() as doc:
+            for i in numbers:
+                yield np.array(doc[i].render(scale=self._zoom).to_pil().convert("RGB"))[:, :, ::-1]
 
     def __len__(self):
         return self.total_pages
 
-    def _open(self):
-        try:
-            return _pdfium().PdfDocument(self._pdf_path)
-        except Exception as e:
-            raise ValueError(f"Failed to open the PDF file: {self._pdf_path}") from e
-
-    def _render_page(self, doc, index: int) -> np.ndarray:
-        bitmap = doc[index].render(scale=self._dpi / 72)
-        return np.array(bitmap.to_pil().convert("RGB"))[:, :, ::-1]
+    def __iter__(self):
+        return self._rasterise(range(self.total_pages))
 
     def __getitem__(self, index):
         if isinstance(index, slice):
-            doc = self._open()
-            try:
-                return [self._render_page(doc, i) for i in range(*index.indices(self.total_pages))]
-            finally:
-                doc.close()
-        if isinstance(index, int):
-            if index < 0:
-                index += self.total_pages
-            if not (0 <= index < self.total_pages):
-                raise IndexError(f"page index {index} out of range")
-            doc = self._open()
-            try:
-                return self._render_page(doc, index)
-            finally:
-                doc.close()
-        raise TypeError(f"indices must be integers or slices, not {type(index).__name__}")
-
-    def __iter__(self):
-        doc = self._open()
-        try:
-            for i in range(self.total_pages):
-                yield self._render_page(doc, i)
-        finally:
-            doc.close()
+            return list(self._rasterise(range(*index.indices(self.total_pages))))
+        if not isinstance(index, int):
+            raise TypeError(f"indices must be integers or slices, not {type(index).__name__}")
+        number = index + self.total_pages if index < 0 else index
+        if not 0 <= number < self.total_pages:
+            raise IndexError(f"page index {index} out of range")
+        (page,) = self._rasterise((number,))  # exhausted: the document is closed again
+        return page
 
 
 def load_pdf(pdf_path: str, dpi=200) -> PdfPageIterator:
