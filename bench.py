@@ -48,6 +48,39 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / f16 MFMA (v_mfma_f32_32x32x16_f16)
+# "conv_split" code (include/ymk.h) -> (16-bit MFMA products per fp32-grade product, dtype string of the bench line)
+SPLIT_MODES = {
+    0: (0, "f32 (v_mfma_f32_32x32x2_f32: exact fp32 products, an fmaf chain in k order)"),
+    16: (3, "f32 held as two scaled fp16 planes per operand on the MFMA pipe: 3 x v_mfma_f32_32x32x16_f16 per product tile (products to "
+            "2^-21, below the fp32 accumulation's own rounding), fp32 accumulate, fp32 activations in HBM; attention, LayerNorm, the "
+            "fused greedy step and every grid-starved launch exact fp32"),
+    2: (3, "f32 held as two bf16 planes per operand (products to 2^-15): 3 x v_mfma_f32_32x32x16_bf16 per product tile, fp32 accumulate"),
+    3: (6, "f32 held as three bf16 planes per operand (products to 2^-23): 6 x v_mfma_f32_32x32x16_bf16 per product tile, fp32 accumulate"),
+}
+
+
+def split_mode():
+    """The operand form the models of this process run with: YMK_CONV_SPLIT / YMK_DEBUG_OPTIONS if set, else the library's
+    default for models (SPLIT_MODEL_DEFAULT in ymk_common.h: 16)."""
+    v = os.environ.get("YMK_CONV_SPLIT")
+    for item in filter(None, os.environ.get("YMK_DEBUG_OPTIONS", "").split(",")):
+        k, _, val = item.partition("=")
+        if k.strip() == "conv_split":
+            v = val
+    v = 16 if v is None or int(v) < 0 else int(v)
+    return v if v in SPLIT_MODES else 0
+
+
+def kernel_source_sha():
+    """Hash of the convolution kernels' sources: stamps PMC-derived numbers kept under profiles/ (stale once a kernel changes)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("ymk_conv.hip", "ymk_conv_split.hip", "ymk_conv_kernel.h"):
+        with open(os.path.join(ROOT, "yomitoku_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 # YMK_BENCH_DRY=1: CPU rehearsal of the ORCHESTRATION only (ranks over gloo, helper processes, step barriers, the
 # max-over-ranks clock, teardown) with stub page workers from tests/bench_dry_stubs.py - what tests/test_bench_dry.py
@@ -256,7 +289,7 @@ REC_PRESETS = {  # --rec-model: (synth.parseq_state_dict kwargs, oracle preset n
 }
 
 
-def conv_roofline(lib, run_once, units, unit_name, kernel_desc, reps=3):
+def conv_roofline(lib, run_once, units, unit_name, kernel_desc, reps=3, split=None):
     """HIP events around every implicit-GEMM launch of one serial pass (`run_once`) -> the roofline dict.  The pass is
     repeated `reps` times and the MEDIAN pass (by total event time) is reported, with the spread next to it."""
     from yomitoku_amd import _lib
@@ -277,9 +310,17 @@ def conv_roofline(lib, run_once, units, unit_name, kernel_desc, reps=3):
     passes.sort()
     ms, fl, ln, alg = passes[len(passes) // 2]
     ach = fl / (ms * 1e-3) / 1e12
+    products = SPLIT_MODES[split if split is not None else split_mode()][0]
+    # the roof of the dominant kernel: exact fp32 MFMA, or the 16-bit MFMA rate over the MFMA products one fp32-grade product
+    # costs (algorithmic FLOPs = 2 M N K throughout: `achieved` is fp32-equivalent work per second)
+    peak = FP32_MFMA_PEAK_TFLOPS if products == 0 else F16_MFMA_PEAK_TFLOPS / products
     return {
-        "bound": "mfma", "kernel": kernel_desc, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        "bound": "mfma", "kernel": kernel_desc, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+        "frac": round(ach / peak, 4), "traffic": None,
+        "peak_note": ("dense fp32 MFMA" if products == 0 else
+                      f"dense 16-bit MFMA {F16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {products} MFMA products per fp32-grade product (fp32-equivalent "
+                      f"TFLOP/s); the same `achieved` is {ach / FP32_MFMA_PEAK_TFLOPS:.3f} of the exact-fp32 MFMA roof the round-3 line was priced against"),
+        "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
         "algorithmic_bytes_per_launch": int(alg // max(1, ln)),
         f"launches_per_{unit_name}": round(ln / units, 2), "avg_launch_us": round(ms * 1e3 / max(1, ln), 2),
         f"kernel_ms_per_{unit_name}": round(ms / units, 4), f"gflop_per_{unit_name}": round(fl / units / 1e9, 2),
@@ -424,30 +465,55 @@ def secondary_metrics(args, device, sds, pages):
     return out
 
 
-SPLIT_DTYPE = ("DBNet and RT-DETRv2 convolutions with fp32 operands cut into 2 bf16 planes (hi + lo), 3 v_mfma_f32_32x32x16_bf16 per "
-               "product tile, fp32 accumulation; PARSeq, attention and every grid-starved launch exact fp32")
+def timed_serve(args, an, host_pages, warm=16):
+    an.serve(host_pages[:warm], wave=args.wave, in_flight=args.in_flight)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = an.serve(host_pages, wave=args.wave, in_flight=args.in_flight)
+    torch.cuda.synchronize()
+    return res, time.perf_counter() - t0
 
 
-def split_metrics(args, an, host_pages):
-    """The SAME analyzer and pages with the opt-in bf16-split convolutions (ymk_conv_bf16.hip) on the detector and the two
-    RT-DETRv2 nets - the configuration profiles/r03_split_eval.json shows 20-34 x inside the 1e-3 tolerance with every
-    discrete output unchanged; the recogniser (6 x) stays exact.  One warm-up pass of 16 pages, one timed step."""
-    nets = (an.text_detector.model, an.layout.layout_parser.model, an.layout.table_structure_recognizer.model)
-    for n in nets:
-        n.set_conv_split(2)
+def analyzer_nets(an):
+    return (an.text_detector.model, an.text_recognizer.model, an.layout.layout_parser.model, an.layout.table_structure_recognizer.model)
+
+
+def exact_fp32_metrics(args, an, host_pages):
+    """The SAME analyzer and pages with every net on the exact fp32 MFMA kernels ("conv_split" 0) - the round-3 headline
+    configuration, kept as the yardstick next to the fp16-split default.  16 warm-up pages, one timed step."""
+    for n in analyzer_nets(an):
+        n.set_conv_split(0)
     try:
-        an.serve(host_pages[:16], wave=args.wave, in_flight=args.in_flight)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        res = an.serve(host_pages, wave=args.wave, in_flight=args.in_flight)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        res, dt = timed_serve(args, an, host_pages)
     finally:
-        for n in nets:
-            n.set_conv_split(0)
-    return {"value": round(len(host_pages) / dt, 2), "unit": "pages/s", "steps": 1, "pages": len(host_pages), "dtype": SPLIT_DTYPE,
-            "failed_pages": sum(isinstance(r, BaseException) for r in res),
-            "evidence": "profiles/r03_split_eval.json (errors vs the oracle / goldens / fp32 kernels), profiles/r03_conv_sweep_bf16_split.txt"}
+        for n in analyzer_nets(an):
+            n.set_conv_split(None)
+    return {"value": round(len(host_pages) / dt, 2), "unit": "pages/s", "steps": 1, "pages": len(host_pages), "dtype": SPLIT_MODES[0][1],
+            "failed_pages": sum(isinstance(r, BaseException) for r in res)}
+
+
+def unmodified_serve_metrics(args, device, sds, host_pages):
+    """`DocumentAnalyzer.serve` exactly as the product ships it - no ground-truth hand-overs: the calibrated seeded heads'
+    own detections flow from stage to stage, so the product's own _stage_boxes / _stage_tables / _stage_cells bodies are inside
+    the clock.  What the nets detect is noise (seeded weights), so the unit counts differ from the headline's; they are
+    reported next to the rate.  16 warm-up pages, one timed step."""
+    from yomitoku_amd import DocumentAnalyzer
+
+    an = DocumentAnalyzer(configs=MODEL_SETS[args.model_set], device=str(device))
+    try:
+        for net, key in zip(analyzer_nets(an), ("det", "rec", "lay", "tab")):
+            net.load_state_dict(sds[key])
+        res, dt = timed_serve(args, an, host_pages)
+    finally:
+        an.close()
+    ok = [r for r in res if not isinstance(r, BaseException)]
+    return {"value": round(len(host_pages) / dt, 2), "unit": "pages/s", "steps": 1, "pages": len(host_pages), "failed_pages": len(res) - len(ok),
+            "units_per_page": {"words": round(float(np.mean([len(r.words) for r in ok])), 1) if ok else None,
+                               "paragraphs": round(float(np.mean([len(r.paragraphs) for r in ok])), 1) if ok else None,
+                               "tables": round(float(np.mean([len(r.tables) for r in ok])), 2) if ok else None,
+                               "cells": round(float(np.mean([sum(len(t.cells) for t in r.tables) for r in ok])), 1) if ok else None},
+            "workload": "the unmodified product path: DocumentAnalyzer.serve(host pages) with the calibrated seeded checkpoints, every stage "
+                        "fed by the previous stage's own output"}
 
 
 def self_spawn(argv, n):
@@ -507,14 +573,6 @@ def main():
     lib = None if DRY else _lib.load()
     if lib is not None and os.environ.get("YMK_DEC_ROWS"):  # A/B knob of the fused greedy step (rows per block)
         _lib.debug_option("dec_rows", int(os.environ["YMK_DEC_ROWS"]))
-    # Launch-latency-bound host threads: a stage thread returning from a 50 us library call must not wait 5 ms (CPython's
-    # default switch interval) behind another stage's Python loop.  An application-level choice, made here.
-    sys.setswitchinterval(float(os.environ.get("YMK_SWITCH_INTERVAL", 2e-4)))
-    if not DRY and hasattr(os, "sched_setaffinity") and world > 1:
-        # one slice of the host cores per rank, so 8 ranks' stage threads do not migrate over each other
-        cores = sorted(os.sched_getaffinity(0))
-        per = max(1, len(cores) // world)
-        os.sched_setaffinity(0, set(cores[local_rank * per : (local_rank + 1) * per]))
 
     if args.workload == "recognizer":
         line = recognizer_workload(args, rank, local_rank, world, device, lib)
@@ -525,14 +583,23 @@ def main():
             torch.distributed.destroy_process_group()
         return
 
-    # ---- weights: drawn once on rank 0, ONE flat RCCL broadcast per checkpoint over xGMI; every rank then reports the CRC
-    # of what it received, so the line shows how many ranks the collective saw and that they hold rank 0's bytes
-    sds = make_checkpoints(args.model_set) if rank == 0 else {k: None for k in ("det", "rec", "lay", "tab")}
-    if rank == 0 and args.workload == "analyzer":
-        sds = calibrate_heads(sds, device, Page(0, device))
-    for k in ("det", "rec", "lay", "tab"):
-        sds[k] = ydist.broadcast_state_dict(sds[k], src=0, device=device)
-    rccl = ydist.replica_report(sds, device)
+    # ---- the sharded job (yomitoku_amd.distributed.ShardedServer): process group, this rank's core slice and thread budget,
+    # weights drawn once on rank 0 and broadcast as flat RCCL messages over xGMI, every rank's CRC of what it received, the
+    # rank's analyzer.  The timed region below is DocumentAnalyzer.serve on this rank's share, bracketed as the contract asks.
+    def rank0_checkpoints():
+        sds = make_checkpoints(args.model_set)
+        return calibrate_heads(sds, device, Page(0, device)) if args.workload == "analyzer" else sds
+
+    def make_analyzer(dev, sds, budget):
+        if args.workload != "analyzer":
+            return None
+        an = build_analyzer(dev, sds, args.model_set)
+        if getattr(an, "text_detector", None) is not None:
+            an.text_detector.post_threads = budget["box_threads"]
+        return an
+
+    server = ydist.ShardedServer(make_analyzer, rank0_checkpoints, backend="gloo" if DRY else None, device=device, pin_cores=not DRY)
+    sds, rccl, an = server.checkpoints, server.replicas, server.analyzer
 
     # ---- synthetic pages of this rank: HOST arrays for the analyzer (staging + H2D inside the clock)
     if args.workload == "detector":
@@ -545,11 +612,9 @@ def main():
         seeds = [1000 * rank + i for i in range(args.pages)]
     pages_job = args.total_pages if args.total_pages else args.pages * world
     pages = make_pages(seeds, device)
-    extra = {}
+    extra = {"host_threads": dict(server.budget, cores=server.cores)}
     failed = 0
-    an = None
     if args.workload == "analyzer":
-        an = build_analyzer(device, sds, args.model_set)
         an.truth = pages
         host_pages = [p.img for p in pages]
 
@@ -626,7 +691,9 @@ def main():
     # brackets that kernel alone.  `python bench.py --roofline-only` under rocprofv3 is the same pass (profiles/).
     roof = None
     if rank == 0 and not DRY:
-        kern = "conv_igemm / conv_splitk (fp32 MFMA implicit GEMM: every conv / linear layer of the four nets)"
+        kern = ("conv_igemm_split (fp16-split MFMA implicit GEMM: the chip-filling conv / linear launches of the four nets) + conv_igemm / "
+                "conv_splitk (exact fp32 MFMA: the stems and the grid-starved launches), max|x| passes included" if split_mode() else
+                "conv_igemm / conv_splitk (fp32 MFMA implicit GEMM: every conv / linear layer of the four nets)")
         if args.workload == "analyzer":
             an.concurrent_chains = False  # the two chains one after the other: an event pair brackets one kernel
             an.stats = {"det_boxes": [], "layout_boxes": [], "cells": []}
@@ -642,16 +709,16 @@ def main():
         else:
             prof_step, units = step, args.pages
         roof = conv_roofline(lib, prof_step, units, "page", kern)
-        pmc = os.path.join(ROOT, "profiles", f"r03_{args.workload}_pmc_conv_traffic.json")
-        if not os.path.exists(pmc):
-            pmc = os.path.join(ROOT, "profiles", f"r02_{args.workload}_pmc_conv_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", f"r04_{args.workload}_pmc_conv_traffic.json")
         if roof is not None and os.path.exists(pmc):
             # HBM bytes per conv launch from the PMC passes of this same serial pass (rocprofv3 cannot run inside bench.py:
-            # profiles/README.md has the commands); compare with algorithmic_bytes_per_launch
+            # profiles/README.md has the commands); compare with algorithmic_bytes_per_launch.  The file carries the hash of the
+            # kernel sources and the operand form it was measured with: anything else is stale and reported as null.
             with open(pmc) as f:
                 t = json.load(f)
-            roof["traffic"] = t["hbm_bytes_per_launch"]
-            roof["traffic_source"] = os.path.relpath(pmc, ROOT)
+            fresh = t.get("kernel_source_sha16") == kernel_source_sha() and int(t.get("conv_split", -1)) == split_mode()
+            roof["traffic"] = t["hbm_bytes_per_launch"] if fresh else None
+            roof["traffic_source"] = os.path.relpath(pmc, ROOT) + ("" if fresh else " (STALE: measured on other kernel sources / operand form)")
         if roof is not None and dt is not None:
             # the same FLOPs over the WALL clock of the timed region (all kernels, host gaps and overlap included)
             wall_tf = roof["gflop_per_page"] * 1e-3 * pages_job * args.steps / dt / max(1, world)
@@ -685,7 +752,8 @@ def main():
     if rank == 0 and world == 1 and args.workload == "analyzer" and not (DRY or args.roofline_only or args.no_secondary):
         # a failing secondary leg must not cost the run its headline line: the error is reported in its place
         secondary = {}
-        for name, leg in (("pages_per_s_bf16x2_split_det_layout_table", lambda: {"pages_per_s_bf16x2_split_det_layout_table": split_metrics(args, an, host_pages)}),
+        for name, leg in (("pages_per_s_exact_fp32", lambda: {"pages_per_s_exact_fp32": exact_fp32_metrics(args, an, host_pages)}),
+                          ("pages_per_s_unmodified_serve", lambda: {"pages_per_s_unmodified_serve": unmodified_serve_metrics(args, device, sds, host_pages)}),
                           ("recogniser_and_default_model_set", lambda: secondary_metrics(args, device, sds, pages))):
             try:
                 secondary.update(leg())
@@ -722,7 +790,7 @@ def main():
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": SPLIT_MODES[split_mode()][1],
             "data": "synthetic",
             "config": {"workload": workload, "pages_per_step_per_gpu": len(seeds) if args.total_pages else args.pages,
                        "parallelism": (f"page-sharded x{world} GPU(s), one process per GPU: DocumentAnalyzer.serve, waves of {args.wave} "
@@ -742,11 +810,7 @@ def main():
             line["dry_run"] = True
             line["metric"] = "DRY RUN - orchestration rehearsal with stub page workers, not a measurement"
         print(json.dumps(line), flush=True)
-    if an is not None:
-        an.close()
-    if world > 1:
-        torch.distributed.barrier()  # rank 0 is still in its roofline leg: the others wait here, not in teardown
-        torch.distributed.destroy_process_group()
+    server.close()  # the analyzer, then (after a barrier: rank 0 is still in its roofline leg while the others arrive) the group
 
 
 if DRY:  # stub page workers / pages / checkpoints for the CPU rehearsal (also in the spawned helper processes)

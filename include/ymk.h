@@ -40,10 +40,16 @@ int ymk_device_count(void);
  * then ymk_model_finalize() folds BatchNorm, repacks panels and uploads to `device`. */
 ymk_model* ymk_model_create(const char* kind, int device);
 void ymk_model_destroy(ymk_model* m);
-/* One parameter may also be set on a finalized model: "conv_split" = 0 (exact fp32 MFMA, the default), 2 or 3 (this
- * model's convolutions / linear layers that fill the chip run with their fp32 operands cut into 2 / 3 bf16 planes, fp32
- * accumulation: ymk_conv_bf16.hip), -1 (follow the process-wide ymk_debug_option).  parseq only: "conv_split_encoder" - the
- * same choice for the ViT blocks' linear layers alone (the decoder and the vocabulary head then follow "conv_split"). */
+/* One parameter may also be set on a finalized model: "conv_split" - how this model's convolutions / linear layers that fill
+ * the chip multiply (ymk_conv_split.hip; grid-starved launches, attention and the fused greedy step are exact fp32 always):
+ *   16  the default: fp32 operands scaled by powers of two and cut into two fp16 planes (11 + 11 significand bits), three
+ *       v_mfma_f32_32x32x16_f16 per product tile, fp32 accumulation - products good to 2^-21, below the fp32 accumulation's
+ *       own rounding for K >= 64 (measured: as far from the exact kernel as the exact kernel in another summation order)
+ *   0   exact fp32 MFMA (v_mfma_f32_32x32x2_f32, an fmaf chain in k order)
+ *   2 / 3   two / three bf16 planes, 3 / 6 MFMAs (2: products to 2^-15 only - evaluation)
+ *   -1  follow the process-wide ymk_debug_option("conv_split") if set, else the default.
+ * parseq only: "conv_split_encoder" - the same choice for the ViT blocks' linear layers alone (the decoder and the
+ * vocabulary head then follow "conv_split"). */
 int ymk_model_set_param(ymk_model* m, const char* key, double value);
 int ymk_model_set_tensor(ymk_model* m, const char* name, const float* host_data, int ndim, const int64_t* dims);
 int ymk_model_finalize(ymk_model* m);
@@ -151,18 +157,24 @@ int ymk_prof_begin(void);
  *   "conv_fast" (27)     bit 0: index shortcut of 1x1 / stride-1 layers, bit 1: residual rows fetched ahead, bit 3: K-tile rows of the
  *                        128 x 64 tile XOR-swizzled instead of padded (48 KB of LDS: three blocks per CU) and that tile for every
  *                        launch with K <= 512, bit 4: accumulators of ragged-Cout launches stored straight from registers;
- *                        bit 2: that direct epilogue for every plain store (A/B runs); bit 5: persistent tile loop for the swizzled
- *                        tile (ymk_conv_persist.hip: compiles, NOT yet run on hardware - off).  3 = the round-2 kernels.  Every setting
+ *                        bit 2: that direct epilogue for every plain store (A/B runs).  3 = the round-2 kernels.  Every setting
  *                        computes the same bits (tests/test_ops_gpu.py::test_conv_epilogue_variants_are_bit_identical).
  *   "dec_rows" (0)       samples per block of the fused greedy step: 0 = by row count, 1 / 2 / 4 forced (bit-identical results)
  *   "parseq_no_rowmax" (0)  1: the fused greedy loop writes every step's logits and arg-maxes them from memory (round-2 form);
  *                        0: the vocabulary head's epilogue reduces each 64-column tile to (max, column) and no AR logits exist
- *   "conv_split" (0)     2 / 3: convolutions that fill the chip run with their fp32 operands cut into 2 / 3 bf16 planes and
- *                        3 / 6 v_mfma_f32_32x32x16_bf16 per product tile, fp32 accumulation (ymk_conv_bf16.hip); 0 = exact fp32 MFMA.
- *                        Also set for a whole process by the environment variable YMK_CONV_SPLIT (yomitoku_amd/_lib.py).
- *   "conv_split_tile" (0) tile shape of that path for A/B runs: 0 = by plane count, 1 = 128 x 64, 2 = 256 x 128 (16 waves),
- *                        3 = 128 x 128 (16 waves), 4 = 128 x 128 (8 waves) */
+ *   "conv_split" (-1)    process-wide operand precision of every model whose own "conv_split" parameter is unset, and of
+ *                        ymk_op_conv2d: 0 = exact fp32 MFMA, 16 = two fp16 planes, 2 / 3 = bf16 planes (ymk_model_set_param above);
+ *                        -1 = unset: models run their default (16), ymk_op_conv2d exact fp32.  Also set for a whole process by
+ *                        the environment variable YMK_CONV_SPLIT (yomitoku_amd/_lib.py).
+ *   "conv_split_tile" (0) tile shape of that path for A/B runs: 0 = by format, 1 = 128 x 64, 2 = 256 x 128 (16 waves),
+ *                        3 = 128 x 128 (16 waves), 4 = 128 x 128 (8 waves), 11 = 256 x 256 (16 waves; two planes);
+ *                        5-10 / 12-14 (bf16 only): 64-k stages, loads two stages ahead, stores threaded through the MFMAs
+ *   "amax_check" (0)     1: every fp16-split launch whose input came with a max|x| record from its producer ALSO measures the
+ *                        input and compares (ymk_amax_check_counters) - the self-check of the record plumbing */
 int ymk_debug_option(const char* key, int value);
+/* out4 = {launches checked, records below the true max|x| (a bug), records more than 2^8 above it, largest record / truth
+ * exponent distance} since the process started; synchronises the device. */
+int ymk_amax_check_counters(int64_t* out4);
 int ymk_prof_end(double* conv_ms, double* conv_flop, int64_t* conv_launches);
 int ymk_prof_bytes(double* conv_bytes);
 

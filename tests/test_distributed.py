@@ -81,3 +81,86 @@ def test_shard_indices_cover_all_pages():
             assert seen == list(range(n))
             sizes = [len(shard_indices(n, r, world)) for r in range(world)]
             assert max(sizes) - min(sizes) <= 1
+
+
+class _StubAnalyzer:
+    """serve() contract of DocumentAnalyzer without a GPU: an entry per page (frame), exceptions in place."""
+
+    def __init__(self, device, checkpoints, budget):
+        self.bias = float(checkpoints["net"]["w"].sum())  # proves the broadcast reached make_analyzer
+        self.budget = budget
+        self.closed = False
+
+    def serve(self, sources, wave=8, in_flight=4, with_source=False, rec_lanes=2):
+        out = []
+        for si, src in enumerate(sources):
+            frames = src if isinstance(src, list) else [src]
+            for fi, frame in enumerate(frames):
+                entry = ValueError(f"bad page {frame}") if frame < 0 else (frame, self.bias, rec_lanes)
+                out.append((si, fi, entry) if with_source else entry)
+        return out
+
+    def close(self):
+        self.closed = True
+
+
+def _sharded_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from yomitoku_amd import distributed as yd
+
+    ck = (lambda: {"net": {"w": torch.arange(6, dtype=torch.float32)}}) if rank == 0 else None
+    # sources: plain pages, one multi-frame file (a list) and one failing page; 7 sources over 2 ranks
+    sources = [10, 11, [20, 21, 22], -1, 13, 14, 15]
+    server = yd.ShardedServer(_StubAnalyzer, ck, backend="gloo", device="cpu")
+    ok = server.analyzer.bias == 15.0 and server.replicas["ranks"] == world and server.replicas["weights_crc_equal"]
+    ok = ok and server.shard(len(sources)) == list(range(rank, 7, world))
+    ok = ok and server.budget["stage_threads"] == 9 and 1 <= server.budget["box_threads"] <= 4 and server.cores >= 1
+    res = server.run(sources, wave=2, in_flight=1)
+    if rank == 0:
+        lanes = server.budget["rec_lanes"]
+        ok = ok and [r if isinstance(r, tuple) else type(r).__name__ for r in res] == [
+            (10, 15.0, lanes), (11, 15.0, lanes), (20, 15.0, lanes), (21, 15.0, lanes), (22, 15.0, lanes), "ValueError", (13, 15.0, lanes),
+            (14, 15.0, lanes), (15, 15.0, lanes)]
+    else:
+        ok = ok and res is None
+    server.close()
+    ok = ok and server.analyzer.closed and not torch.distributed.is_initialized()
+    q.put((rank, bool(ok)))
+
+
+def test_sharded_server_world2():
+    """ShardedServer / serve_sharded: init -> core slice -> broadcast -> analyzer -> shard by source -> serve -> ordered gather
+    with a failing page and a multi-frame source, two gloo ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == {0: True, 1: True}
+
+
+def test_serve_sharded_single_process():
+    from yomitoku_amd import distributed as yd
+
+    env = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
+    try:
+        res = yd.serve_sharded([1, 2, [3, 4]], _StubAnalyzer, {"net": {"w": torch.ones(3)}}, backend="gloo", wave=4)
+    finally:
+        for k, v in env.items():
+            if v is not None:
+                os.environ[k] = v
+    assert [r[0] for r in res] == [1, 2, 3, 4] and res[0][1] == 3.0
+
+
+def test_thread_budget_follows_the_core_slice():
+    from yomitoku_amd.distributed import thread_budget
+
+    assert thread_budget(128) == {"stage_threads": 9, "box_threads": 4, "rec_lanes": 2}
+    assert thread_budget(16) == {"stage_threads": 9, "box_threads": 4, "rec_lanes": 2}   # 8 ranks on a 128-core host
+    assert thread_budget(6) == {"stage_threads": 9, "box_threads": 1, "rec_lanes": 1}

@@ -115,36 +115,6 @@ def test_conv_epilogue_variants_are_bit_identical(dev, case, epilogue):
             _lib.debug_option(key, val)
 
 
-@pytest.mark.skipif(os.environ.get("YMK_EXPERIMENTAL") != "1",
-                    reason="conv_igemm_persist (conv_fast bit 5) was written after the round's GPU budget was spent: opt-in, "
-                           "run with YMK_EXPERIMENTAL=1 (tools/jobs/r04_persistent.sh) before anything routes to it")
-@pytest.mark.parametrize("case", [(1, 64, 1, 200000, 64, 1, 1, 0, 1), (1, 192, 1, 50000, 256, 1, 1, 0, 1), (8, 64, 160, 160, 64, 3, 1, 1, 1),
-                                  (2, 256, 320, 320, 64, 3, 1, 1, 1), (1, 192, 1, 70001, 576, 1, 1, 0, 1)])
-def test_persistent_tile_loop_is_bit_identical(dev, case):
-    """The persistent tile loop (a block walks a sequence of 128 x 64 tiles, the next tile's first loads issued before this
-    tile's epilogue) against the one-tile-per-block kernel: same K order, same epilogue - every output bit."""
-    from yomitoku_amd import _lib
-    from tests import hipops
-
-    n, cin, h, w, cout, k, stride, pad, dil = case
-    g = torch.Generator().manual_seed(13)
-    x = torch.randn(n, cin, h, w, generator=g).to(dev)
-    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
-    scale, bias = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
-    oh, ow = (h + 2 * pad - dil * (k - 1) - 1) // stride + 1, (w + 2 * pad - dil * (k - 1) - 1) // stride + 1
-    res = torch.randn(n, cout, oh, ow, generator=g).to(dev)
-    configs = [(None, None, None, "none"), (scale, bias, res, "relu"), (scale, None, None, "gelu")]
-    try:
-        want = [hipops.conv2d(x, wt, sc, bi, rs, stride, pad, dil, act) for sc, bi, rs, act in configs]
-        _lib.debug_option("conv_fast", _lib.CONV_FAST_DEFAULT | 32)
-        got = [hipops.conv2d(x, wt, sc, bi, rs, stride, pad, dil, act) for sc, bi, rs, act in configs]
-        for a, b in zip(want, got):
-            assert torch.equal(a, b), float((a - b).abs().max())
-    finally:
-        for key, val in RESET:
-            _lib.debug_option(key, val)
-
-
 def _conv_case(dev, case, hipops):
     n, cin, h, w, cout, k, stride, pad, dil = case
     g = torch.Generator().manual_seed(hash(case) % (2**31))

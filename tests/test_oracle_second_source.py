@@ -381,3 +381,148 @@ def test_vit_restatement_parameter_count_and_block_vs_transformers():
         out = out[0] if isinstance(out, tuple) else out
         ref = blk(x)
     assert (out - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+
+
+def _hf_vit_layer(tr, D, heads, blk_sd):
+    """A transformers ViTLayer (pre-LN, eps 1e-6, exact GELU, separate q / k / v) carrying one timm-named block."""
+    from transformers.models.vit.modeling_vit import ViTLayer
+
+    cfg = tr.ViTConfig(hidden_size=D, num_attention_heads=heads, intermediate_size=4 * D, hidden_act="gelu", layer_norm_eps=1e-6,
+                       qkv_bias=True, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    try:
+        cfg._attn_implementation = "eager"
+    except Exception:
+        pass
+    layer = ViTLayer(cfg).eval()
+    q, k, v = blk_sd["attn.qkv.weight"].chunk(3, 0)
+    qb, kb, vb = blk_sd["attn.qkv.bias"].chunk(3, 0)
+    if "attention.q_proj.weight" in set(layer.state_dict()):  # transformers >= 5 naming
+        a = {"q": "attention.q_proj", "k": "attention.k_proj", "v": "attention.v_proj", "o": "attention.o_proj", "fc1": "mlp.fc1", "fc2": "mlp.fc2"}
+    else:
+        a = {"q": "attention.attention.query", "k": "attention.attention.key", "v": "attention.attention.value",
+             "o": "attention.output.dense", "fc1": "intermediate.dense", "fc2": "output.dense"}
+    mapped = {"layernorm_before.weight": blk_sd["norm1.weight"], "layernorm_before.bias": blk_sd["norm1.bias"],
+              "layernorm_after.weight": blk_sd["norm2.weight"], "layernorm_after.bias": blk_sd["norm2.bias"],
+              a["q"] + ".weight": q, a["q"] + ".bias": qb, a["k"] + ".weight": k, a["k"] + ".bias": kb, a["v"] + ".weight": v, a["v"] + ".bias": vb,
+              a["o"] + ".weight": blk_sd["attn.proj.weight"], a["o"] + ".bias": blk_sd["attn.proj.bias"],
+              a["fc1"] + ".weight": blk_sd["mlp.fc1.weight"], a["fc1"] + ".bias": blk_sd["mlp.fc1.bias"],
+              a["fc2"] + ".weight": blk_sd["mlp.fc2.weight"], a["fc2"] + ".bias": blk_sd["mlp.fc2.bias"]}
+    missing, unexpected = layer.load_state_dict(mapped, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    return layer
+
+
+@pytest.mark.parametrize("geometry", [dict(D=192, heads=6, patch=(4, 8), depth=12, W=216),   # parseq-tiny-dynw-v4, a narrow mini-batch
+                                      dict(D=192, heads=6, patch=(4, 8), depth=12, W=800),   # ... the full canvas
+                                      dict(D=256, heads=4, patch=(8, 8), depth=3, W=344)])   # 8 x 8 patches (parseq / parseq-large)
+def test_vit_encoder_whole_depth_and_dynamic_width_vs_transformers_chain(geometry):
+    """oracle.parseq.vit_encode - the CPU reference of every PARSeq encoder test - against a chain that shares no code with
+    it: patches cut with Tensor.unfold and projected by a plain matmul, the learned position table indexed token by token
+    from (row, column) of the FULL grid (parseq_transformer.py:220-227: a narrow input keeps the columns it has), `depth`
+    transformers ViTLayers, torch.nn.LayerNorm(eps 1e-6) at the end.  Proves the whole-depth wiring, the final norm and the
+    cropped position rows - what the one-block check above cannot."""
+    tr = pytest.importorskip("transformers")
+    from oracle.parseq import make_cfg, vit_encode
+
+    D, heads, (ph, pw), depth, W = geometry["D"], geometry["heads"], geometry["patch"], geometry["depth"], geometry["W"]
+    g = torch.Generator().manual_seed(41)
+    full_gh, full_gw = 32 // ph, 800 // pw
+    sd = {"encoder.patch_embed.proj.weight": torch.randn(D, 3, ph, pw, generator=g) * 0.1, "encoder.patch_embed.proj.bias": torch.randn(D, generator=g) * 0.1,
+          "encoder.pos_embed": torch.randn(1, full_gh * full_gw, D, generator=g) * 0.5,
+          "encoder.norm.weight": torch.rand(D, generator=g) + 0.5, "encoder.norm.bias": torch.randn(D, generator=g) * 0.1}
+    for i in range(depth):
+        p = f"encoder.blocks.{i}."
+        for name, shape, std in (("attn.qkv.weight", (3 * D, D), D ** -0.5), ("attn.proj.weight", (D, D), D ** -0.5),
+                                 ("mlp.fc1.weight", (4 * D, D), D ** -0.5), ("mlp.fc2.weight", (D, 4 * D), (4 * D) ** -0.5)):
+            sd[p + name] = torch.randn(shape, generator=g) * std
+            sd[p + name.replace("weight", "bias")] = torch.randn(shape[0], generator=g) * 0.05
+        for n in ("norm1", "norm2"):
+            sd[p + n + ".weight"] = torch.rand(D, generator=g) + 0.5
+            sd[p + n + ".bias"] = torch.randn(D, generator=g) * 0.1
+    cfg = make_cfg(patch=(ph, pw), enc_dim=D, enc_heads=heads, enc_depth=depth)
+    x = torch.randn(2, 3, 32, W, generator=g)
+    with torch.no_grad():
+        got = vit_encode(sd, cfg, x)
+        gh, gw = 32 // ph, W // pw
+        patches = x.unfold(2, ph, ph).unfold(3, pw, pw)                      # B, 3, gh, gw, ph, pw
+        patches = patches.permute(0, 2, 3, 1, 4, 5).reshape(2, gh * gw, 3 * ph * pw)
+        t = patches @ sd["encoder.patch_embed.proj.weight"].reshape(D, -1).T + sd["encoder.patch_embed.proj.bias"]
+        rows = torch.tensor([r * full_gw + c for r in range(gh) for c in range(gw)])
+        t = t + sd["encoder.pos_embed"][0, rows]
+        for i in range(depth):
+            p = f"encoder.blocks.{i}."
+            out = _hf_vit_layer(tr, D, heads, {k[len(p):]: v for k, v in sd.items() if k.startswith(p)})(t)
+            t = out[0] if isinstance(out, tuple) else out
+        ln = torch.nn.LayerNorm(D, eps=1e-6)
+        ln.weight.data, ln.bias.data = sd["encoder.norm.weight"], sd["encoder.norm.bias"]
+        want = ln(t)
+    assert got.shape == want.shape == (2, gh * gw, D)
+    assert (got - want).abs().max().item() < 2e-4 * max(1.0, want.abs().max().item())
+
+
+def test_dilated_layer4_vs_functional_composition_from_the_torchvision_spec():
+    """torchvision.models.resnet50(replace_stride_with_dilation=[False, False, True]) (models/dbnet_plus.py:33-37), layer4
+    as its _make_layer(dilate=True) builds it: the stride of 2 becomes a dilation - block 0 keeps dilation 1 (the
+    `previous_dilation`) with stride 1 in its 3 x 3 AND in its 1 x 1 projection shortcut, blocks 1-2 run their 3 x 3 at
+    dilation 2 / padding 2; Bottleneck v1.5 = conv1x1-BN-ReLU, conv3x3-BN-ReLU, conv1x1-BN, + identity, ReLU; eval BatchNorm
+    eps 1e-5.  Composed here from F.conv2d and the BatchNorm formula only (no oracle/_refstubs, no oracle/dbnet code),
+    started from layer3 features of transformers' independent ResNet, and compared with oracle.dbnet.resnet50_dilated_features."""
+    tr = pytest.importorskip("transformers")
+    from oracle._refstubs import _ResNet50
+    from oracle.dbnet import resnet50_dilated_features
+
+    g = torch.Generator().manual_seed(43)
+    names = [(k, v.shape) for k, v in _ResNet50([False, False, True]).state_dict().items() if v.dtype.is_floating_point]
+    sd = {}
+    for k, shape in names:  # names and shapes are the published torchvision ones (checked against the parameter count above)
+        if k.endswith("running_var"):
+            sd[k] = torch.rand(shape, generator=g) + 0.5
+        elif k.endswith("running_mean") or k.endswith("bias"):
+            sd[k] = torch.randn(shape, generator=g) * 0.1
+        elif len(shape) == 4:
+            sd[k] = torch.randn(shape, generator=g) * (2.0 / (shape[1] * shape[2] * shape[3])) ** 0.5
+        else:
+            sd[k] = torch.rand(shape, generator=g) + 0.5
+    x = torch.randn(1, 3, 96, 160, generator=g)
+    with torch.no_grad():
+        feats = resnet50_dilated_features({"backbone.body." + k: v for k, v in sd.items()}, x)
+
+        # layers 1-3 from the independent implementation
+        cfg = tr.ResNetConfig(num_channels=3, embedding_size=64, hidden_sizes=[256, 512, 1024, 2048], depths=[3, 4, 6, 3],
+                              layer_type="bottleneck", hidden_act="relu", downsample_in_first_stage=False)
+        hf = tr.ResNetModel(cfg).eval()
+        dst = {}
+
+        def put(d_prefix, s_conv, s_bn):
+            dst[d_prefix + ".convolution.weight"] = sd[s_conv + ".weight"]
+            for k in ("weight", "bias", "running_mean", "running_var"):
+                dst[d_prefix + ".normalization." + k] = sd[s_bn + "." + k]
+
+        put("embedder.embedder", "conv1", "bn1")
+        for s, depth in enumerate([3, 4, 6, 3]):
+            for b in range(depth):
+                p, q = f"encoder.stages.{s}.layers.{b}", f"layer{s + 1}.{b}"
+                for j in range(3):
+                    put(f"{p}.layer.{j}", f"{q}.conv{j + 1}", f"{q}.bn{j + 1}")
+                if b == 0:
+                    put(f"{p}.shortcut", f"{q}.downsample.0", f"{q}.downsample.1")
+        missing, unexpected = hf.load_state_dict(dst, strict=False)
+        assert not unexpected and not [m for m in missing if "num_batches" not in m]
+        hidden = hf(x, output_hidden_states=True).hidden_states
+        assert (feats[2] - hidden[3]).abs().max().item() < 1e-4 * max(1.0, hidden[3].abs().max().item())
+
+        def bn(t, p):
+            shape = (1, -1, 1, 1)
+            return (t - sd[p + ".running_mean"].view(shape)) / torch.sqrt(sd[p + ".running_var"].view(shape) + 1e-5) * sd[p + ".weight"].view(shape) \
+                + sd[p + ".bias"].view(shape)
+
+        t = hidden[3]  # layer3 output, 1024 channels at H/16
+        for b, dil in enumerate((1, 2, 2)):
+            p = f"layer4.{b}"
+            y = torch.relu(bn(torch.nn.functional.conv2d(t, sd[p + ".conv1.weight"]), p + ".bn1"))
+            y = torch.relu(bn(torch.nn.functional.conv2d(y, sd[p + ".conv2.weight"], stride=1, padding=dil, dilation=dil), p + ".bn2"))
+            y = bn(torch.nn.functional.conv2d(y, sd[p + ".conv3.weight"]), p + ".bn3")
+            idn = bn(torch.nn.functional.conv2d(t, sd[p + ".downsample.0.weight"], stride=1), p + ".downsample.1") if b == 0 else t
+            t = torch.relu(y + idn)
+    assert feats[3].shape == t.shape == (1, 2048, 6, 10)  # H/16: the stride was replaced, the resolution kept
+    assert (feats[3] - t).abs().max().item() < 1e-4 * max(1.0, t.abs().max().item())

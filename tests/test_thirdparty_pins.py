@@ -1,10 +1,15 @@
-"""The oracle's restatements of cv2 / pyclipper / torchvision / timm against the libraries' OWN outputs, stored by
-`python -m oracle.pin_third_party` on a machine that has them (they are not installable in the
-build container).  Every test SKIPS - loudly - while its file is absent; with the files present this is what turns
-"parity unpinned" into "pinned" for INTER_AREA, warpPerspective, findContours order, minAreaRect, fillPoly + mean,
-Clipper's round offset, the dilated ResNet-50 and the timm ViT."""
+"""The oracle's restatements of cv2 / pyclipper / torchvision / timm against the libraries' OWN outputs (SURVEY.md
+section 8(c)).  The outputs come from `oracle/pin_third_party.py`: either stored under tests/golden/ by
+`python -m oracle.pin_third_party` on a machine that has the packages, or - when a package imports in the process that
+runs the tests - generated on the spot into a temporary directory.  The packages are not installable in the build
+container, so every comparison runs TWICE: once in the CPU suite and once, marked `gpu`, on the GPU box, whose image the
+builder has never seen: one free attempt per driver run.  A test SKIPS - loudly, naming the import that failed - while
+neither source exists; with either this is what turns "parity unpinned" into "pinned" for INTER_AREA, warpPerspective,
+findContours order, minAreaRect, fillPoly + mean, Clipper's round offset, the dilated ResNet-50 and the timm ViT."""
+import importlib
 import os
 import sys
+import tempfile
 
 import numpy as np
 import pytest
@@ -12,14 +17,34 @@ import pytest
 from oracle import pin_third_party as pin
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
+NEEDS = {"cv2": ("cv2",), "pyclipper": ("pyclipper", "shapely"), "torchvision": ("torchvision",), "timm": ("timm",)}
+_generated = {}
+
+
+@pytest.fixture(autouse=True, params=["cpu_suite", pytest.param("gpu_box", marks=pytest.mark.gpu)])
+def where(request):
+    """Every test of this file exists in both suites (`-m "not gpu"` here, `-m gpu` on the driver's box)."""
+    return request.param
 
 
 def _load(lib):
     path = os.path.join(GOLD, f"thirdparty_{lib}.npz")
-    if not os.path.exists(path):
-        pytest.skip(f"{os.path.relpath(path)} not generated: run `python -m oracle.pin_third_party` where {lib} is installed - "
-                    f"until then the oracle's {lib} restatement is NOT pinned against the library (parity partial)")
-    return np.load(path, allow_pickle=False)
+    if os.path.exists(path):
+        return np.load(path, allow_pickle=False)
+    if lib not in _generated:
+        try:
+            for module in NEEDS[lib]:
+                importlib.import_module(module)
+        except ImportError as exc:
+            _generated[lib] = exc
+        else:
+            out_dir = tempfile.mkdtemp(prefix="ymk_pins_")
+            getattr(pin, f"pin_{lib}")(out_dir)
+            _generated[lib] = os.path.join(out_dir, f"thirdparty_{lib}.npz")
+    if isinstance(_generated[lib], Exception):
+        pytest.skip(f"{os.path.relpath(path)} absent and {lib} cannot be pinned in this process ({type(_generated[lib]).__name__}: "
+                    f"{_generated[lib]}): the oracle's {lib} restatement is NOT pinned against the library here (parity partial)")
+    return np.load(_generated[lib], allow_pickle=False)
 
 
 def test_pin_script_inputs_are_deterministic():

@@ -57,6 +57,7 @@ SIGNATURES = {
     ),
     "ymk_table_hole_rects": (c_int, [c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, POINTER(c_int)]),
     "ymk_debug_option": (c_int, [c_char_p, c_int]),
+    "ymk_amax_check_counters": (c_int, [POINTER(c_int64)]),
     "ymk_prof_begin": (c_int, []),
     "ymk_prof_end": (c_int, [POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
     "ymk_prof_bytes": (c_int, [POINTER(c_double)]),
@@ -125,6 +126,16 @@ CONV_FAST_DEFAULT = 27  # ymk_debug_option("conv_fast"): the library's default b
 def debug_option(key: str, value: int):
     """Test / measurement knob of the library (include/ymk.h: ymk_debug_option)."""
     check(load().ymk_debug_option(key.encode(), int(value)), f"ymk_debug_option({key})")
+
+
+def amax_check_counters():
+    """(launches checked, records below the true max|x|, records > 2^8 above it, largest exponent distance) of the
+    ymk_debug_option("amax_check", 1) self-check (include/ymk.h)."""
+    import ctypes
+
+    out = (ctypes.c_int64 * 4)()
+    check(load().ymk_amax_check_counters(out), "ymk_amax_check_counters")
+    return tuple(int(v) for v in out)
 
 
 def ptr(t):

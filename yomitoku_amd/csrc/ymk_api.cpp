@@ -21,6 +21,7 @@ bool conv_debug_option(const std::string& key, int value);
 bool parseq_debug_option(const std::string& key, int value);
 bool decstep_debug_option(const std::string& key, int value);
 bool conv_split_debug_option(const std::string& key, int value);
+void amax_check_counters(long long* out4);
 }  // namespace ymk
 
 struct ymk_model {
@@ -174,6 +175,15 @@ int ymk_debug_option(const char* key, int value) {
   YMK_API_END
 }
 
+int ymk_amax_check_counters(int64_t* out4) {
+  YMK_API_BEGIN
+  YMK_CHECK(out4 != nullptr, "null argument");
+  long long v[4];
+  ymk::amax_check_counters(v);
+  for (int i = 0; i < 4; ++i) out4[i] = v[i];
+  YMK_API_END
+}
+
 int ymk_prof_begin(void) {
   YMK_API_BEGIN
   ymk::prof_begin();
@@ -223,7 +233,7 @@ int ymk_op_conv2d(const float* x_dev, int n, int h, int w, int c, const float* w
   a.act = act;
   a.res = res_dev ? &res : nullptr;
   SplitCtxOwner split_ctx;  // split copies of this call's panel live and die with it
-  ConvSplitScope scope(-1, split_ctx.get());
+  ConvSplitScope scope(-1, split_ctx.get(), 0);  // single operators: exact fp32 unless the process-wide option says otherwise
   conv2d((hipStream_t)stream, in, cw, a, out);
   YMK_HIP(hipStreamSynchronize((hipStream_t)stream));  // pool frees the panel on return
   YMK_API_END

@@ -39,11 +39,22 @@ struct Error : public std::runtime_error {
     if (!(cond)) throw ::ymk::Error(std::string("check failed: ") + #cond + ": " + (msg)); \
   } while (0)
 
+// ---------------------------------------------------------------- max|x| records
+// The fp16-split convolutions scale their input by a power of two taken from max|x| over the whole input view
+// (ymk_conv_split.hip).  A producer that writes a tensor can leave that maximum behind for free: an "amax record" is 32
+// words on 32 separate 128-byte lines (so that the atomicMax of thousands of waves do not queue on one address), zeroed at
+// the start of the forward; every wave of the producing kernel folds |v| of what it stores into word (its wave number mod
+// 32), the consumer reads the 32 words and takes their maximum.  A tensor without a record (`amax == nullptr`) costs the
+// consumer a pass over its input (k_absmax).  Only kernels that write the WHOLE tensor fill a record, and a tensor that is
+// modified in place afterwards must drop it (set amax = nullptr).
+constexpr int AMAX_LINES = 32, AMAX_LINE_WORDS = 32, AMAX_REC_WORDS = AMAX_LINES * AMAX_LINE_WORDS;
+
 // ---------------------------------------------------------------- tensors
 struct Tensor {
   float* p = nullptr;
   int n = 0, h = 0, w = 0, c = 0;
   int ld = 0;  // floats between consecutive pixels (>= c)
+  unsigned* amax = nullptr;  // record of max|x| over the tensor, filled by its producer (see above), or null
   size_t pixels() const { return (size_t)n * h * w; }
   Tensor slice_c(int c0, int cn) const {
     Tensor t = *this;
@@ -66,10 +77,36 @@ class Arena {
   size_t high_water() const { return high_; }
   size_t capacity() const { return cap_; }
   bool dry_run = false;  // when true only measures (returns fake pointers)
+  // max|x| records of this forward: `records` of them carved from the arena and zeroed on stream s (call once, right
+  // after reset()); amax_next() hands them out, null once they are used up (the consumer then makes its own pass)
+  void amax_begin(hipStream_t s, int records);
+  unsigned* amax_next();
  private:
   char* base_ = nullptr;
   size_t cap_ = 0, off_ = 0, high_ = 0;
+  unsigned* amax_pool_ = nullptr;
+  int amax_n_ = 0, amax_used_ = 0;
 };
+
+// device side of the records
+__device__ __forceinline__ void amax_fold(unsigned& am, float v) { am = max(am, __float_as_uint(fabsf(v))); }
+__device__ __forceinline__ void amax_fold4(unsigned& am, const float4 v) {
+  am = max(max(am, __float_as_uint(fabsf(v.x))), max(__float_as_uint(fabsf(v.y)), max(__float_as_uint(fabsf(v.z)), __float_as_uint(fabsf(v.w)))));
+}
+// all 64 lanes of a wave call it (t = thread index in the block): one atomicMax per wave, on the wave's line of the record
+__device__ __forceinline__ void amax_commit(unsigned* rec, unsigned am, int t) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, o));
+  if ((t & 63) == 0 && am != 0u)
+    atomicMax(rec + ((blockIdx.x * (blockDim.x >> 6) + (t >> 6)) & (AMAX_LINES - 1)) * AMAX_LINE_WORDS, am);
+}
+// the record's maximum, in every lane
+__device__ __forceinline__ unsigned amax_read(const unsigned* rec, int lane) {
+  unsigned m = rec[(lane & (AMAX_LINES - 1)) * AMAX_LINE_WORDS];
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  return m;
+}
 
 // ---------------------------------------------------------------- activations
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_SIGMOID = 3, ACT_GELU = 4 };
@@ -103,6 +140,9 @@ struct ConvArgs {
   // all of whose rows sit in groups with group_open[g] == 0 is not computed (its outputs keep their old contents)
   const int* row_group = nullptr;
   const int* group_open = nullptr;
+  // max|x| records for callers without Tensor objects (gemm): of the input (filled by its producer) / to fill for the output
+  const unsigned* amax_in = nullptr;
+  unsigned* amax_out = nullptr;
 };
 
 // Split-operand convolutions (ymk_conv_split.hip).  "conv_split" codes: 0 = exact fp32 MFMA; 2 / 3 = operands cut into
@@ -119,15 +159,19 @@ struct SplitCtxOwner {
  private:
   SplitCtx* p_ = nullptr;
 };
+// The models' default: what a forward runs with when neither its "conv_split" parameter nor the process-wide
+// ymk_debug_option("conv_split") / YMK_CONV_SPLIT says otherwise (round 4: the fp16 split; 0 selects the exact fp32 kernels)
+constexpr int SPLIT_MODEL_DEFAULT = SPLIT_F16X2;
 // Operand precision of the calling thread's conv2d / gemm launches while the scope lives.  A model's forward opens one with
-// its "conv_split" parameter and its SplitCtx; a nested scope without a context keeps the enclosing one; split < 0 follows
-// the process-wide ymk_debug_option("conv_split").  Without a context the split path is not taken.
+// its "conv_split" parameter, its SplitCtx and SPLIT_MODEL_DEFAULT; a nested scope without a context / default keeps the
+// enclosing ones.  Resolution per launch: the scope's split if >= 0, else the process-wide option if set (>= 0), else the
+// scope's default (0 outside every scope).  Without a context the split path is not taken.
 class ConvSplitScope {
  public:
-  explicit ConvSplitScope(int split, SplitCtx* ctx = nullptr);
+  explicit ConvSplitScope(int split, SplitCtx* ctx = nullptr, int dflt = -1);
   ~ConvSplitScope();
  private:
-  int prev_;
+  int prev_, prev_dflt_;
   SplitCtx* prev_ctx_;
 };
 
@@ -137,7 +181,8 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
 // Row-major GEMM view of the same kernel: out[m][:] = act(A[m][:] . W^T * scale + bias + res[m][:]).
 // `res_ld == 0` broadcasts one residual row to every m.
 void gemm(hipStream_t s, const float* A, int M, int K, int lda, const ConvW& w, int act, const float* res, int res_ld,
-          float* out, int out_ld, const int* row_group = nullptr, const int* group_open = nullptr, int epi = EPI_STORE);
+          float* out, int out_ld, const int* row_group = nullptr, const int* group_open = nullptr, int epi = EPI_STORE,
+          const unsigned* amax_in = nullptr, unsigned* amax_out = nullptr);
 
 // Host-side packing: OIHW fp32 -> panel. `cin_pad4` packs for the tap4 mode (cin<=4).
 void pack_conv_weight(const float* oihw, int cout, int cin, int kh, int kw, bool tap4,
@@ -158,6 +203,8 @@ void avgpool2x2_ceil(hipStream_t s, const Tensor& in, const Tensor& out);
 constexpr int GAP_CHUNKS = 256;
 void global_avgpool(hipStream_t s, const Tensor& in, float* scratch, float* out_nc);
 void add_act(hipStream_t s, const Tensor& a, const Tensor& b, int act, const Tensor& out);
+// dst record = max(dst record, src record), line by line (a tensor that also holds values copied from src's tensor)
+void amax_merge(hipStream_t s, unsigned* dst, const unsigned* src);
 
 // Adaptive-scale-fusion pieces (DBNet++), see ymk_dbnet.cpp
 void asf_channel_gate(hipStream_t s, const float* gap_nc, const float* w1, const float* w2, int n,
@@ -208,6 +255,10 @@ ConvW make_conv(DevicePool& pool, const WeightStore& ws, const std::string& conv
 // nn.Linear(in,out): weight [out][in] (+bias) -> 1x1 conv panel
 ConvW make_linear(DevicePool& pool, const WeightStore& ws, const std::string& prefix, bool has_bias = true);
 ConvW make_linear_raw(DevicePool& pool, const float* w_out_in, const float* bias, int out, int in);
+// A STATIC max|x| record for the output of LayerNorm(gamma, beta) over d elements: a normalised element is at most sqrt(d - 1)
+// in magnitude, so |y| <= sqrt(d) max|gamma| + max|beta| whatever the input - a bound a few times above the real maximum,
+// which is all the power-of-two scale of the fp16-split kernels needs (ymk_conv_split.hip).  No pass, no atomics.
+unsigned* make_layernorm_amax_record(DevicePool& pool, const std::vector<float>& gamma, const std::vector<float>& beta);
 
 // ---------------------------------------------------------------- models
 class Model {

@@ -459,17 +459,20 @@ static std::atomic<int> g_no_splitk{0};      // 1: every launch through conv_ige
 static std::atomic<int> g_conv_fast{27};     // ConvK::fast
 static std::atomic<int> g_conv_variant{0};   // conv_igemm schedule selector for A/B runs, see launch_wide()
 static std::atomic<int> g_prof_dump{0};      // 1: ymk_prof_end prints one line per launch to stderr
-static std::atomic<int> g_conv_split{0};     // 0: exact fp32 MFMA (the product path); 2 / 3 / 16: split operands (ymk_conv_split.hip)
+static std::atomic<int> g_conv_split{-1};     // -1: unset (a model runs its own default); 0: exact fp32 MFMA everywhere; 2 / 3 / 16: split operands (ymk_conv_split.hip)
 static int splitk_forced() { return g_splitk_force.load(std::memory_order_relaxed); }
 static bool no_splitk() { return g_no_splitk.load(std::memory_order_relaxed) != 0; }
 static thread_local int t_conv_split = -1;  // >= 0: set by a ConvSplitScope on this thread (a model's own parameter)
 static thread_local SplitCtx* t_split_ctx = nullptr;
-ConvSplitScope::ConvSplitScope(int split, SplitCtx* ctx) : prev_(t_conv_split), prev_ctx_(t_split_ctx) {
+static thread_local int t_split_default = 0;
+ConvSplitScope::ConvSplitScope(int split, SplitCtx* ctx, int dflt) : prev_(t_conv_split), prev_dflt_(t_split_default), prev_ctx_(t_split_ctx) {
   t_conv_split = split;
   if (ctx) t_split_ctx = ctx;
+  if (dflt >= 0) t_split_default = dflt;
 }
 ConvSplitScope::~ConvSplitScope() {
   t_conv_split = prev_;
+  t_split_default = prev_dflt_;
   t_split_ctx = prev_ctx_;
 }
 
@@ -590,13 +593,13 @@ static void launch(hipStream_t s, ConvK& k) {
   const int mt = (k.M + BM - 1) / BM, nt = (k.Cout + BN - 1) / BN;
   k.ntiles_n = nt;
   if (MODE == 0 && (mt * nt < SPLITK_MAX_GRID || splitk_forced() >= 0) && !no_splitk() && try_splitk(s, k)) return;
-  // ConvK::fast bits 2 / 4: direct epilogue (plain stores only; everywhere / ragged Cout); bit 3: swizzled K tiles;
-  // bit 5 (opt-in, not yet measured): persistent tile loop for the swizzled tile (ymk_conv_persist.hip)
+  // ConvK::fast bits 2 / 4: direct epilogue (plain stores only; everywhere / ragged Cout); bit 3: swizzled K tiles.
+  // (A persistent tile loop over the swizzled tile - next tile's first loads issued before this tile's epilogue - was
+  // measured in round 4 and removed: bit-identical, 5-30 % slower on 15 of 17 shapes, profiles/r04_conv_sweep_persistent_tile_loop.txt)
   constexpr bool HAS_OPT = MODE == 0 && PF == 1;
   constexpr bool HAS_SWZ = HAS_OPT && BM == 128 && BN == 64 && WM * WN == 8;
   const bool direct = HAS_OPT && k.epi == EPI_STORE && ((k.fast & 4) || ((k.fast & 16) && !k.vec));
   const bool swz = HAS_SWZ && (k.fast & 8);
-  if (swz && !direct && (k.fast & 32) && conv2d_persistent(s, k)) return;
   auto* e = conv_prof_open(s, k, BM, BN, mt * nt, 1);
   const dim3 grid(mt * nt), block(64 * WM * WN);
   if constexpr (HAS_SWZ) {
@@ -674,6 +677,8 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
   k.epi = a.epi;
   k.row_group = a.row_group;
   k.group_open = a.group_open;
+  k.amax = in.amax ? in.amax : a.amax_in;
+  k.amax_out = a.epi == EPI_ROWMAX ? nullptr : (out.amax ? out.amax : a.amax_out);
   YMK_CHECK((a.row_group == nullptr) == (a.group_open == nullptr), "conv: row_group and group_open come together");
   YMK_CHECK(w.w != nullptr, "conv weight not packed");
   if (w.mode == 0) {
@@ -720,7 +725,9 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
     return;
   }
   {  // split operands (bf16 / fp16 planes) with fp32 accumulation for the launches that fill the chip (measurement / evaluation)
-    const int split = t_conv_split >= 0 ? t_conv_split : g_conv_split.load(std::memory_order_relaxed);
+    int split = t_conv_split;
+    if (split < 0) split = g_conv_split.load(std::memory_order_relaxed);
+    if (split < 0) split = t_split_default;
     if (split != 0 && a.row_group == nullptr && t_split_ctx != nullptr && conv2d_split(s, k, w, split, t_split_ctx)) return;
   }
   // tile selection: wide tiles when there is enough work to fill 256 CUs x 2 blocks
@@ -757,7 +764,7 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
 }
 
 void gemm(hipStream_t s, const float* A, int M, int K, int lda, const ConvW& w, int act, const float* res, int res_ld,
-          float* out, int out_ld, const int* row_group, const int* group_open, int epi) {
+          float* out, int out_ld, const int* row_group, const int* group_open, int epi, const unsigned* amax_in, unsigned* amax_out) {
   YMK_CHECK(K == w.cin, "gemm: K " + std::to_string(K) + " != weight in-features " + std::to_string(w.cin));
   Tensor in{const_cast<float*>(A), 1, 1, M, K, lda};
   Tensor o{out, 1, 1, M, w.cout, out_ld};
@@ -768,6 +775,8 @@ void gemm(hipStream_t s, const float* A, int M, int K, int lda, const ConvW& w, 
   a.row_group = row_group;
   a.group_open = group_open;
   a.epi = epi;
+  a.amax_in = amax_in;
+  a.amax_out = amax_out;
   conv2d(s, in, w, a, o);
 }
 

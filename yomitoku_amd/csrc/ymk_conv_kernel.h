@@ -30,10 +30,9 @@ struct ConvK {
   int fast;     // ymk_debug_option("conv_fast"), default 27: bit 0 pointwise index shortcut, bit 1 residual prefetch,
                 // bit 2 direct epilogue for every plain store (A/B runs; slower than the staged one where 16-byte stores
                 // are possible), bit 3 swizzled K tiles / three 128 x 64 blocks per CU, bit 4 direct epilogue for the
-                // launches that cannot store 16 bytes per lane (ragged Cout: the 7119-wide vocabulary head); bit 5 (off):
-                // persistent tile loop for the swizzled tile (ymk_conv_persist.hip, not yet run on hardware)
-  int ntiles;   // conv_igemm_persist only: M tiles x N tiles of the launch
-  const unsigned* amax;  // fp16-split kernels only: bits of max|x| over the input view (ymk_conv_split.hip)
+                // launches that cannot store 16 bytes per lane (ragged Cout: the 7119-wide vocabulary head)
+  const unsigned* amax;  // fp16-split kernels only: max|x| record of the input view (ymk_common.h; ymk_conv_split.hip)
+  unsigned* amax_out;    // every kernel: record to fold max|y| of the stored outputs into, or null
 };
 
 // true when some row of the block's M tile [m0, m0 + BM) is still needed (or no row predicate was given); block-uniform
@@ -60,7 +59,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 constexpr int LDK = 36;  // padded K-tile row (floats)
 
-// ---- K-tile layout in LDS (conv_igemm OPT bit 1, conv_igemm_persist)
+// ---- K-tile layout in LDS (conv_igemm OPT bit 1)
 constexpr int lds_row(int opt) { return (opt & 2) ? 32 : LDK; }
 constexpr int blocks_per_cu(int bm, int bn, int opt) {
   const int bytes = 2 * (bm + bn) * lds_row(opt) * 4;
@@ -151,9 +150,10 @@ __device__ __forceinline__ void epilogue_tile(const ConvK& p, const float* Cs, i
     }
     return;
   }
-  if (co >= p.Cout) return;
+  unsigned am = 0u;  // max|y| of what this thread stores (bit pattern), for the output's record
+  const bool live = co < p.Cout;  // (no early return: the record's wave reduction below wants all 64 lanes)
   const int ohw = p.OH * p.OW;
-  if (p.vec) {
+  if (live && p.vec) {
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = zero4;
     if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + co);
     if (p.bias) bi = *reinterpret_cast<const float4*>(p.bias + co);
@@ -197,9 +197,10 @@ __device__ __forceinline__ void epilogue_tile(const ConvK& p, const float* Cs, i
         v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
       }
       *reinterpret_cast<float4*>(p.out + o) = v;
+      amax_fold4(am, v);
       if (PRE) __builtin_amdgcn_sched_barrier(0);  // one row at a time: the 16-wave tiles have 64 registers per lane
     }
-  } else {  // ragged Cout / unaligned rows: scalar stores (EPI_STORE only)
+  } else if (live) {  // ragged Cout / unaligned rows: scalar stores (EPI_STORE only)
     for (int row = r0; row < BM; row += RPP) {
       const int m = m0 + row;
       if (m >= p.M) break;
@@ -211,9 +212,11 @@ __device__ __forceinline__ void epilogue_tile(const ConvK& p, const float* Cs, i
         v = apply_act(v, p.act);
         if (p.res_post) v += rr;
         p.out[(size_t)m * p.out_ld + co + e] = v;
+        amax_fold(am, v);
       }
     }
   }
+  if (p.amax_out) amax_commit(p.amax_out, am, t);
 }
 
 // ---- epilogue straight from the accumulators (EPI_STORE): lane (li, lh) of a wave holds, for MFMA tile (a, b), register
@@ -223,6 +226,7 @@ __device__ __forceinline__ void epilogue_tile(const ConvK& p, const float* Cs, i
 // functions per element).
 template <int ACT, int TM, int TN>
 __device__ __forceinline__ void epilogue_direct_act(const ConvK& p, const f32x16 (&acc)[TM][TN], int mw, int nw, int li, int lh) {
+  unsigned am = 0u;
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
     const int co = nw + 32 * b + li;
@@ -247,10 +251,14 @@ __device__ __forceinline__ void epilogue_direct_act(const ConvK& p, const f32x16
         if (rp && !p.res_post) v += rr[r];
         v = apply_act(v, ACT);
         if (p.res_post) v += rr[r];
-        if (cok && mb + dr < p.M) op[(size_t)dr * p.out_ld] = v;
+        if (cok && mb + dr < p.M) {
+          op[(size_t)dr * p.out_ld] = v;
+          amax_fold(am, v);
+        }
       }
     }
   }
+  if (p.amax_out) amax_commit(p.amax_out, am, threadIdx.x);
 }
 
 template <int TM, int TN>
@@ -270,8 +278,5 @@ std::pair<hipEvent_t, hipEvent_t>* conv_prof_open(hipStream_t s, const ConvK& k,
 // split-operand path (ymk_conv_split.hip): true when the launch was taken.  code 2 / 3: bf16 planes (3 / 6 MFMAs per
 // product tile), SPLIT_F16X2: two scaled fp16 planes (3 MFMAs)
 bool conv2d_split(hipStream_t s, ConvK& k, const ConvW& w, int code, SplitCtx* ctx);
-
-// persistent tile loop over the swizzled 128 x 64 tile (ymk_conv_persist.hip; opt-in, conv_fast bit 5): true when taken
-bool conv2d_persistent(hipStream_t s, ConvK& k);
 
 }  // namespace ymk

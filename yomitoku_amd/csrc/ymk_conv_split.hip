@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64 * WM * WN, (bf16_waves_per_simd<BM, BN, WM, WN, 
   const int t = threadIdx.x;
   float sa = 1.f, inv_sa = 1.f;
   if (FMT == 1) {
-    const float2 sc = f16_scales(*p.amax);
+    const float2 sc = f16_scales((unsigned)__builtin_amdgcn_readfirstlane((int)amax_read(p.amax, t)));  // wave-uniform: scalar registers
     sa = sc.x;
     inv_sa = sc.y;
   }
@@ -437,7 +437,8 @@ __global__ void k_split_panel_f16(const float* __restrict__ w, unsigned short* _
 }
 
 // ---- max|x| over an NHWC view (pixels x c floats, pixel stride ld; c, ld multiples of 4) -> atomicMax of the fp32 bit
-// patterns into *slot (zero before the launch); the launch also clears *next, the word the following launch will use
+// patterns into word 0 of the record `slot` (zero before the launch; the other lines of these records stay zero); the
+// launch also clears word 0 of `next`, the record the following launch will use
 __global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ in, size_t items, int c4, int ld, unsigned* __restrict__ slot,
                                                 unsigned* __restrict__ next) {
   __shared__ unsigned red[4];
@@ -471,6 +472,28 @@ __global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ in, si
   if ((t & 63) == 0) red[t >> 6] = m;
   __syncthreads();
   if (t == 0) atomicMax(slot, max(max(red[0], red[1]), max(red[2], red[3])));
+}
+
+// ---- self-check of the producers' records (ymk_debug_option("amax_check", 1); tests/test_conv_split_gpu.py): a launch whose
+// input came with a record ALSO makes the pass, and a one-wave kernel compares the two: counters[0] = launches checked,
+// [1] = records BELOW the true max|x| (a stale or incomplete record: the fp16 planes may overflow - a bug), [2] = records more
+// than 2^8 above it (a derived bound so loose that it costs low-plane bits), [3] = the largest record / truth ratio as a power of two
+static std::atomic<int> g_amax_check{0};
+static unsigned long long* g_amax_counters = nullptr;  // device, 4 words
+__global__ void k_amax_verify(const unsigned* __restrict__ rec, const unsigned* __restrict__ truth, unsigned long long* __restrict__ counters) {
+  const unsigned got = amax_read(rec, threadIdx.x), want = amax_read(truth, threadIdx.x);
+  if (threadIdx.x != 0) return;
+  atomicAdd(&counters[0], 1ull);
+  if (got < want) atomicAdd(&counters[1], 1ull);
+  const int slack = (int)(got >> 23) - (int)(want >> 23);  // exponent distance
+  if (want != 0u && slack > 8) atomicAdd(&counters[2], 1ull);
+  if (want != 0u && slack > 0) atomicMax(&counters[3], (unsigned long long)slack);
+}
+void amax_check_counters(long long* out4) {
+  for (int i = 0; i < 4; ++i) out4[i] = 0;
+  if (!g_amax_counters) return;
+  YMK_HIP(hipDeviceSynchronize());
+  YMK_HIP(hipMemcpy(out4, g_amax_counters, 4 * sizeof(long long), hipMemcpyDeviceToHost));
 }
 
 // ---- per-model state
@@ -508,8 +531,8 @@ class SplitCtx {
   // max|x| of the input view of launch k, on stream s; returns the device word the convolution kernel reads
   const unsigned* absmax(hipStream_t s, const ConvK& k) {
     if (!slots_) {
-      slots_ = reinterpret_cast<unsigned*>(alloc(2 * sizeof(unsigned)));
-      YMK_HIP(hipMemset(slots_, 0, 2 * sizeof(unsigned)));
+      slots_ = reinterpret_cast<unsigned*>(alloc(2 * AMAX_REC_WORDS * sizeof(unsigned)));
+      YMK_HIP(hipMemset(slots_, 0, 2 * AMAX_REC_WORDS * sizeof(unsigned)));
     }
     // the two words alternate along ONE stream (each launch clears the other word for its successor); a context that
     // moves to another stream waits for the old one first
@@ -519,8 +542,8 @@ class SplitCtx {
     const size_t pixels = (size_t)(k.in_bytes / 4 - k.C) / k.in_ld + 1;
     const size_t items = pixels * (size_t)(k.C / 4);
     const int blocks = (int)std::min<size_t>(1024, (items + 1023) / 1024);
-    unsigned* cur = slots_ + parity_;
-    hipLaunchKernelGGL(k_absmax, dim3(blocks), dim3(256), 0, s, k.in, items, k.C / 4, k.in_ld, cur, slots_ + (parity_ ^ 1));
+    unsigned* cur = slots_ + parity_ * AMAX_REC_WORDS;
+    hipLaunchKernelGGL(k_absmax, dim3(blocks), dim3(256), 0, s, k.in, items, k.C / 4, k.in_ld, cur, slots_ + (parity_ ^ 1) * AMAX_REC_WORDS);
     parity_ ^= 1;
     return cur;
   }
@@ -563,7 +586,15 @@ static void launch_split(hipStream_t s, ConvK& k, const void* wsplit, SplitCtx* 
   const int mt = (k.M + BM - 1) / BM, nt = (k.Cout + BN - 1) / BN;
   k.ntiles_n = nt;
   auto* e = conv_prof_open(s, k, BM, BN, mt * nt, (FMT ? 160 : 10 * NS));
-  if (FMT == 1) k.amax = ctx->absmax(s, k);  // inside the timed span: the pass is part of the layer's cost
+  if (FMT == 1 && k.amax == nullptr) {
+    k.amax = ctx->absmax(s, k);  // no record from the producer: a pass over the input (inside the timed span)
+  } else if (FMT == 1 && g_amax_check.load(std::memory_order_relaxed)) {
+    if (!g_amax_counters) {
+      YMK_HIP(hipMalloc((void**)&g_amax_counters, 4 * sizeof(unsigned long long)));
+      YMK_HIP(hipMemset(g_amax_counters, 0, 4 * sizeof(unsigned long long)));
+    }
+    hipLaunchKernelGGL(k_amax_verify, dim3(1), dim3(64), 0, s, k.amax, ctx->absmax(s, k), g_amax_counters);
+  }
   hipLaunchKernelGGL((conv_igemm_split<BM, BN, WM, WN, NS, KS, PF, FMT>), dim3(mt * nt), dim3(64 * WM * WN), 0, s, k,
                      reinterpret_cast<const uint4*>(wsplit));
   if (e) YMK_HIP(hipEventRecord(e->second, s));
@@ -580,8 +611,9 @@ static void launch_split(hipStream_t s, ConvK& k, const void* wsplit, SplitCtx* 
 // (bf16 only; the fp16 form keeps the shapes that won there: 0 / 3 = 128 x 128 x 16 waves, 1 = 128 x 64, 2 = 256 x 128, 11)
 static std::atomic<int> g_split_tile{0};
 bool conv_split_debug_option(const std::string& key, int value) {
-  if (key != "conv_split_tile") return false;
-  g_split_tile = value;
+  if (key == "conv_split_tile") g_split_tile = value;
+  else if (key == "amax_check") g_amax_check = value;
+  else return false;
   return true;
 }
 
@@ -628,6 +660,8 @@ static void dispatch_f16(hipStream_t s, ConvK& k, const void* ws, int tile, bool
   }
 }
 
+bool conv2d_f16_dma(hipStream_t s, ConvK& k, const void* wsplit, size_t w_bytes, bool narrow);  // ymk_conv_dma.hip
+
 bool conv2d_split(hipStream_t s, ConvK& k, const ConvW& w, int code, SplitCtx* ctx) {
   if (w.mode != 0 || ctx == nullptr || (code != 2 && code != 3 && code != SPLIT_F16X2)) return false;  // 4-channel stems keep the fp32 kernel
   const long blocks128 = (long)((k.M + 127) / 128) * ((w.cout + 127) / 128);
@@ -636,6 +670,19 @@ bool conv2d_split(hipStream_t s, ConvK& k, const ConvW& w, int code, SplitCtx* c
   int tile = g_split_tile.load(std::memory_order_relaxed);
   if (tile == 0) tile = code == 3 ? 2 : 3;
   const bool narrow = w.cout <= 64 || tile == 1;
+  if (code == SPLIT_F16X2 && tile == 20) {  // the LDS-DMA form (ymk_conv_dma.hip): 256 x 128 / 256 x 64 tiles
+    k.scale = pn.scale;
+    const bool nar = w.cout <= 64;
+    k.ntiles_n = (k.Cout + (nar ? 64 : 128) - 1) / (nar ? 64 : 128);
+    auto* e = conv_prof_open(s, k, 256, nar ? 64 : 128, ((k.M + 255) / 256) * k.ntiles_n, 161);
+    if (k.amax == nullptr) k.amax = ctx->absmax(s, k);
+    const size_t w_bytes = (size_t)((w.cout + 255) / 256 * 256) * w.kpad * 2 * 2;
+    const bool taken = conv2d_f16_dma(s, k, pn.planes, w_bytes, nar);
+    if (e) YMK_HIP(hipEventRecord(e->second, s));
+    YMK_HIP(hipGetLastError());
+    YMK_CHECK(taken, "conv_f16_dma refused a launch");
+    return true;
+  }
   if (code == SPLIT_F16X2) {
     k.scale = pn.scale;
     dispatch_f16(s, k, pn.planes, tile, narrow, ctx);

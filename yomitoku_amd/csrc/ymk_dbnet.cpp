@@ -99,7 +99,7 @@ class DBNetModel : public Model {
   // x: device NCHW fp32 [n][3][h][w] (h, w multiples of 32); prob: device [n][1][h][w]
   void forward(const float* x_nchw, int n, int h, int w, float* prob, hipStream_t s) {
     YMK_CHECK(finalized, "model not finalized");
-    ConvSplitScope split_scope(conv_split(), split_ctx.get());
+    ConvSplitScope split_scope(conv_split(), split_ctx.get(), SPLIT_MODEL_DEFAULT);
     YMK_CHECK(n > 0 && h % 32 == 0 && w % 32 == 0 && h >= 32 && w >= 32, "dbnet input must be a multiple of 32");
     const uint64_t key = ((uint64_t)n << 40) | ((uint64_t)h << 20) | (uint64_t)w;
     if (key != shape_key_) {
@@ -139,15 +139,18 @@ class DBNetModel : public Model {
   }
 
  private:
+  // `rec`: the max|x| record the launch folds its outputs into (ymk_common.h); by default a fresh one for a fresh output
   Tensor conv(hipStream_t s, const Tensor& in, const ConvW& w, int stride, int pad, int dil, int act,
-              const Tensor* res = nullptr, const Tensor* into = nullptr) {
+              const Tensor* res = nullptr, const Tensor* into = nullptr, unsigned* rec = nullptr) {
     Tensor out;
     if (into) {
       out = *into;
     } else {
       out = arena.tensor(in.n, conv_out_dim(in.h, w.kh, stride, pad, dil), conv_out_dim(in.w, w.kw, stride, pad, dil),
                          w.cout);
+      out.amax = arena.amax_next();
     }
+    if (rec) out.amax = rec;
     if (arena.dry_run) return out;
     ConvArgs a;
     a.stride = stride;
@@ -169,10 +172,12 @@ class DBNetModel : public Model {
 
   void run(const float* x_nchw, int n, int h, int w, float* prob, hipStream_t s) {
     const bool dry = arena.dry_run;
+    arena.amax_begin(s, 96);  // one max|x| record per convolution output (about 70 of them)
     Tensor x4 = arena.tensor(n, h, w, 4);
     if (!dry) nchw3_to_nhwc4(s, x_nchw, n, h, w, x4);
     Tensor c1 = conv(s, x4, stem_, 2, 3, 1, ACT_RELU);
     Tensor p = arena.tensor(n, (c1.h + 2 - 3) / 2 + 1, (c1.w + 2 - 3) / 2 + 1, c1.c);
+    p.amax = c1.amax;  // a maximum over windows of c1: bounded by c1's own max|x|
     if (!dry) maxpool3x3s2(s, c1, p);
     Tensor feat[4];
     Tensor cur = p;
@@ -199,10 +204,13 @@ class DBNetModel : public Model {
 
     const int fh = p1.h, fw = p1.w;
     Tensor fuse = arena.tensor(n, fh, fw, 256);
+    // ONE record for the four parts of the concat buffer: three of them are bilinear up-samplings (convex combinations: no
+    // value beyond their source's), the fourth a convolution writing its slice
+    fuse.amax = arena.amax_next();
     {
-      Tensor o4 = conv(s, p4, out_proj_[3], 1, 1, 1, ACT_NONE);
-      Tensor o3 = conv(s, p3, out_proj_[2], 1, 1, 1, ACT_NONE);
-      Tensor o2 = conv(s, p2, out_proj_[1], 1, 1, 1, ACT_NONE);
+      Tensor o4 = conv(s, p4, out_proj_[3], 1, 1, 1, ACT_NONE, nullptr, nullptr, fuse.amax);
+      Tensor o3 = conv(s, p3, out_proj_[2], 1, 1, 1, ACT_NONE, nullptr, nullptr, fuse.amax);
+      Tensor o2 = conv(s, p2, out_proj_[1], 1, 1, 1, ACT_NONE, nullptr, nullptr, fuse.amax);
       Tensor s0 = fuse.slice_c(0, 64), s1 = fuse.slice_c(64, 64), s2 = fuse.slice_c(128, 64), s3 = fuse.slice_c(192, 64);
       if (!dry) {
         // nn.Upsample(scale_factor=4 / 4 / 2): output = floor(in * scale)
@@ -220,6 +228,7 @@ class DBNetModel : public Model {
     float* gate = arena.alloc_f((size_t)n * 64);
     float* cmean = arena.alloc_f((size_t)n * fh * fw);
     Tensor fused = arena.tensor(n, fh, fw, 256);
+    fused.amax = fuse.amax;  // fuse times attention weights in (0, 1) (sigmoids): bounded by fuse's max|x|
     if (!dry) {
       global_avgpool(s, ax, gap_scr, gap);
       asf_channel_gate(s, gap, asf_w1_, asf_w2_, n, asf_c_, asf_cmid_, gate);

@@ -389,4 +389,15 @@ void deconv2x2_to1_sigmoid(hipStream_t s, const Tensor& in, const float* w_c4, f
   YMK_HIP(hipGetLastError());
 }
 
+// ---------------------------------------------------------------- max|x| records (ymk_common.h)
+__global__ void k_amax_merge(unsigned* __restrict__ dst, const unsigned* __restrict__ src) {
+  const int i = threadIdx.x * AMAX_LINE_WORDS;
+  dst[i] = max(dst[i], src[i]);
+}
+void amax_merge(hipStream_t s, unsigned* dst, const unsigned* src) {
+  if (dst == nullptr || src == nullptr) return;
+  hipLaunchKernelGGL(k_amax_merge, dim3(1), dim3(AMAX_LINES), 0, s, dst, src);
+  YMK_HIP(hipGetLastError());
+}
+
 }  // namespace ymk

@@ -44,6 +44,7 @@ namespace {
 
 struct EncBlock {
   float *ln1g, *ln1b, *ln2g, *ln2b;
+  unsigned *ln1_rec, *ln2_rec;  // static max|x| records of the two LayerNorm outputs (make_layernorm_amax_record)
   ConvW qkv, proj, fc1, fc2;
 };
 
@@ -95,6 +96,8 @@ class ParseqModel : public Model {
       b.ln1b = pool.upload(ws.get(p + "norm1.bias").data);
       b.ln2g = pool.upload(ws.get(p + "norm2.weight").data);
       b.ln2b = pool.upload(ws.get(p + "norm2.bias").data);
+      b.ln1_rec = make_layernorm_amax_record(pool, ws.get(p + "norm1.weight").data, ws.get(p + "norm1.bias").data);
+      b.ln2_rec = make_layernorm_amax_record(pool, ws.get(p + "norm2.weight").data, ws.get(p + "norm2.bias").data);
       b.qkv = make_linear(pool, ws, p + "attn.qkv");
       b.proj = make_linear(pool, ws, p + "attn.proj");
       b.fc1 = make_linear(pool, ws, p + "mlp.fc1");
@@ -102,6 +105,7 @@ class ParseqModel : public Model {
     }
     enc_ng_ = pool.upload(ws.get(e + "norm.weight").data);
     enc_nb_ = pool.upload(ws.get(e + "norm.bias").data);
+    enc_n_rec_ = make_layernorm_amax_record(pool, ws.get(e + "norm.weight").data, ws.get(e + "norm.bias").data);
 
     const std::string d = "decoder.layers.0.";
     auto split_mha = [&](const std::string& name, ConvW& wq, ConvW& wkv, ConvW& wo) {
@@ -151,6 +155,9 @@ class ParseqModel : public Model {
     nqg_ = up(d + "norm_q.weight"); nqb_ = up(d + "norm_q.bias");
     ncg_ = up(d + "norm_c.weight"); ncb_ = up(d + "norm_c.bias");
     dng_ = up("decoder.norm.weight"); dnb_ = up("decoder.norm.bias");
+    n1_rec_ = make_layernorm_amax_record(pool, ws.get(d + "norm1.weight").data, ws.get(d + "norm1.bias").data);
+    n2_rec_ = make_layernorm_amax_record(pool, ws.get(d + "norm2.weight").data, ws.get(d + "norm2.bias").data);
+    dn_rec_ = make_layernorm_amax_record(pool, ws.get("decoder.norm.weight").data, ws.get("decoder.norm.bias").data);
     head_ = make_linear(pool, ws, "head");
     YMK_CHECK(head_.cout == C_, "head width must be num_tokens - 2");
     {
@@ -199,7 +206,7 @@ class ParseqModel : public Model {
   // out_len[g] / ar_steps[g]: rows valid per sample / greedy steps of group g as its own loop would have run them.
   void forward_groups(const PGroup* groups, int ng, float* logits, int* out_len, int* ar_steps, hipStream_t s) {
     YMK_CHECK(finalized, "model not finalized");
-    ConvSplitScope split_scope(conv_split(), split_ctx.get());
+    ConvSplitScope split_scope(conv_split(), split_ctx.get(), SPLIT_MODEL_DEFAULT);
     YMK_CHECK(ng > 0, "parseq: no mini-batch");
     uint64_t key = 1469598103934665603ull;
     for (int g = 0; g < ng; ++g) {
@@ -267,20 +274,23 @@ class ParseqModel : public Model {
                    float* t2, float* h, float* out, int ld_out) {
     const int D = Dd_, hd = D / dh_;
     const float scale = 1.f / std::sqrt((float)hd);
+    // max|x| records of the GEMM inputs (fp16-split launches: the refinement pass's 60 000 rows): LayerNorm outputs have
+    // static ones, the cross-attention output is a convex combination of memory V rows, the FFN hidden state gets one
     ln(s, q, n1g_, n1b_, 1e-5f, t, M, D);
-    gemm(s, t, M, D, D, ca_q_, ACT_NONE, nullptr, 0, t2, D);
+    gemm(s, t, M, D, D, ca_q_, ACT_NONE, nullptr, 0, t2, D, nullptr, nullptr, EPI_STORE, n1_rec_);
     if (Lq >= 32)
       flash_attention(s, t2, memkv, memkv + D, t, B, dh_, Lq, L, hd, D, 2 * D, 2 * D, D, (long)Lq * D, (long)L * 2 * D,
                       (long)L * 2 * D, (long)Lq * D, scale, mem);
     else
       small_attention(s, t2, memkv, memkv + D, t, B, dh_, Lq, L, hd, D, 2 * D, 2 * D, D, (long)Lq * D, (long)L * 2 * D,
                       (long)L * 2 * D, (long)Lq * D, scale, nullptr, 0, nullptr, 0, mem);
-    gemm(s, t, M, D, D, ca_o_, ACT_NONE, q, D, q, D);
+    gemm(s, t, M, D, D, ca_o_, ACT_NONE, q, D, q, D, nullptr, nullptr, EPI_STORE, memkv_rec_);
     ln(s, q, n2g_, n2b_, 1e-5f, t, M, D);
-    gemm(s, t, M, D, D, lin1_, ACT_GELU, nullptr, 0, h, lin1_.cout);
-    gemm(s, h, M, lin1_.cout, lin1_.cout, lin2_, ACT_NONE, q, D, q, D);
+    unsigned* h_rec = arena.amax_next();
+    gemm(s, t, M, D, D, lin1_, ACT_GELU, nullptr, 0, h, lin1_.cout, nullptr, nullptr, EPI_STORE, n2_rec_, h_rec);
+    gemm(s, h, M, lin1_.cout, lin1_.cout, lin2_, ACT_NONE, q, D, q, D, nullptr, nullptr, EPI_STORE, h_rec);
     ln(s, q, dng_, dnb_, 1e-5f, t, M, D);
-    gemm(s, t, M, D, D, head_, ACT_NONE, nullptr, 0, out, ld_out);
+    gemm(s, t, M, D, D, head_, ACT_NONE, nullptr, 0, out, ld_out, nullptr, nullptr, EPI_STORE, dn_rec_);
   }
 
   void run(const PGroup* groups, int ng, float* logits, int* out_len, int* ar_steps, hipStream_t s) {
@@ -299,6 +309,7 @@ class ParseqModel : public Model {
     }
     const bool ragged = ng > 1;
     // ---------------- encoder
+    arena.amax_begin(s, 160);  // max|x| records (ymk_common.h): two per encoder block, one per decoder-tail call, K|V
     float* x4buf = arena.alloc_f(x4_max);
     float* xs = arena.alloc_f((size_t)M * D);  // [M][D] token stream, updated in place
     float* y = arena.alloc_f((size_t)M * D);
@@ -391,20 +402,24 @@ class ParseqModel : public Model {
     std::optional<ConvSplitScope> enc_scope;
     if (enc_split >= 0) enc_scope.emplace(enc_split);
     for (const EncBlock& b : blocks_) {
+      // records of the GEMM inputs: static for the LayerNorm outputs; the q|k|v GEMM leaves one that also bounds the attention
+      // output (a convex combination of V rows); fc1 leaves one for the hidden state
+      unsigned *qkv_rec = arena.amax_next(), *h_rec = arena.amax_next();
       ln(s, xs, b.ln1g, b.ln1b, 1e-6f, y, M, D);
-      gemm(s, y, M, D, D, b.qkv, ACT_NONE, nullptr, 0, qkv, 3 * D);
+      gemm(s, y, M, D, D, b.qkv, ACT_NONE, nullptr, 0, qkv, 3 * D, nullptr, nullptr, EPI_STORE, b.ln1_rec, qkv_rec);
       flash_attention(s, qkv, qkv + D, qkv + 2 * D, att, B, eh_, L, L, hd, 3 * D, 3 * D, 3 * D, D, (long)L * 3 * D,
                       (long)L * 3 * D, (long)L * 3 * D, (long)L * D, scale, enc_t);
-      gemm(s, att, M, D, D, b.proj, ACT_NONE, xs, D, xs, D);
+      gemm(s, att, M, D, D, b.proj, ACT_NONE, xs, D, xs, D, nullptr, nullptr, EPI_STORE, qkv_rec);
       ln(s, xs, b.ln2g, b.ln2b, 1e-6f, y, M, D);
-      gemm(s, y, M, D, D, b.fc1, ACT_GELU, nullptr, 0, hbuf, b.fc1.cout);
-      gemm(s, hbuf, M, b.fc1.cout, b.fc1.cout, b.fc2, ACT_NONE, xs, D, xs, D);
+      gemm(s, y, M, D, D, b.fc1, ACT_GELU, nullptr, 0, hbuf, b.fc1.cout, nullptr, nullptr, EPI_STORE, b.ln2_rec, h_rec);
+      gemm(s, hbuf, M, b.fc1.cout, b.fc1.cout, b.fc2, ACT_NONE, xs, D, xs, D, nullptr, nullptr, EPI_STORE, h_rec);
     }
     ln(s, xs, enc_ng_, enc_nb_, 1e-6f, mem, M, D);
     enc_scope.reset();
 
     // ---------------- decoder: batch-invariant pieces + memory K|V
-    gemm(s, mem, M, D, D, ca_kv_, ACT_NONE, nullptr, 0, memkv, 2 * D);
+    memkv_rec_ = arena.amax_next();
+    gemm(s, mem, M, D, D, ca_kv_, ACT_NONE, nullptr, 0, memkv, 2 * D, nullptr, nullptr, EPI_STORE, enc_n_rec_, memkv_rec_);
     ln(s, posq_, nqg_, nqb_, 1e-5f, t1, NS, D);
     gemm(s, t1, NS, D, D, sa_q_, ACT_NONE, nullptr, 0, qsa, D);
     init_decode(s, tok, NS, state, bos_, pad_, B);  // tok[:, 0] = bos, rest pad; state = {0, 0, -1, 0}
@@ -541,6 +556,8 @@ class ParseqModel : public Model {
   ConvW sa_q_, sa_kv_, sa_o_, ca_q_, ca_kv_, ca_o_, lin1_, lin2_, head_;
   DecStepW fw_{};  // transposed decoder weights for the fused step
   float *n1g_, *n1b_, *n2g_, *n2b_, *nqg_, *nqb_, *ncg_, *ncb_, *dng_, *dnb_;
+  unsigned *n1_rec_ = nullptr, *n2_rec_ = nullptr, *dn_rec_ = nullptr, *enc_n_rec_ = nullptr;  // static LayerNorm output records
+  unsigned* memkv_rec_ = nullptr;  // this forward's record of the memory K|V projection (what cross-attention outputs are bounded by)
   float *emb_ = nullptr, *posq_ = nullptr;
   unsigned char* qmask_ = nullptr;
   int* host_flags_ = nullptr;      // mapped pinned: (rows still open) + 1 per AR step

@@ -187,7 +187,7 @@ class RtdetrModel : public Model {
   // x: device fp32 [B][3][H][W]; logits: [B][nq][nc]; boxes: [B][nq][4] (cxcywh in [0,1])
   void forward(const float* x, int B, int H, int W, float* logits, float* boxes, hipStream_t s) {
     YMK_CHECK(finalized, "model not finalized");
-    ConvSplitScope split_scope(conv_split(), split_ctx.get());
+    ConvSplitScope split_scope(conv_split(), split_ctx.get(), SPLIT_MODEL_DEFAULT);
     YMK_CHECK(B > 0 && H % 32 == 0 && W % 32 == 0, "rtdetr input must be a multiple of 32");
     const int tok = (H / 8) * (W / 8) + (H / 16) * (W / 16) + (H / 32) * (W / 32);
     YMK_CHECK(tok == ntok_, "input size does not match the checkpoint's anchors (eval_spatial_size)");
@@ -234,6 +234,7 @@ class RtdetrModel : public Model {
     Tensor out = into ? *into
                       : arena.tensor(in.n, conv_out_dim(in.h, w.kh, stride, pad, 1), conv_out_dim(in.w, w.kw, stride, pad, 1),
                                      w.cout);
+    if (!into) out.amax = arena.amax_next();  // a fresh output gets a max|x| record (ymk_common.h); a slice keeps its buffer's
     if (dry()) return out;
     ConvArgs a;
     a.stride = stride;
@@ -270,6 +271,7 @@ class RtdetrModel : public Model {
 
   void run(const float* x, int B, int H, int W, float* logits, float* boxes, hipStream_t s) {
     const int D = 256;
+    arena.amax_begin(s, 128);  // max|x| records: one per convolution output / concat buffer (about 100)
     // ---------------- PResNet-50vd
     Tensor x4 = arena.tensor(B, H, W, 4);
     if (!dry()) nchw3_to_nhwc4(s, x, B, H, W, x4);
@@ -277,6 +279,7 @@ class RtdetrModel : public Model {
     c = conv(s, c, stem_[1], 1, 1, ACT_RELU);
     c = conv(s, c, stem_[2], 1, 1, ACT_RELU);
     Tensor p = arena.tensor(B, (c.h - 1) / 2 + 1, (c.w - 1) / 2 + 1, c.c);
+    p.amax = c.amax;  // window maxima of c: bounded by c's max|x|
     if (!dry()) maxpool3x3s2(s, c, p);
     Tensor feat[4];
     Tensor cur = p;
@@ -289,6 +292,7 @@ class RtdetrModel : public Model {
           Tensor src = cur;
           if (k.pool) {
             src = arena.tensor(B, (cur.h + 1) / 2, (cur.w + 1) / 2, cur.c);
+            src.amax = cur.amax;  // window means of cur
             if (!dry()) avgpool2x2_ceil(s, cur, src);
           }
           sh = conv(s, src, k.shortc, 1, 0, ACT_NONE);
@@ -316,20 +320,33 @@ class RtdetrModel : public Model {
       float* h = lin(s, s1, M5, aifi_l1_, ACT_GELU);
       float* t2 = lin(s, h, M5, aifi_l2_, ACT_NONE, s1);
       if (!dry()) layernorm(s, t2, D, 0, aifi_n2g_, aifi_n2b_, 1e-5f, P5.p, D, M5, D);  // back into the feature map
+      P5.amax = nullptr;  // rewritten in place: the convolution's record no longer describes it
     }
     Tensor catA = arena.tensor(B, C4.h, C4.w, 2 * D);     // [up(L5) | P4]
     Tensor catB = arena.tensor(B, C3.h, C3.w, 2 * D);     // [up(L4) | P3]
     Tensor catP0 = arena.tensor(B, C4.h, C4.w, 2 * D);    // [down(F3) | L4]
     Tensor catP1 = arena.tensor(B, C5.h, C5.w, 2 * D);    // [down(N4) | L5]
+    // one max|x| record per concat buffer, filled by the convolutions that write its halves; a half that is a nearest
+    // up-sampling of another buffer's half takes that buffer's record over (amax_merge) once its producer has run
+    catA.amax = arena.amax_next();
+    catB.amax = arena.amax_next();
+    catP0.amax = arena.amax_next();
+    catP1.amax = arena.amax_next();
     Tensor sA0 = catA.slice_c(0, D), sA1 = catA.slice_c(D, D), sB0 = catB.slice_c(0, D), sB1 = catB.slice_c(D, D);
     Tensor sP00 = catP0.slice_c(0, D), sP01 = catP0.slice_c(D, D), sP10 = catP1.slice_c(0, D), sP11 = catP1.slice_c(D, D);
     conv(s, C4, enc_in_[1], 1, 0, ACT_NONE, nullptr, &sA1);
     conv(s, C3, enc_in_[0], 1, 0, ACT_NONE, nullptr, &sB1);
     conv(s, P5, lateral_[0], 1, 0, ACT_SILU, nullptr, &sP11);  // L5
-    if (!dry()) upsample_nearest2x(s, sP11, sA0);
+    if (!dry()) {
+      upsample_nearest2x(s, sP11, sA0);
+      amax_merge(s, catA.amax, catP1.amax);  // (catP1's record holds L5 alone at this point)
+    }
     Tensor F4 = csp_fwd(s, catA, fpn_[0]);
     conv(s, F4, lateral_[1], 1, 0, ACT_SILU, nullptr, &sP01);  // L4
-    if (!dry()) upsample_nearest2x(s, sP01, sB0);
+    if (!dry()) {
+      upsample_nearest2x(s, sP01, sB0);
+      amax_merge(s, catB.amax, catP0.amax);
+    }
     Tensor F3 = csp_fwd(s, catB, fpn_[1]);
     conv(s, F3, down_[0], 2, 1, ACT_SILU, nullptr, &sP00);
     Tensor N4 = csp_fwd(s, catP0, pan_[0]);

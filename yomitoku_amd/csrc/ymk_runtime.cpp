@@ -30,6 +30,17 @@ void* Arena::alloc_bytes(size_t bytes) {
   YMK_CHECK(off_ <= cap_, "arena overflow: need " + std::to_string(off_) + " have " + std::to_string(cap_));
   return base_ + at;
 }
+void Arena::amax_begin(hipStream_t s, int records) {
+  amax_n_ = records;
+  amax_used_ = 0;
+  const size_t bytes = (size_t)records * AMAX_REC_WORDS * sizeof(unsigned);
+  amax_pool_ = (unsigned*)alloc_bytes(bytes);
+  if (!dry_run) YMK_HIP(hipMemsetAsync(amax_pool_, 0, bytes, s));
+}
+unsigned* Arena::amax_next() {
+  if (amax_pool_ == nullptr || amax_used_ >= amax_n_) return nullptr;
+  return amax_pool_ + (size_t)(amax_used_++) * AMAX_REC_WORDS;
+}
 float* Arena::alloc_f(size_t count) { return (float*)alloc_bytes(count * sizeof(float)); }
 Tensor Arena::tensor(int n, int h, int w, int c) {
   Tensor t;
@@ -129,6 +140,16 @@ ConvW make_linear_raw(DevicePool& pool, const float* w_out_in, const float* bias
   c.w = pool.upload(panel);
   if (bias) c.bias = pool.upload(bias, out);
   return c;
+}
+
+unsigned* make_layernorm_amax_record(DevicePool& pool, const std::vector<float>& gamma, const std::vector<float>& beta) {
+  float g = 0.f, b = 0.f;
+  for (float v : gamma) g = std::max(g, std::fabs(v));
+  for (float v : beta) b = std::max(b, std::fabs(v));
+  const float bound = std::sqrt((float)gamma.size()) * g + b;
+  std::vector<float> rec(AMAX_REC_WORDS, 0.f);  // all-zero bit patterns but word 0
+  rec[0] = bound;                                // the record holds fp32 bit patterns: upload the float as it is
+  return reinterpret_cast<unsigned*>(pool.upload(rec));
 }
 
 ConvW make_linear(DevicePool& pool, const WeightStore& ws, const std::string& prefix, bool has_bias) {

@@ -140,3 +140,115 @@ def replica_report(sds: Mapping[str, Mapping[str, torch.Tensor]], device=None) -
     return {"ranks": world, "backend": dist.get_backend() if dist.is_initialized() else None,
             "weights_crc_equal": all(c == crcs[0] for c in crcs),
             "weights_crc": {k: f"{int(v):08x}" for k, v in zip(names, crcs[0])}}
+
+
+# ------------------------------------------------------------------------------------------------ the sharded job
+def claim_core_slice(local_rank: int, local_world: int):
+    """Pin this process to its 1 / local_world share of the cores it may run on (Linux; elsewhere a no-op) and return the
+    share's size.  One rank keeps ~15 threads runnable (nine pipeline stages, two recogniser lanes, the box-extraction pool):
+    eight ranks wandering over each other's cores is what this prevents."""
+    if not hasattr(os, "sched_getaffinity"):
+        return os.cpu_count() or 1
+    cores = sorted(os.sched_getaffinity(0))
+    if local_world <= 1:
+        return len(cores)
+    per = max(1, len(cores) // local_world)
+    mine = cores[local_rank * per : (local_rank + 1) * per] or cores
+    os.sched_setaffinity(0, set(mine))
+    return len(mine)
+
+
+def thread_budget(cores: int) -> dict:
+    """Host threads of one rank for a share of `cores` cores.  The nine stage threads of DocumentAnalyzer.serve mostly sleep
+    in library calls (GIL released), so they stay; what scales with the share is the C++ box-extraction pool (4 at >= 16
+    cores, never more than a quarter of the share) and the second recogniser lane (dropped below 8 cores, where its extra
+    stream only adds runnable threads)."""
+    return {"stage_threads": 9, "box_threads": max(1, min(4, cores // 4)), "rec_lanes": 2 if cores >= 8 else 1}
+
+
+class ShardedServer:
+    """The page loop of cli/main.py:116-120 over the GPUs of one node - what north_star calls "pages shard naturally (one page
+    per GPU) ... with RCCL broadcast of weights": ONE process per GPU (torchrun, or any launcher that sets RANK / LOCAL_RANK /
+    WORLD_SIZE), each a full replica.
+
+        server = ShardedServer(make_analyzer, checkpoints)      # init -> core slice -> broadcast -> replica report -> analyzer
+        results = server.run(sources, wave=8, in_flight=4)       # shard -> DocumentAnalyzer.serve -> ordered gather (rank 0)
+        server.close()
+
+    make_analyzer(device, checkpoints, budget) builds this rank's DocumentAnalyzer from the broadcast checkpoints ({name:
+    state dict}; `checkpoints` is that mapping - or a callable returning it - on rank 0 and ignored elsewhere).  Sources are
+    dealt round-robin BY SOURCE (a multi-frame file stays on one rank); an entry that failed stays an exception object in
+    its place, exactly as `serve` reports it, and cannot hold the other ranks (nothing on the per-page path communicates)."""
+
+    def __init__(self, make_analyzer, checkpoints=None, backend: str | None = None, device=None, pin_cores: bool = True):
+        self.rank, self.local_rank, self.world = init(backend)
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", self.world))
+        self.cores = claim_core_slice(self.local_rank, local_world) if pin_cores else (os.cpu_count() or 1)
+        self.budget = thread_budget(self.cores)
+        if device is None:
+            device = torch.device("cuda", self.local_rank) if torch.cuda.is_available() else torch.device("cpu")
+        self.device = torch.device(device)
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)
+        sds = None
+        if self.rank == 0:
+            sds = checkpoints() if callable(checkpoints) else checkpoints
+        names = [None]
+        if self.rank == 0:
+            names[0] = list(sds) if sds is not None else None
+        if self.world > 1:
+            dist.broadcast_object_list(names, src=0)
+        self.checkpoints = None
+        if names[0] is not None:
+            self.checkpoints = OrderedDict((k, broadcast_state_dict(sds[k] if self.rank == 0 else None, src=0, device=self.device))
+                                           for k in names[0])
+        self.replicas = replica_report(self.checkpoints, self.device) if self.checkpoints else None
+        self.analyzer = make_analyzer(self.device, self.checkpoints, self.budget)
+
+    def shard(self, n_sources: int) -> List[int]:
+        return shard_indices(n_sources, self.rank, self.world)
+
+    def serve_local(self, sources: Sequence, **serve_kwargs) -> list:
+        """This rank's share through DocumentAnalyzer.serve: [(global source index, frame index, entry)], in order."""
+        mine = self.shard(len(sources))
+        serve_kwargs.setdefault("rec_lanes", self.budget["rec_lanes"])
+        local = self.analyzer.serve([sources[i] for i in mine], with_source=True, **serve_kwargs)
+        return [(mine[si], fi, entry) for si, fi, entry in local]
+
+    def gather(self, local: Sequence) -> list | None:
+        """Every rank's (source, frame, entry) triples on rank 0, ordered by (source, frame): the entries alone are returned
+        there, None elsewhere.  A host-side gather of Python objects (schemas and exception objects pickle), not a data-path
+        collective."""
+        parts = [list(local)]
+        if self.world > 1:
+            parts = [None] * self.world if self.rank == 0 else None
+            dist.gather_object(list(local), parts, dst=0)
+            if self.rank != 0:
+                return None
+        merged = sorted((t for part in parts for t in part), key=lambda t: (t[0], t[1]))
+        return [entry for _, _, entry in merged]
+
+    def run(self, sources: Sequence, **serve_kwargs) -> list | None:
+        return self.gather(self.serve_local(sources, **serve_kwargs))
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier()
+
+    def close(self, destroy_group: bool = True):
+        close = getattr(self.analyzer, "close", None)
+        if close is not None:
+            close()
+        if destroy_group and self.world > 1 and dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def serve_sharded(sources: Sequence, make_analyzer, checkpoints=None, backend: str | None = None, **serve_kwargs):
+    """One call per rank: the whole sharded job (ShardedServer: init -> broadcast -> shard -> serve -> ordered gather).
+    Returns every page's entry in source order on rank 0, None on the other ranks."""
+    server = ShardedServer(make_analyzer, checkpoints, backend=backend)
+    try:
+        return server.run(sources, **serve_kwargs)
+    finally:
+        server.close()

@@ -193,9 +193,7 @@ class LayoutParser(BaseModule):
         1 x Q x 4, (h, w)) as host arrays - what `pages_from_raw` turns into LayoutParserSchemas on the host."""
         pages = [img if isinstance(img, torch.Tensor) else imaging.page_to_device(img, self.device) for img in imgs]
         oh, ow = (int(v) for v in self._cfg.data.img_size)
-        if not getattr(self, "_workspace_reserved", False):
-            self.model.reserve(self.MAX_PAGES_PER_FORWARD, oh, ow, self.device)  # any wave size: no reallocation later
-            self._workspace_reserved = True
+        self.model.reserve_once(self.MAX_PAGES_PER_FORWARD, oh, ow, self.device)  # any wave size: no reallocation later (once per live handle)
         raw = []
         for start in range(0, len(pages), self.MAX_PAGES_PER_FORWARD):
             chunk = pages[start : start + self.MAX_PAGES_PER_FORWARD]

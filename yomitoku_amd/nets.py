@@ -118,6 +118,7 @@ class HipNet:
             raise
         self._h = h
         self._device_index = int(device_index)
+        self._reserve_tried_for = None  # a new handle has no workspace reservation (reserve_once)
 
     def set_conv_split(self, planes):
         """Operand precision of THIS model's convolutions / linear layers (include/ymk.h, "conv_split"): 0 = exact fp32 MFMA
@@ -155,6 +156,25 @@ class HipNet:
             self.to(device if device is not None else "cuda")
         with torch.cuda.device(self._device_index):
             _lib.check(_lib.load().ymk_model_reserve(self._h, int(n), int(h), int(w), _lib.current_stream_ptr()), "ymk_model_reserve")
+
+    def reserve_once(self, n: int, h: int, w: int, device=None) -> bool:
+        """reserve() once per LIVE handle (a rebuild by load_state_dict() / to() starts over).  A reservation that fails -
+        hipMalloc of the worst-case workspace, e.g. several processes sharing one GPU or a smaller HBM - is logged and the
+        model falls back to growing its workspace on demand; it is not retried for this handle (a retry would free the
+        working slab again on every call)."""
+        if self._h is not None and getattr(self, "_reserve_tried_for", None) == self._h:
+            return bool(self._reserve_ok)
+        try:
+            self.reserve(n, h, w, device)
+            self._reserve_ok = True
+        except _lib.YmkError as exc:
+            import logging
+
+            logging.getLogger("yomitoku_amd.base").warning(
+                "%s: could not reserve the worst-case workspace (%d x %d x %d): %s - falling back to grow-on-demand", type(self).__name__, n, h, w, exc)
+            self._reserve_ok = False
+        self._reserve_tried_for = self._h
+        return bool(self._reserve_ok)
 
     @property
     def weight_bytes(self) -> int:

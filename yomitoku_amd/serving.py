@@ -45,6 +45,7 @@ import gc
 import logging
 import os
 import queue
+import sys
 import threading
 import time
 from collections import deque
@@ -64,10 +65,11 @@ class Wave:
     """The pages that share device batches, and what the stages have produced for them so far."""
 
     __slots__ = ("seq", "ids", "imgs", "pages", "ring", "uploaded", "maps", "sizes", "dets", "rec_plan", "recs", "lay_raw",
-                 "lay_parsed", "tab_raw", "lays", "error", "failed_stage", "layout_done", "joined", "retry")
+                 "lay_parsed", "tab_raw", "lays", "error", "failed_stage", "layout_done", "joined", "retry", "job")
 
-    def __init__(self, seq=0, ids=(), imgs=(), pages=(), ring=0, uploaded=None, retry=False):
+    def __init__(self, seq=0, ids=(), imgs=(), pages=(), ring=0, uploaded=None, retry=False, job=None):
         self.seq, self.ids, self.imgs, self.pages, self.ring, self.uploaded = seq, list(ids), list(imgs), list(pages), ring, uploaded
+        self.job = job  # the serve() call this wave belongs to: a late wave of an aborted job must not write into the next one
         self.sizes = [tuple(int(v) for v in p.shape[:2]) for p in self.pages]
         self.maps = self.dets = self.rec_plan = self.recs = self.lay_raw = self.lay_parsed = self.tab_raw = self.lays = None
         self.error: Optional[BaseException] = None
@@ -110,6 +112,22 @@ def _full_gc_deferred(on: bool):
         gc.set_threshold(t0, t1, t2)
 
 
+@contextlib.contextmanager
+def _switch_interval(seconds):
+    """CPython's thread switch interval shortened while the block runs, restored afterwards.  The stage threads are
+    launch-latency-bound: one returning from a 50 us library call must not wait 5 ms (the default interval) behind another
+    stage's Python loop before it can issue its next launch.  None / 0 leaves the interpreter alone."""
+    if not seconds:
+        yield
+        return
+    before = sys.getswitchinterval()
+    sys.setswitchinterval(float(seconds))
+    try:
+        yield
+    finally:
+        sys.setswitchinterval(before)
+
+
 class PagePipeline:
     def __init__(self, analyzer, wave: int = 8, in_flight: int = 4, defer_full_gc: bool = True, stage_priority=None,
                  rec_lanes: int = 2):
@@ -122,6 +140,8 @@ class PagePipeline:
         YMK_STAGE_PRIORITY="recognize:-1,..." (measurement knob)."""
         self.analyzer = analyzer
         self.defer_full_gc = bool(defer_full_gc)
+        # thread switch interval for the duration of a job (YMK_SWITCH_INTERVAL overrides; 0 = leave the interpreter's)
+        self.switch_interval = float(os.environ.get("YMK_SWITCH_INTERVAL", 2e-4))
         self.stage_priority = dict(stage_priority or {})
         rec = getattr(analyzer, "text_recognizer", None)
         self.rec_lanes = 1 if getattr(rec, "rec_orientation_fallback", False) else max(1, int(os.environ.get("YMK_REC_LANES", rec_lanes)))
@@ -190,9 +210,16 @@ class PagePipeline:
                         fn(wave)
                 except BaseException as exc:  # noqa: BLE001 - delivered to the page's result slot
                     wave.fail(name, exc)
+                    if stream is not None:
+                        # kernels the failed stage already queued may still read the wave's pages / pinned maps / crops, which
+                        # the finish stage is about to hand back: drain them first (best effort - the device may be the problem)
+                        try:
+                            stream.synchronize()
+                        except Exception:  # noqa: BLE001
+                            pass
                     if name == "finish":  # cannot happen short of a bug in _finish itself: never lose a page or a slot
                         for idx in wave.ids:
-                            self._job.results.setdefault(idx, exc)
+                            wave.job.results.setdefault(idx, exc)
                         if wave.pages is not None:
                             self._release(wave)
                 if self.trace is not None:
@@ -211,7 +238,7 @@ class PagePipeline:
                 a._stage_split(wave)
 
     def _release(self, wave):
-        job = self._job
+        job = wave.job
         wave.pages = wave.maps = wave.rec_plan = None  # the device pages, the pinned map views and the crop tensors go back
         self._rings.put(wave.ring)
         with job.cond:
@@ -219,7 +246,7 @@ class PagePipeline:
             job.cond.notify_all()
 
     def _finish(self, wave):
-        job = self._job
+        job = wave.job
         if wave.error is not None:
             if len(wave) > 1:
                 logger.warning("wave of %d pages failed in stage %s (%s: %s); re-running its pages one by one", len(wave),
@@ -258,7 +285,7 @@ class PagePipeline:
         if self.trace is not None:
             self.trace.append(("wait_slot", self._seq, len(ids), t_start, t_ring))
             self.trace.append(("stage_h2d", self._seq, len(ids), t_ring, time.perf_counter()))
-        wave = Wave(self._seq, ids, imgs, pages, ring, uploaded, retry)
+        wave = Wave(self._seq, ids, imgs, pages, ring, uploaded, retry, job)
         with job.cond:
             job.outstanding += 1
             job.waves += 1
@@ -272,7 +299,7 @@ class PagePipeline:
         caller that writes `<file>_p<page>.json` per page needs (cli/main.py:122-137)."""
         from .data.functions import load_image
 
-        with self._serve_lock, _full_gc_deferred(self.defer_full_gc):
+        with self._serve_lock, _full_gc_deferred(self.defer_full_gc), _switch_interval(self.switch_interval):
             job = self._job = _Job()
             n = 0
             origin = []  # page id -> (source index, frame index)

@@ -138,9 +138,7 @@ class TableStructureRecognizer(BaseModule):
         arrays, in page / box order - what `tables_from_raw` turns into TableStructureRecognizerSchemas on the host."""
         pages = [img if isinstance(img, torch.Tensor) else imaging.page_to_device(img, self.device) for img in imgs]
         oh, ow = self._cfg.data.img_size
-        if not getattr(self, "_workspace_reserved", False):
-            self.model.reserve(self.MAX_TABLES_PER_FORWARD, int(oh), int(ow), self.device)  # any table count: no reallocation later
-            self._workspace_reserved = True
+        self.model.reserve_once(self.MAX_TABLES_PER_FORWARD, int(oh), int(ow), self.device)  # any table count: no reallocation later (once per live handle)
         flat = [(p, box) for p, boxes in enumerate(boxes_list) for box in boxes]
         raw = []
         for start in range(0, len(flat), self.MAX_TABLES_PER_FORWARD):

@@ -117,13 +117,12 @@ class TextDetector(BaseModule):
         forward_pages call of this module WITH THE SAME `ring` reuses) per page, in input order."""
         pages = [img if isinstance(img, torch.Tensor) else imaging.page_to_device(img, self.device) for img in imgs]
         cfg = self._cfg.data
-        if not getattr(self, "_workspace_reserved", False):
-            # multi-page serving: the workspace is sized once for the largest forward (MAX_PAGES_PER_FORWARD images of
-            # limit_size x shortest_size, either orientation: ~16 GB of 288), so no mix of page sizes reaches hipMalloc later
-            long_side = max(32, int(cfg.limit_size) // 32 * 32)
-            short_side = max(32, min(int(cfg.shortest_size), int(cfg.limit_size)) // 32 * 32)
-            self.model.reserve(self.MAX_PAGES_PER_FORWARD, long_side, short_side, self.device)
-            self._workspace_reserved = True
+        # multi-page serving: the workspace is sized once per live handle for the largest forward (MAX_PAGES_PER_FORWARD images
+        # of limit_size x shortest_size, either orientation: ~16 GB of 288), so no mix of page sizes reaches hipMalloc later;
+        # if that much cannot be had the model grows its workspace on demand (nets.reserve_once)
+        long_side = max(32, int(cfg.limit_size) // 32 * 32)
+        short_side = max(32, min(int(cfg.shortest_size), int(cfg.limit_size)) // 32 * 32)
+        self.model.reserve_once(self.MAX_PAGES_PER_FORWARD, long_side, short_side, self.device)
         by_size = {}
         for i, page in enumerate(pages):
             dims = imaging.resize_shortest_edge_dims(page.shape[0], page.shape[1], cfg.shortest_size, cfg.limit_size)
@@ -148,7 +147,8 @@ class TextDetector(BaseModule):
         from concurrent.futures import ThreadPoolExecutor
 
         if not hasattr(self, "_post_pool"):
-            self._post_pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="ymk-dbpost")
+            # `post_threads`: size of the pool (default 4; a sharded job sets it from its rank's core slice, distributed.thread_budget)
+            self._post_pool = ThreadPoolExecutor(max_workers=max(1, int(getattr(self, "post_threads", 4))), thread_name_prefix="ymk-dbpost")
         return [TextDetectorSchema(points=quads, scores=scores)
                 for quads, scores in self._post_pool.map(self.post_processor, list(maps), list(sizes))]
 

@@ -317,11 +317,9 @@ class TextRecognizer(BaseModule):
     def plan_pages(self, imgs, points_list):
         """The mini-batches of every page are formed per page exactly as in `__call__` (bucketing, width budget, padding)
         and their crop tensors built; a page's result never depends on its neighbours (mini-batches never mix pages)."""
-        if not getattr(self, "_workspace_reserved", False):
-            # multi-page serving: size the PARSeq workspace once for the largest grouped forward, so that no wave - however
-            # its lines fall into mini-batches - reaches hipMalloc / hipFree (tiny: ~12 GB, large-v4_1: ~23 GB of 288 GB)
-            self.model.reserve(self.MAX_LINES_PER_FORWARD, int(self._cfg.data.img_size[0]), int(self._cfg.data.img_size[1]), self.device)
-            self._workspace_reserved = True
+        # multi-page serving: size the PARSeq workspace once per live handle for the largest grouped forward, so that no wave -
+        # however its lines fall into mini-batches - reaches hipMalloc / hipFree (tiny: ~12 GB, large-v4_1: ~23 GB of 288 GB)
+        self.model.reserve_once(self.MAX_LINES_PER_FORWARD, int(self._cfg.data.img_size[0]), int(self._cfg.data.img_size[1]), self.device)
         preps = [self.preprocess(img, pts) for img, pts in zip(imgs, points_list)]
         jobs, spans = [], []
         for batches, _, dataset, _ in preps:
@@ -351,7 +349,7 @@ class TextRecognizer(BaseModule):
                 rep = type(self.model)(self.model.cfg).load_state_dict(self.model._sd).to(self.device)
                 rep._source_sd = self.model._sd
                 rep.tokenizer = self.tokenizer
-                rep.reserve(self.MAX_LINES_PER_FORWARD, int(self._cfg.data.img_size[0]), int(self._cfg.data.img_size[1]), self.device)
+                rep.reserve_once(self.MAX_LINES_PER_FORWARD, int(self._cfg.data.img_size[0]), int(self._cfg.data.img_size[1]), self.device)
                 self._replicas[lane] = rep
             if rep._conv_split != self.model._conv_split:
                 rep.set_conv_split(self.model._conv_split)
