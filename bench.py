@@ -77,7 +77,7 @@ def kernel_source_sha():
     import hashlib
 
     h = hashlib.sha256()
-    for name in ("ymk_conv.hip", "ymk_conv_split.hip", "ymk_conv_kernel.h"):
+    for name in ("ymk_conv.hip", "ymk_conv_split.hip", "ymk_conv_dma.hip", "ymk_conv_kernel.h"):
         with open(os.path.join(ROOT, "yomitoku_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

@@ -43,7 +43,7 @@ def test_bf16_split_conv_matches_fp64_and_fp32_kernels(dev, case):
         _lib.debug_option("conv_split", -1)
     err = {s: float((o - ref).abs().max()) / scale for s, o in outs.items()}
     print(case, {s: f"{e:.2e}" for s, e in err.items()})
-    assert err[0] < 2e-6
+    assert err[0] < 3e-6  # a k-ordered fmaf chain of up to 2304 terms
     assert err[3] < 4e-6, "three bf16 planes (6 MFMAs) must be fp32-grade"
     assert err[16] < 4e-6, "two fp16 planes (3 MFMAs): dropped terms are 2^-21 per product, below the fp32 accumulation's rounding"
     assert err[2] < 2.0 ** -14, "two bf16 planes (3 MFMAs): dropped terms are 2^-16 per product"
@@ -125,8 +125,9 @@ DMA_CASES = CASES + [  # n, h, w, cin, cout, k, stride, pad, dil, act, residual
 ]
 
 
+@pytest.mark.parametrize("tile", [20, 21])  # 256-row tiles / 8 waves / three stages; 128-row tiles / 4 waves / two stages
 @pytest.mark.parametrize("case", DMA_CASES)
-def test_f16_split_lds_dma_kernel_equals_the_register_staged_kernel(dev, case):
+def test_f16_split_lds_dma_kernel_equals_the_register_staged_kernel(dev, case, tile):
     """conv_f16_dma (ymk_conv_dma.hip: both operands by LDS-DMA, fp32 activations converted at the fragment read, three LDS
     stages, 256-row tiles) multiplies the same planes and adds each accumulator's terms in the same order as
     conv_igemm_split<FMT = 1>: every output bit must agree - which proves the swizzled source addressing, the zero fill of
@@ -147,8 +148,9 @@ def test_f16_split_lds_dma_kernel_equals_the_register_staged_kernel(dev, case):
     ref = {"relu": torch.relu, "none": lambda t: t, "gelu": torch.nn.functional.gelu, "silu": torch.nn.functional.silu}[act](ref)
     try:
         _lib.debug_option("conv_split", 16)
+        _lib.debug_option("conv_split_tile", 3)  # the register-staged kernel, whatever the automatic choice for this shape
         want = hipops.conv2d(x.to(dev), wt, sc, bi, r.to(dev) if res else None, stride, pad, dil, act).cpu()
-        _lib.debug_option("conv_split_tile", 20)
+        _lib.debug_option("conv_split_tile", tile)
         got = hipops.conv2d(x.to(dev), wt, sc, bi, r.to(dev) if res else None, stride, pad, dil, act).cpu()
         again = hipops.conv2d(x.to(dev), wt, sc, bi, r.to(dev) if res else None, stride, pad, dil, act).cpu()
     finally:

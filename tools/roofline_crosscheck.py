@@ -20,7 +20,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from _rocprof_io import counter_rows, kernel_rows  # noqa: E402
 
-CONV = ("ymk::conv_igemm<", "ymk::conv_splitk<")
+CONV = ("ymk::conv_igemm<", "ymk::conv_splitk<", "ymk::conv_igemm_split<", "ymk::conv_f16_dma<")
 
 
 def _is_conv(name):
@@ -59,13 +59,23 @@ def block_shape(line_path):
     return roof, pages, launches, tail
 
 
+def _bench_stamp():
+    """What bench.py compares before it quotes these numbers: the hash of the convolution kernels' sources and the operand
+    form ("conv_split") of the measured process (bench.py: kernel_source_sha / split_mode)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    return {"kernel_source_sha16": bench.kernel_source_sha(), "conv_split": bench.split_mode()}
+
+
 def traffic_report(roof, launches, tail, fetch_dir, write_dir, out_path):
     fetch, n_f = _counter_block(fetch_dir, "FETCH_SIZE", launches, tail)
     write, n_w = _counter_block(write_dir, "WRITE_SIZE", launches, tail)
     traffic = {
+        **_bench_stamp(),
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --roofline-only "
                   "--no-cpu-baseline; conv dispatches of the timed serial pass only",
-        "kernels": "conv_igemm<*> + conv_splitk<*>", "launches": launches,
+        "kernels": "conv_igemm_split<*> + conv_f16_dma<*> + conv_igemm<*> + conv_splitk<*>", "launches": launches,
         "conv_dispatches_in_fetch_pass": n_f, "conv_dispatches_in_write_pass": n_w,
         "fetch_bytes_per_launch_as_reported": round(fetch), "write_bytes_per_launch": round(write),
         "hbm_bytes_per_launch": round(2.0 * fetch + write),
@@ -101,6 +111,8 @@ def main(argv):
         "all_kernels_ms_per_page_in_block": round(all_kernels_ns / 1e6 / pages, 4),
         "conv_share_of_gpu_time_in_block": round(sum(dur) / all_kernels_ns, 4),
         "block_span_ms_per_page": round(span / 1e6 / pages, 4),
+        "absmax_pass_ms_per_page_in_block": round(sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in in_span
+                                                      if "k_absmax" in r["Kernel_Name"]) / 1e6 / pages, 4),
         "per_kernel_in_block": {k: {"calls": c, "total_ms": round(t / 1e6, 3), "avg_us": round(t / c / 1e3, 2)}
                                 for k, (c, t) in sorted(by_kernel.items(), key=lambda kv: -kv[1][1])},
     }

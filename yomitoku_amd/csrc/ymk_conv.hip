@@ -714,6 +714,12 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
   }
   k.fast = g_conv_fast.load(std::memory_order_relaxed);
 
+  {  // split operands (fp16 / bf16 planes) with fp32 accumulation for the launches that fill the chip - the models' default
+    int split = t_conv_split;
+    if (split < 0) split = g_conv_split.load(std::memory_order_relaxed);
+    if (split < 0) split = t_split_default;
+    if (split != 0 && t_split_ctx != nullptr && conv2d_split(s, k, w, split, t_split_ctx)) return;
+  }
   if (a.epi == EPI_ROWMAX) {  // fixed 64-column tiles (the caller sized the partial table for them), never split-K
     k.vec = 0;
     const int mt = (k.M + 63) / 64, nt = (k.Cout + ROWMAX_TILE_N - 1) / ROWMAX_TILE_N;
@@ -723,12 +729,6 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
     if (e) YMK_HIP(hipEventRecord(e->second, s));
     YMK_HIP(hipGetLastError());
     return;
-  }
-  {  // split operands (bf16 / fp16 planes) with fp32 accumulation for the launches that fill the chip (measurement / evaluation)
-    int split = t_conv_split;
-    if (split < 0) split = g_conv_split.load(std::memory_order_relaxed);
-    if (split < 0) split = t_split_default;
-    if (split != 0 && a.row_group == nullptr && t_split_ctx != nullptr && conv2d_split(s, k, w, split, t_split_ctx)) return;
   }
   // tile selection: wide tiles when there is enough work to fill 256 CUs x 2 blocks
   const long blocks128 = (long)((k.M + 127) / 128) * ((w.cout + 127) / 128);

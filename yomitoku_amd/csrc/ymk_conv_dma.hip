@@ -28,7 +28,6 @@ typedef _Float16 hf16x8_t __attribute__((ext_vector_type(8)));
 typedef float hf32x2_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-constexpr int DMA_BM = 256, DMA_WAVES = 8, DMA_NT = 64 * DMA_WAVES, DMA_NST = 3;
 
 __device__ __forceinline__ float2 dma_f16_scales(unsigned amax_bits) {  // as f16_scales of ymk_conv_split.hip
   int e = (int)(amax_bits >> 23);
@@ -54,17 +53,25 @@ __device__ __forceinline__ void split8(const f32x4 u, const f32x4 v, float sa, h
   lo = hf16x8_t{l[0].x, l[0].y, l[1].x, l[1].y, l[2].x, l[2].y, l[3].x, l[3].y};
 }
 
-template <int BN>
-__global__ __launch_bounds__(DMA_NT, 2) void conv_f16_dma(ConvK p, const uint4* __restrict__ wsplit, unsigned w_bytes) {
+// DMA_WAVES waves of 32 rows x BN columns (block tile 32 DMA_WAVES x BN), DMA_NST LDS stages of one 32-k tile, loads
+// DMA_NST - 1 tiles ahead.  <BN, 8, 3>: 256-row tiles, 144 KB, one block per CU.  <BN, 4, 2>: 128-row tiles, 68 KB, TWO blocks
+// per CU - another block's main loop covers a block's prologue and epilogue (what the short-K layers need).
+template <int BN, int DMA_WAVES, int DMA_NST>
+__global__ __launch_bounds__(64 * DMA_WAVES, 2) void conv_f16_dma(ConvK p, const uint4* __restrict__ wsplit, unsigned w_bytes) {
+  constexpr int DMA_BM = 32 * DMA_WAVES, DMA_NT = 64 * DMA_WAVES;
   constexpr int TN = BN / 32;                 // 32-column MFMA tiles of a wave
-  constexpr int A_STAGE = DMA_BM * 128;       // bytes: 256 rows x 32 fp32
+  constexpr int A_STAGE = DMA_BM * 128;       // bytes: BM rows x 32 fp32
   constexpr int B_STAGE = BN * 128;           // bytes: BN rows x 2 planes x 32 halves
   constexpr int STAGE_B = A_STAGE + B_STAGE;
-  constexpr int BI = BN / 64;                 // B DMA instructions per wave per K tile (8 rows each)
+  constexpr int BROWS = BN / DMA_WAVES;       // B rows a wave loads per K tile
+  constexpr int BI = BROWS / 8;               // B DMA instructions per wave per K tile (8 rows each)
   constexpr int NLOAD = 4 + BI;               // DMA instructions a wave issues per K tile
   constexpr int LDC = BN + 4;
-  static_assert(DMA_NST * STAGE_B >= DMA_BM * LDC * 4, "the stages must hold the fp32 output tile of the epilogue");
-  __shared__ __attribute__((aligned(16))) char lds[DMA_NST * STAGE_B];
+  constexpr int PD = DMA_NST - 1;             // prefetch distance in K tiles
+  constexpr int EPI_B = DMA_BM * LDC * 4;     // the fp32 output tile of the epilogue
+  constexpr int LDS_B = DMA_NST * STAGE_B > EPI_B ? DMA_NST * STAGE_B : EPI_B;
+  static_assert(BROWS % 8 == 0 && PD >= 1 && PD <= 2, "shape");
+  __shared__ __attribute__((aligned(16))) char lds[LDS_B];
 
   const int t = threadIdx.x, wv = t >> 6, lane = t & 63, li = lane & 31, lh = lane >> 5;
   const float2 sc = dma_f16_scales((unsigned)__builtin_amdgcn_readfirstlane((int)amax_read(p.amax, t)));
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(DMA_NT, 2) void conv_f16_dma(ConvK p, const uint4* 
   unsigned boff[BI];  // byte offset of the lane's 16 bytes of B within the weight panel, K tile 0
 #pragma unroll
   for (int j = 0; j < BI; ++j) {
-    const int row = (BN / DMA_WAVES) * wv + 8 * j + jr;  // BN / 8 rows of B per wave
+    const int row = BROWS * wv + 8 * j + jr;  // the wave's share of the B rows
     boff[j] = (unsigned)(n0 + row) * (unsigned)(ktiles * 128) + (unsigned)((js ^ ((row >> 1) & 7)) * 16);
   }
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(DMA_NT, 2) void conv_f16_dma(ConvK p, const uint4* 
 
   // K tile kt -> LDS stage st: 4 + BI LDS-DMA instructions of this wave
   auto issue = [&](int kt, int st) {
-    if (cur_cc == 0) {  // wave-uniform: a new filter tap
+    if (cur_cc == 0 || p.KH * p.KW > 1) {  // wave-uniform: a new filter tap - every K tile of a k x k layer (channel-major panels)
       const int dh = cur_kh * p.dil, dw = cur_kw * p.dil;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -140,14 +147,14 @@ __global__ __launch_bounds__(DMA_NT, 2) void conv_f16_dma(ConvK p, const uint4* 
       const bool chan_ok = cur_cc * 128 + (int)cbyte[i] < p.C * 4;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)(As + i * 1024), 16, (int)(chan_ok ? voff[i] : OOB_OFFSET), soff, 0, 0);
     }
-    char* Bs = lds + st * STAGE_B + A_STAGE + ((BN / DMA_WAVES) * wv) * 128;
+    char* Bs = lds + st * STAGE_B + A_STAGE + (BROWS * wv) * 128;
 #pragma unroll
     for (int j = 0; j < BI; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void*)(Bs + j * 1024), 16, (int)boff[j], kt * 128, 0, 0);
-    if (++cur_cc == p.ctiles) {
-      cur_cc = 0;
-      if (++cur_kw == p.KW) {
-        cur_kw = 0;
-        ++cur_kh;
+    if (++cur_kw == p.KW) {  // the taps of one 32-channel slice back to back (k_split_panel_f16: channel-major K order)
+      cur_kw = 0;
+      if (++cur_kh == p.KH) {
+        cur_kh = 0;
+        ++cur_cc;
       }
     }
   };
@@ -188,19 +195,20 @@ __global__ __launch_bounds__(DMA_NT, 2) void conv_f16_dma(ConvK p, const uint4* 
   };
 
   issue(0, 0);
-  if (ktiles > 1) issue(1, 1);
-  int st = 0, st2 = 2;  // stage of tile kt / of tile kt + 2
+  if (PD > 1 && ktiles > 1) issue(1, 1);
+  int st = 0, stp = PD;  // stage of tile kt / of tile kt + PD
   for (int kt = 0; kt < ktiles; ++kt) {
-    // tile kt has landed once this wave's own DMAs of it have (the younger tile's may stay in flight) and every wave has
-    // said so; the same barrier tells that every wave is done reading the stage tile kt + 2 is about to overwrite
-    if (kt + 1 < ktiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+    // tile kt has landed once this wave's own DMAs of it have (a younger tile's may stay in flight) and every wave has
+    // said so; the same barrier tells that every wave is done reading the stage tile kt + PD is about to overwrite
+    if (PD > 1 && kt + 1 < ktiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (PD == 1 && kt + 1 < ktiles) issue(kt + 1, stp);  // one tile ahead: as early as the barrier allows
     compute(st, 0);
-    if (kt + 2 < ktiles) issue(kt + 2, st2);  // behind the first step's MFMAs: the address arithmetic rides in their shadow
+    if (PD > 1 && kt + PD < ktiles) issue(kt + PD, stp);  // behind the first step's MFMAs: the address arithmetic rides in their shadow
     compute(st, 1);
     st = st == DMA_NST - 1 ? 0 : st + 1;
-    st2 = st2 == DMA_NST - 1 ? 0 : st2 + 1;
+    stp = stp == DMA_NST - 1 ? 0 : stp + 1;
   }
 
   // ---- epilogue: accumulators (times 1 / sa: exact) -> LDS as [256][BN + 4] fp32 -> the shared coalesced epilogue
@@ -217,18 +225,26 @@ __global__ __launch_bounds__(DMA_NT, 2) void conv_f16_dma(ConvK p, const uint4* 
   epilogue_tile<DMA_BM, BN, DMA_NT>(p, Cs, m0, n0, t);
 }
 
-template <int BN>
+template <int BN, int WAVES, int NST>
 static void launch_dma(hipStream_t s, ConvK& k, const void* wsplit, size_t w_bytes) {
-  const int mt = (k.M + DMA_BM - 1) / DMA_BM, nt = (k.Cout + BN - 1) / BN;
+  const int mt = (k.M + 32 * WAVES - 1) / (32 * WAVES), nt = (k.Cout + BN - 1) / BN;
   k.ntiles_n = nt;
-  hipLaunchKernelGGL((conv_f16_dma<BN>), dim3(mt * nt), dim3(DMA_NT), 0, s, k, reinterpret_cast<const uint4*>(wsplit), (unsigned)w_bytes);
+  hipLaunchKernelGGL((conv_f16_dma<BN, WAVES, NST>), dim3(mt * nt), dim3(64 * WAVES), 0, s, k, reinterpret_cast<const uint4*>(wsplit), (unsigned)w_bytes);
 }
 
-// taken for the shapes it is built for; the caller (conv2d_split) has resolved the panel and the input's max|x| record
-bool conv2d_f16_dma(hipStream_t s, ConvK& k, const void* wsplit, size_t w_bytes, bool narrow) {
+// the caller (conv2d_split) has resolved the panel and the input's max|x| record.  rows: 128 (4 waves, two stages, two or three
+// blocks per CU: the form the dispatch uses) or 256 (8 waves, three stages, one block per CU: kept for A/B runs - level on the
+// long-K layers, behind wherever a block's prologue / epilogue weighs, profiles/r04_conv_sweep_f16_lds_dma.txt; a three-stage
+// 128 x 64 form measured no better than the two-stage one and was dropped)
+bool conv2d_f16_dma(hipStream_t s, ConvK& k, const void* wsplit, size_t w_bytes, bool narrow, int rows) {
   if (w_bytes >= (size_t)OOB_OFFSET) return false;
-  if (narrow) launch_dma<64>(s, k, wsplit, w_bytes);
-  else launch_dma<128>(s, k, wsplit, w_bytes);
+  if (rows == 128) {
+    if (narrow) launch_dma<64, 4, 2>(s, k, wsplit, w_bytes);
+    else launch_dma<128, 4, 2>(s, k, wsplit, w_bytes);
+  } else {
+    if (narrow) launch_dma<64, 8, 3>(s, k, wsplit, w_bytes);
+    else launch_dma<128, 8, 3>(s, k, wsplit, w_bytes);
+  }
   return true;
 }
 

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64 * WM * WN, (bf16_waves_per_simd<BM, BN, WM, WN, 
   auto load_stage = [&](int st, int set) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      if (cur_cc == 0) {  // wave-uniform: a new filter tap
+      if (FMT == 1 ? (cur_cc == 0 || p.KH * p.KW > 1) : cur_cc == 0) {  // wave-uniform: a new filter tap (fp16 panels: every K tile of a k x k layer)
         const int dh = cur_kh * p.dil, dw = cur_kw * p.dil;
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
@@ -195,7 +195,15 @@ __global__ __launch_bounds__(64 * WM * WN, (bf16_waves_per_simd<BM, BN, WM, WN, 
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(chan_ok ? voff[i] : OOB_OFFSET), soff, 0);
         ra[set][ks][i] = __builtin_bit_cast(f32x4, v);
       }
-      if (++cur_cc == p.ctiles) {
+      if (FMT == 1) {  // channel-major panels: the taps of one channel slice back to back
+        if (++cur_kw == p.KW) {
+          cur_kw = 0;
+          if (++cur_kh == p.KH) {
+            cur_kh = 0;
+            ++cur_cc;
+          }
+        }
+      } else if (++cur_cc == p.ctiles) {
         cur_cc = 0;
         if (++cur_kw == p.KW) {
           cur_kw = 0;
@@ -410,8 +418,12 @@ __global__ void k_split_panel(const float* __restrict__ w, unsigned short* __res
 
 // fp16 form: one block per panel row.  The row is scaled by the power of two that puts its largest |w| into [2^14, 2^15);
 // scale_out[row] = (BatchNorm scale of the channel, or 1) / that power - what the epilogue multiplies the accumulators by.
+// K ORDER of the fp16 panels: CHANNEL-major - K tile (channel slice cc, tap) sits at cc * taps + tap, where the fp32 panel has
+// it at tap * ctiles + cc.  The kernels then walk the taps of one 32-channel slice back to back: the nine shifted windows of
+// a 3 x 3 layer overlap in all but one pixel column / row, and with only 128 bytes per pixel live they stay in L1 / L2, where
+// the tap-major order streams the whole Cin x 4 B of every pixel past between two visits (section 9 item 3 of round 3).
 __global__ void k_split_panel_f16(const float* __restrict__ w, unsigned short* __restrict__ out, int kpad, const float* __restrict__ scale,
-                                  int cout, float* __restrict__ scale_out) {
+                                  int cout, float* __restrict__ scale_out, int taps, int ctiles) {
   __shared__ unsigned red[4];
   const int row = blockIdx.x, t = threadIdx.x;
   const float* wr = w + (size_t)row * kpad;
@@ -424,7 +436,9 @@ __global__ void k_split_panel_f16(const float* __restrict__ w, unsigned short* _
   m = max(max(red[0], red[1]), max(red[2], red[3]));
   const float2 sc = f16_scales(m);
   for (int k = t; k < kpad; k += 256) {
-    const int kt = k >> 5, kk = k & 31;
+    const int kt_src = k >> 5, kk = k & 31;
+    const int tap = kt_src / ctiles, cc = kt_src - tap * ctiles;
+    const int kt = cc * taps + tap;
     float r = wr[k] * sc.x;
     const _Float16 h = (_Float16)r;
     r -= (float)h;
@@ -519,7 +533,7 @@ class SplitCtx {
     if (code == SPLIT_F16X2) {
       pn.scale = reinterpret_cast<float*>(alloc(real * sizeof(float)));
       hipLaunchKernelGGL(k_split_panel_f16, dim3((unsigned)real), dim3(256), 0, s, w.w, reinterpret_cast<unsigned short*>(pn.planes), w.kpad,
-                         w.scale, w.cout, pn.scale);
+                         w.scale, w.cout, pn.scale, w.kh * w.kw, w.ctiles);
     } else {
       const int blocks = (int)((n + 255) / 256);
       if (ns == 2) hipLaunchKernelGGL(k_split_panel<2>, dim3(blocks), dim3(256), 0, s, w.w, reinterpret_cast<unsigned short*>(pn.planes), n, w.kpad);
@@ -660,29 +674,48 @@ static void dispatch_f16(hipStream_t s, ConvK& k, const void* ws, int tile, bool
   }
 }
 
-bool conv2d_f16_dma(hipStream_t s, ConvK& k, const void* wsplit, size_t w_bytes, bool narrow);  // ymk_conv_dma.hip
+bool conv2d_f16_dma(hipStream_t s, ConvK& k, const void* wsplit, size_t w_bytes, bool narrow, int rows);  // ymk_conv_dma.hip
 
 bool conv2d_split(hipStream_t s, ConvK& k, const ConvW& w, int code, SplitCtx* ctx) {
   if (w.mode != 0 || ctx == nullptr || (code != 2 && code != 3 && code != SPLIT_F16X2)) return false;  // 4-channel stems keep the fp32 kernel
-  const long blocks128 = (long)((k.M + 127) / 128) * ((w.cout + 127) / 128);
-  if (blocks128 < 256) return false;  // grid-starved launches keep the fp32 paths (split-K / small tiles)
+  // launches that fill the chip: >= 256 tiles of 128 x 128, or - Cout > 64 - of 128 x 64 (a batch-2 RT-DETRv2 stage, the
+  // greedy loop's vocabulary head at a few hundred rows); the rest keeps the fp32 paths (split-K / small tiles)
+  const bool rowmax = k.epi == EPI_ROWMAX;  // (max, column) per 64-column tile: the 128 x 64 tile
+  const long mt128 = (k.M + 127) / 128;
+  const long blocks128 = mt128 * ((w.cout + 127) / 128), blocks64 = mt128 * ((w.cout + 63) / 64);
+  bool few = false;
+  if (blocks128 < 256) {
+    if (blocks64 < 256) return false;
+    few = true;
+  }
   const SplitCtx::Panels& pn = ctx->panels(s, w, code);
   int tile = g_split_tile.load(std::memory_order_relaxed);
+  const bool auto_tile = tile == 0;
   if (tile == 0) tile = code == 3 ? 2 : 3;
-  const bool narrow = w.cout <= 64 || tile == 1;
-  if (code == SPLIT_F16X2 && tile == 20) {  // the LDS-DMA form (ymk_conv_dma.hip): 256 x 128 / 256 x 64 tiles
+  const bool narrow = w.cout <= 64 || tile == 1 || rowmax || few;
+  // the LDS-DMA form (ymk_conv_dma.hip; 128-row tiles, two or three blocks per CU) where it measured ahead of the
+  // register-staged kernel (profiles/r04_conv_sweep_f16_lds_dma.txt): every k x k layer (+2..17 %: the 3 x 3 layers of all
+  // three backbones and the decoders), long-K 1 x 1 reductions (+3..7 %) and the 64-column 1 x 1 layers (+1..6 %).  Wide 1 x 1
+  // layers with short K - the expands with their residual reads, the ViT GEMMs - lose 10-35 % there (their time is the
+  // epilogue's memory traffic, which sixteen-wave blocks keep more of in flight) and stay on the register-staged kernel.
+  const int taps = k.KH * k.KW;
+  const bool dma_shape = taps > 1 || (k.Kpad >= 1024 && w.cout <= 512) || w.cout <= 64;
+  const bool dma_fills = mt128 * ((w.cout + 127) / 128) >= 256 || (w.cout <= 64 && mt128 >= 256);
+  if (code == SPLIT_F16X2 && !rowmax && k.row_group == nullptr && (tile == 20 || tile == 21 || (auto_tile && dma_shape && dma_fills))) {
     k.scale = pn.scale;
     const bool nar = w.cout <= 64;
+    const int rows = tile == 20 ? 256 : 128;
     k.ntiles_n = (k.Cout + (nar ? 64 : 128) - 1) / (nar ? 64 : 128);
-    auto* e = conv_prof_open(s, k, 256, nar ? 64 : 128, ((k.M + 255) / 256) * k.ntiles_n, 161);
+    auto* e = conv_prof_open(s, k, rows, nar ? 64 : 128, ((k.M + rows - 1) / rows) * k.ntiles_n, 161);
     if (k.amax == nullptr) k.amax = ctx->absmax(s, k);
     const size_t w_bytes = (size_t)((w.cout + 255) / 256 * 256) * w.kpad * 2 * 2;
-    const bool taken = conv2d_f16_dma(s, k, pn.planes, w_bytes, nar);
+    const bool taken = conv2d_f16_dma(s, k, pn.planes, w_bytes, nar, rows);
     if (e) YMK_HIP(hipEventRecord(e->second, s));
     YMK_HIP(hipGetLastError());
     YMK_CHECK(taken, "conv_f16_dma refused a launch");
     return true;
   }
+  if (tile == 20 || tile == 21) tile = 3;
   if (code == SPLIT_F16X2) {
     k.scale = pn.scale;
     dispatch_f16(s, k, pn.planes, tile, narrow, ctx);

@@ -462,9 +462,9 @@ class ParseqModel : public Model {
         // the vocabulary head skips the M tiles whose rows all sit in mini-batches that finished at an earlier step
         const int* open_prev = (gop && i > 0) ? gop + (size_t)(i - 1) * ng : nullptr;
         if (ar_rowmax)
-          gemm(s, t1, B, D, D, head_, ACT_NONE, nullptr, 0, armax, 2 * head_tiles, open_prev ? gid : nullptr, open_prev, EPI_ROWMAX);
+          gemm(s, t1, B, D, D, head_, ACT_NONE, nullptr, 0, armax, 2 * head_tiles, open_prev ? gid : nullptr, open_prev, EPI_ROWMAX, dn_rec_);
         else
-          gemm(s, t1, B, D, D, head_, ACT_NONE, nullptr, 0, arlog + (size_t)i * C, NS * C, open_prev ? gid : nullptr, open_prev);
+          gemm(s, t1, B, D, D, head_, ACT_NONE, nullptr, 0, arlog + (size_t)i * C, NS * C, open_prev ? gid : nullptr, open_prev, EPI_STORE, dn_rec_);
       } else {
         // content row i (token tok[:, i]) -> norm_c -> K|V cache row i
         ctx_embed_ln(s, tok, NS, i, 1, emb_, posq_, ncg_, ncb_, 1e-5f, cn, NS, D, B);
