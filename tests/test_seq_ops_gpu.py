@@ -50,6 +50,36 @@ def test_flash_attention(dev, b, heads, hd, lq, lk):
     _close(hipops.attention(q.to(dev), k.to(dev), v.to(dev), heads), _ref_attn(q, k, v, heads), 2e-5)
 
 
+@pytest.mark.parametrize("b,heads,hd,lq,lk", [(2, 6, 32, 184, 184), (1, 8, 64, 100, 100), (3, 8, 96, 40, 40), (2, 6, 32, 800, 800),
+                                              (2, 8, 32, 101, 37), (2, 8, 48, 100, 100), (1, 8, 96, 400, 400)])
+@pytest.mark.parametrize("gain", [1.0, 300.0, 1e-3])
+def test_flash_attention_fp16_split_products(dev, b, heads, hd, lq, lk, gain):
+    """k_flash_attn_f16: both products of the attention as fp16-split MFMAs (two scaled fp16 planes per fp32 operand, three
+    MFMAs per 16-k step, fp32 accumulate; P in (0, 1] scaled by 2^14) - what the encoders run when their convolutions do.  The
+    same tolerance as the exact-fp32 kernel against the float64-free torch reference, at operand magnitudes 1e-3 ... 300
+    (the scales follow max|x| of q, k and v: `gain` scales k and v, q is scaled back so that the logits stay the same)."""
+    from yomitoku_amd import _lib
+    from tests import hipops
+
+    g = torch.Generator().manual_seed(lq * 7 + hd)
+    d = heads * hd
+    q, k, v = (torch.randn(b, n, d, generator=g) for n in (lq, lk, lk))
+    q, k, v = q * 2.0 / gain, k * gain, v * gain
+    ref = _ref_attn(q.double(), k.double(), v.double(), heads).float()
+    try:
+        _lib.debug_option("conv_split", 16)
+        got = hipops.attention(q.to(dev), k.to(dev), v.to(dev), heads)
+        again = hipops.attention(q.to(dev), k.to(dev), v.to(dev), heads)
+    finally:
+        _lib.debug_option("conv_split", -1)
+    exact = hipops.attention(q.to(dev), k.to(dev), v.to(dev), heads)
+    assert torch.equal(got, again)
+    scale = float(ref.abs().max())
+    e_split, e_exact = float((got.cpu() - ref).abs().max()) / scale, float((exact.cpu() - ref).abs().max()) / scale
+    print(f"hd {hd} lq {lq} lk {lk} gain {gain}: fp16-split {e_split:.2e}, exact fp32 {e_exact:.2e}")
+    assert e_split < 2e-5 and e_split < 4 * e_exact + 2e-6
+
+
 @pytest.mark.parametrize("b,heads,hd,lq,lk", [(3, 6, 32, 1, 9), (2, 8, 64, 101, 18), (4, 6, 32, 1, 736), (2, 8, 96, 101, 101)])
 def test_small_attention_with_masks(dev, b, heads, hd, lq, lk):
     from tests import hipops

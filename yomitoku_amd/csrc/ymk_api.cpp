@@ -254,7 +254,19 @@ int ymk_op_attention(const float* q_dev, const float* k_dev, const float* v_dev,
   if (use_small || mask_qk_dev || kpm_dev)
     ymk::small_attention((hipStream_t)stream, q_dev, k_dev, v_dev, o_dev, b, heads, lq, lk, hd, D, D, D, D, (long)lq * D,
                          (long)lk * D, (long)lk * D, (long)lq * D, scale, mask_qk_dev, lk, kpm_dev, lk);
-  else
+  else if (ymk::conv_effective_split() == ymk::SPLIT_F16X2) {
+    // ymk_debug_option("conv_split", 16): the fp16-split form, its three max|x| records measured here (tests)
+    unsigned* rec = nullptr;
+    YMK_HIP(hipMalloc((void**)&rec, 3 * ymk::AMAX_REC_WORDS * sizeof(unsigned)));
+    YMK_HIP(hipMemsetAsync(rec, 0, 3 * ymk::AMAX_REC_WORDS * sizeof(unsigned), (hipStream_t)stream));
+    ymk::absmax_record((hipStream_t)stream, q_dev, (size_t)b * lq * D, rec);
+    ymk::absmax_record((hipStream_t)stream, k_dev, (size_t)b * lk * D, rec + ymk::AMAX_REC_WORDS);
+    ymk::absmax_record((hipStream_t)stream, v_dev, (size_t)b * lk * D, rec + 2 * ymk::AMAX_REC_WORDS);
+    ymk::flash_attention((hipStream_t)stream, q_dev, k_dev, v_dev, o_dev, b, heads, lq, lk, hd, D, D, D, D, (long)lq * D,
+                         (long)lk * D, (long)lk * D, (long)lq * D, scale, nullptr, rec, rec + ymk::AMAX_REC_WORDS, rec + 2 * ymk::AMAX_REC_WORDS);
+    YMK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    YMK_HIP(hipFree(rec));
+  } else
     ymk::flash_attention((hipStream_t)stream, q_dev, k_dev, v_dev, o_dev, b, heads, lq, lk, hd, D, D, D, D, (long)lq * D,
                          (long)lk * D, (long)lk * D, (long)lq * D, scale);
   YMK_API_END

@@ -175,6 +175,11 @@ class ConvSplitScope {
   SplitCtx* prev_ctx_;
 };
 
+// the "conv_split" code conv2d / gemm launches of the calling thread resolve to right now (scope, process-wide option, default)
+int conv_effective_split();
+// max|x| over n floats (n % 4 == 0, 16-byte aligned) into word 0 of the zeroed record rec (ymk_conv_split.hip; tests / tools)
+void absmax_record(hipStream_t s, const float* x, size_t n, unsigned* rec);
+
 // out must be pre-shaped (n, oh, ow, cout[, ld]); for EPI_DECONV2X2 out is (n, 2h, 2w, cout/4).
 void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, const Tensor& out);
 

@@ -476,6 +476,13 @@ ConvSplitScope::~ConvSplitScope() {
   t_split_ctx = prev_ctx_;
 }
 
+int conv_effective_split() {
+  int split = t_conv_split;
+  if (split < 0) split = g_conv_split.load(std::memory_order_relaxed);
+  if (split < 0) split = t_split_default;
+  return split;
+}
+
 bool conv_debug_option(const std::string& key, int value) {
   if (key == "splitk_force") g_splitk_force = value;
   else if (key == "no_splitk") g_no_splitk = value;

@@ -488,6 +488,13 @@ __global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ in, si
   if (t == 0) atomicMax(slot, max(max(red[0], red[1]), max(red[2], red[3])));
 }
 
+void absmax_record(hipStream_t s, const float* x, size_t n, unsigned* rec) {
+  const size_t items = n / 4;
+  const int blocks = (int)std::min<size_t>(1024, (items + 1023) / 1024);
+  hipLaunchKernelGGL(k_absmax, dim3(blocks), dim3(256), 0, s, x, items, 1, 4, rec, rec + AMAX_LINE_WORDS);  // (clears a word nobody reads)
+  YMK_HIP(hipGetLastError());
+}
+
 // ---- self-check of the producers' records (ymk_debug_option("amax_check", 1); tests/test_conv_split_gpu.py): a launch whose
 // input came with a record ALSO makes the pass, and a one-wave kernel compares the two: counters[0] = launches checked,
 // [1] = records BELOW the true max|x| (a stale or incomplete record: the fp16 planes may overflow - a bug), [2] = records more

@@ -277,10 +277,11 @@ class ParseqModel : public Model {
     // max|x| records of the GEMM inputs (fp16-split launches: the refinement pass's 60 000 rows): LayerNorm outputs have
     // static ones, the cross-attention output is a convex combination of memory V rows, the FFN hidden state gets one
     ln(s, q, n1g_, n1b_, 1e-5f, t, M, D);
-    gemm(s, t, M, D, D, ca_q_, ACT_NONE, nullptr, 0, t2, D, nullptr, nullptr, EPI_STORE, n1_rec_);
+    unsigned* q_rec = Lq >= 32 ? arena.amax_next() : nullptr;  // the refinement pass: bounds the queries for the fp16-split attention
+    gemm(s, t, M, D, D, ca_q_, ACT_NONE, nullptr, 0, t2, D, nullptr, nullptr, EPI_STORE, n1_rec_, q_rec);
     if (Lq >= 32)
       flash_attention(s, t2, memkv, memkv + D, t, B, dh_, Lq, L, hd, D, 2 * D, 2 * D, D, (long)Lq * D, (long)L * 2 * D,
-                      (long)L * 2 * D, (long)Lq * D, scale, mem);
+                      (long)L * 2 * D, (long)Lq * D, scale, mem, q_rec, memkv_rec_, memkv_rec_);
     else
       small_attention(s, t2, memkv, memkv + D, t, B, dh_, Lq, L, hd, D, 2 * D, 2 * D, D, (long)Lq * D, (long)L * 2 * D,
                       (long)L * 2 * D, (long)Lq * D, scale, nullptr, 0, nullptr, 0, mem);
@@ -408,7 +409,7 @@ class ParseqModel : public Model {
       ln(s, xs, b.ln1g, b.ln1b, 1e-6f, y, M, D);
       gemm(s, y, M, D, D, b.qkv, ACT_NONE, nullptr, 0, qkv, 3 * D, nullptr, nullptr, EPI_STORE, b.ln1_rec, qkv_rec);
       flash_attention(s, qkv, qkv + D, qkv + 2 * D, att, B, eh_, L, L, hd, 3 * D, 3 * D, 3 * D, D, (long)L * 3 * D,
-                      (long)L * 3 * D, (long)L * 3 * D, (long)L * D, scale, enc_t);
+                      (long)L * 3 * D, (long)L * 3 * D, (long)L * D, scale, enc_t, qkv_rec, qkv_rec, qkv_rec);
       gemm(s, att, M, D, D, b.proj, ACT_NONE, xs, D, xs, D, nullptr, nullptr, EPI_STORE, qkv_rec);
       ln(s, xs, b.ln2g, b.ln2b, 1e-6f, y, M, D);
       gemm(s, y, M, D, D, b.fc1, ACT_GELU, nullptr, 0, hbuf, b.fc1.cout, nullptr, nullptr, EPI_STORE, b.ln2_rec, h_rec);

@@ -18,7 +18,10 @@ struct SeqTab {
 // O[b, q, h*hd:(h+1)*hd] = softmax(scale * Q K^T) V   (no mask; keys 0..Lk-1)
 void flash_attention(hipStream_t s, const float* q, const float* k, const float* v, float* o, int B, int H, int Lq, int Lk,
                      int hd, int ldq, int ldk, int ldv, int ldo, long bsq, long bsk, long bsv, long bso, float scale,
-                     const SeqTab* tab = nullptr);
+                     const SeqTab* tab = nullptr, const unsigned* amax_q = nullptr, const unsigned* amax_k = nullptr,
+                     const unsigned* amax_v = nullptr);
+// (amax_q / amax_k / amax_v: max|x| records - ymk_common.h - bounding q, k and v: with all three, and the fp16 split in force for the
+// calling thread's convolutions, both products of the attention run as fp16-split MFMAs too; otherwise exact fp32)
 // same contract plus boolean masks (non-zero = blocked), for few queries / short key lists
 void small_attention(hipStream_t s, const float* q, const float* k, const float* v, float* o, int B, int H, int Lq, int Lk,
                      int hd, int ldq, int ldk, int ldv, int ldo, long bsq, long bsk, long bsv, long bso, float scale,

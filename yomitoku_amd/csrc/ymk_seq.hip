@@ -114,6 +114,8 @@ struct AttnP {
   // koff/klen: keys and values of sample b start at row koff[b] and number klen[b]; qoff/qlen: the same for the
   // queries and the output rows.  Null = the uniform strided form.
   const int *qoff, *qlen, *koff, *klen;
+  // fp16-split form only (k_flash_attn_f16): max|x| records (ymk_common.h) bounding q, k and v
+  const unsigned *amax_q, *amax_k, *amax_v;
 };
 
 // HD: head dim as laid out in LDS / the accumulators (a multiple of 32); HDR <= HD: the real head dim (a multiple of 8).
@@ -276,13 +278,231 @@ __global__ __launch_bounds__(256, 1) void k_flash_attn(AttnP p) {
   }
 }
 
+// ---------------------------------------------------------------- flash attention, fp16-split operands (round 4)
+// The same algorithm with both products on the 16-bit MFMA pipe, fp32-grade: S^T = K Q^T and O^T += V^T P^T multiply
+// fp32 operands as two scaled fp16 planes each (three v_mfma_f32_32x32x16_f16 per 16-k step: lo x hi, hi x lo, hi x hi -
+// ymk_conv_split.hip has the error analysis: products to 2^-21), fp32 accumulate, softmax arithmetic in fp32 as before.
+// Scales (powers of two, exact): q (times the softmax scale), k and v each by the one that puts the max|x| record of their
+// producer into [2^14, 2^15), P in (0, 1] by 2^14.  The D layout of S^T puts keys
+// (r & 3) + 8 (r >> 2) + 4 lh into register r of lane half lh: registers 8 j .. 8 j + 7 ARE the lane's eight k values of
+// 16-key step j of the P^T operand, provided V^T is gathered with the same key order - so P never leaves registers here
+// either.  32 x 32 x 16 MFMAs: 6 per 32-key sub-tile per 16 head dims of Q K^T ... 12 + 6 NDC instead of 4 HDR / 2 + 16 NDC
+// twice-as-long fp32 ones.
+typedef _Float16 ah16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 ah16x8 __attribute__((ext_vector_type(8)));
+typedef float af32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float2 attn_f16_scales(unsigned amax_bits) {  // as f16_scales of ymk_conv_split.hip
+  int e = (int)(amax_bits >> 23);
+  e = e < 27 ? 27 : (e > 227 ? 227 : e);
+  float2 r;
+  r.x = __uint_as_float((unsigned)(268 - e) << 23);
+  r.y = __uint_as_float((unsigned)(e - 14) << 23);
+  return r;
+}
+// 8 floats times the power of two sc -> hi / lo planes
+__device__ __forceinline__ void attn_split8(const float (&x)[8], float sc, ah16x8& hi, ah16x8& lo) {
+  ah16x2 h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    af32x2 v = {x[2 * i] * sc, x[2 * i + 1] * sc};
+    h[i] = __builtin_convertvector(v, ah16x2);
+    v -= __builtin_convertvector(h[i], af32x2);  // exact
+    l[i] = __builtin_convertvector(v, ah16x2);
+  }
+  hi = ah16x8{h[0].x, h[0].y, h[1].x, h[1].y, h[2].x, h[2].y, h[3].x, h[3].y};
+  lo = ah16x8{l[0].x, l[0].y, l[1].x, l[1].y, l[2].x, l[2].y, l[3].x, l[3].y};
+}
+
+template <int HD, int HDR = HD>
+__global__ __launch_bounds__(256, (HD <= 32 ? 3 : (HD <= 64 ? 2 : 1))) void k_flash_attn_f16(AttnP p) {
+  constexpr int KT = 64;
+  constexpr int LDH = HD + 4;
+  constexpr int NKS = HDR / 16;    // 16-k steps of the QK^T product
+  constexpr int NDC = HD / 32;
+  constexpr int LPT = (KT * HDR / 4) / 256;
+  static_assert(HD % 32 == 0 && HDR % 16 == 0 && HDR <= HD && (KT * HDR / 4) % 256 == 0, "head dim");
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * KT * LDH];
+
+  const int t = threadIdx.x, wv = t >> 6, lane = t & 63, li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wv * 32;
+  const float* qb = p.q + (size_t)b * p.bsq + h * HDR;
+  const float* kb = p.k + (size_t)b * p.bsk + h * HDR;
+  const float* vb = p.v + (size_t)b * p.bsv + h * HDR;
+  float* ob = p.o + (size_t)b * p.bso + h * HDR;
+  int Lq = p.Lq, Lk = p.Lk;
+  if (p.koff) {
+    const size_t r = (size_t)p.koff[b];
+    kb = p.k + r * p.ldk + h * HDR;
+    vb = p.v + r * p.ldv + h * HDR;
+    Lk = p.klen[b];
+  }
+  if (p.qoff) {
+    const size_t r = (size_t)p.qoff[b];
+    qb = p.q + r * p.ldq + h * HDR;
+    ob = p.o + r * p.ldo + h * HDR;
+    Lq = p.qlen[b];
+  }
+  if ((int)blockIdx.x * 128 >= Lq) return;  // block-uniform: the grid is sized for the longest sample
+
+  const float2 cq = attn_f16_scales((unsigned)__builtin_amdgcn_readfirstlane((int)amax_read(p.amax_q, t)));
+  const float2 ck = attn_f16_scales((unsigned)__builtin_amdgcn_readfirstlane((int)amax_read(p.amax_k, t)));
+  const float2 cv = attn_f16_scales((unsigned)__builtin_amdgcn_readfirstlane((int)amax_read(p.amax_v, t)));
+  const float s_q = cq.x, s_k = ck.x, s_v = cv.x;
+  const float s_unscale = cq.y * ck.y;                // S = sacc / (s_q s_k)
+  const float o_unscale = cv.y * (1.f / 16384.f);     // O = oacc / (s_v 2^14)
+
+  // this lane's query row, times the softmax scale (<= 1: the launcher checks) and s_q, as planes: d = ks*16 + 8*lh + e
+  ah16x8 qh[NKS], ql[NKS];
+  {
+    const int qi = min(q0 + li, Lq - 1);
+    const float* qr = qb + (size_t)qi * p.ldq;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(qr + ks * 16 + lh * 8);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(qr + ks * 16 + lh * 8 + 4);
+      const float x[8] = {a.x * p.scale, a.y * p.scale, a.z * p.scale, a.w * p.scale, c.x * p.scale, c.y * p.scale, c.z * p.scale, c.w * p.scale};
+      attn_split8(x, s_q, qh[ks], ql[ks]);
+    }
+  }
+
+  f32x16 oacc[NDC];
+#pragma unroll
+  for (int dc = 0; dc < NDC; ++dc)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[dc][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  f32x4 rk[LPT], rv[LPT];
+  auto load_kv = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+      const int idx = t + 256 * i;
+      const int row = idx / (HDR / 4), c4 = idx - row * (HDR / 4);
+      const int key = min(k0 + row, Lk - 1);
+      rk[i] = *reinterpret_cast<const f32x4*>(kb + (size_t)key * p.ldk + c4 * 4);
+      rv[i] = *reinterpret_cast<const f32x4*>(vb + (size_t)key * p.ldv + c4 * 4);
+    }
+  };
+  auto store_kv = [&](int buf) {
+    float* Ks = lds + buf * (2 * KT * LDH);
+    float* Vs = Ks + KT * LDH;
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+      const int idx = t + 256 * i;
+      const int row = idx / (HDR / 4), c4 = idx - row * (HDR / 4);
+      *reinterpret_cast<f32x4*>(Ks + row * LDH + c4 * 4) = rk[i];
+      *reinterpret_cast<f32x4*>(Vs + row * LDH + c4 * 4) = rv[i];
+    }
+  };
+
+  const int ntiles = (Lk + KT - 1) / KT;
+  load_kv(0);
+  store_kv(0);
+  __syncthreads();
+  for (int tt = 0; tt < ntiles; ++tt) {
+    const int buf = tt & 1;
+    if (tt + 1 < ntiles) load_kv((tt + 1) * KT);
+    const float* Ks = lds + buf * (2 * KT * LDH);
+    const float* Vs = Ks + KT * LDH;
+#pragma unroll
+    for (int sub = 0; sub < (q0 < Lq ? KT / 32 : 0); ++sub) {
+      const int kbase = tt * KT + sub * 32;
+      if (kbase >= Lk) break;  // wave-uniform
+      // ---- S^T[key][q] for 32 keys x 32 queries: A = K rows (key li, d = ks*16 + 8*lh + e), B = the query planes
+      f32x16 sacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+      const float* kr = Ks + (sub * 32 + li) * LDH + lh * 8;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(kr + ks * 16);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(kr + ks * 16 + 4);
+        const float x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+        ah16x8 kh, kl;
+        attn_split8(x, s_k, kh, kl);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sacc, 0, 0, 0);
+      }
+      // ---- online softmax for this lane's query
+      float mt = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        sacc[r] = key >= Lk ? -INFINITY : sacc[r] * s_unscale;
+        mt = fmaxf(mt, sacc[r]);
+      }
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float m_new = fmaxf(m_run, mt);  // finite: every tile has >= 1 valid key
+      const float alpha = __expf(m_run - m_new);
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sacc[r] = __expf(sacc[r] - m_new);
+        ps += sacc[r];
+      }
+      ps += __shfl_xor(ps, 32, 64);
+      l_run = l_run * alpha + ps;
+      m_run = m_new;
+      // ---- P^T planes: registers 8 j .. 8 j + 7 are the lane's eight k values of 16-key step j
+      ah16x8 ph[2], pl[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float x[8] = {sacc[8 * j], sacc[8 * j + 1], sacc[8 * j + 2], sacc[8 * j + 3], sacc[8 * j + 4], sacc[8 * j + 5], sacc[8 * j + 6], sacc[8 * j + 7]};
+        attn_split8(x, 16384.f, ph[j], pl[j]);
+      }
+      // ---- O^T[d][q] = alpha * O^T + V^T P^T: A = V^T (d = dc*32 + li; the same key order as P's registers)
+#pragma unroll
+      for (int dc = 0; dc < NDC; ++dc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dc][r] *= alpha;
+        const float* vr = Vs + (sub * 32 + 4 * lh) * LDH + dc * 32 + li;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float x[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int r = 8 * j + e;
+            x[e] = vr[((r & 3) + 8 * (r >> 2)) * LDH];
+          }
+          ah16x8 vh, vl;
+          attn_split8(x, s_v, vh, vl);
+          oacc[dc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[j], oacc[dc], 0, 0, 0);
+          oacc[dc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[j], oacc[dc], 0, 0, 0);
+          oacc[dc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[j], oacc[dc], 0, 0, 0);
+        }
+      }
+    }
+    if (tt + 1 < ntiles) store_kv(buf ^ 1);
+    __syncthreads();
+  }
+  const int qi = q0 + li;
+  if (qi < Lq) {
+    const float inv = o_unscale / l_run;
+    float* orow = ob + (size_t)qi * p.ldo;
+#pragma unroll
+    for (int dc = 0; dc < NDC; ++dc)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 w;
+        w.x = oacc[dc][4 * g + 0] * inv;
+        w.y = oacc[dc][4 * g + 1] * inv;
+        w.z = oacc[dc][4 * g + 2] * inv;
+        w.w = oacc[dc][4 * g + 3] * inv;
+        if (dc * 32 + 8 * g + 4 * lh < HDR) *reinterpret_cast<f32x4*>(orow + dc * 32 + 8 * g + 4 * lh) = w;
+      }
+  }
+}
+
 void flash_attention(hipStream_t s, const float* q, const float* k, const float* v, float* o, int B, int H, int Lq, int Lk,
                      int hd, int ldq, int ldk, int ldv, int ldo, long bsq, long bsk, long bsv, long bso, float scale,
-                     const SeqTab* tab) {
+                     const SeqTab* tab, const unsigned* amax_q, const unsigned* amax_k, const unsigned* amax_v) {
   if (B == 0 || Lq == 0) return;
   YMK_CHECK(Lk > 0, "attention: no keys");
   YMK_CHECK(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0, "attention: strides must be multiples of 4");
-  AttnP p{q, k, v, o, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, Lq, Lk, H, scale, nullptr, nullptr, nullptr, nullptr};
+  AttnP p{q, k, v, o, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, Lq, Lk, H, scale, nullptr, nullptr, nullptr, nullptr, amax_q, amax_k, amax_v};
   if (tab) {
     p.qoff = tab->qoff;
     p.qlen = tab->qlen;
@@ -291,6 +511,17 @@ void flash_attention(hipStream_t s, const float* q, const float* k, const float*
     YMK_CHECK((p.qoff == nullptr) == (p.qlen == nullptr) && (p.koff == nullptr) == (p.klen == nullptr), "attention: offset and length tables come in pairs");
   }
   dim3 grid((Lq + 127) / 128, H, B);
+  // fp16-split products when the caller knows bounds of q, k and v (their producers' max|x| records) and the thread's
+  // convolutions run in that form too (conv_effective_split: the model's "conv_split" / the process-wide option)
+  const bool f16 = amax_q && amax_k && amax_v && scale <= 1.f && scale > 0.f && conv_effective_split() == SPLIT_F16X2 && ldq % 4 == 0;
+  if (f16 && (hd == 32 || hd == 64 || hd == 96 || hd == 48)) {
+    if (hd == 32) hipLaunchKernelGGL(k_flash_attn_f16<32>, grid, dim3(256), 0, s, p);
+    else if (hd == 64) hipLaunchKernelGGL(k_flash_attn_f16<64>, grid, dim3(256), 0, s, p);
+    else if (hd == 96) hipLaunchKernelGGL(k_flash_attn_f16<96>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_flash_attn_f16<64, 48>), grid, dim3(256), 0, s, p);
+    YMK_HIP(hipGetLastError());
+    return;
+  }
   if (hd == 32) hipLaunchKernelGGL(k_flash_attn<32>, grid, dim3(256), 0, s, p);
   else if (hd == 64) hipLaunchKernelGGL(k_flash_attn<64>, grid, dim3(256), 0, s, p);
   else if (hd == 96) hipLaunchKernelGGL(k_flash_attn<96>, grid, dim3(256), 0, s, p);
