@@ -49,6 +49,7 @@ import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / f16 MFMA (v_mfma_f32_32x32x16_f16)
+HBM_PEAK_GBS, HBM_ACHIEVABLE_GBS = 8000.0, 6290.0  # MI355X_MICROARCH.md: HBM3E spec / measured float4 copy
 # "conv_split" code (include/ymk.h) -> (16-bit MFMA products per fp32-grade product, dtype string of the bench line)
 SPLIT_MODES = {
     0: (0, "f32 (v_mfma_f32_32x32x2_f32: exact fp32 products, an fmaf chain in k order)"),
@@ -311,15 +312,24 @@ def conv_roofline(lib, run_once, units, unit_name, kernel_desc, reps=3, split=No
     ms, fl, ln, alg = passes[len(passes) // 2]
     ach = fl / (ms * 1e-3) / 1e12
     products = SPLIT_MODES[split if split is not None else split_mode()][0]
-    # the roof of the dominant kernel: exact fp32 MFMA, or the 16-bit MFMA rate over the MFMA products one fp32-grade product
-    # costs (algorithmic FLOPs = 2 M N K throughout: `achieved` is fp32-equivalent work per second)
-    peak = FP32_MFMA_PEAK_TFLOPS if products == 0 else F16_MFMA_PEAK_TFLOPS / products
+    # the two roofs of the implicit-GEMM kernels.  MFMA: exact fp32 MFMA, or the 16-bit MFMA rate over the MFMA products one
+    # fp32-grade product costs (algorithmic FLOPs = 2 M N K throughout: fp32-equivalent work per second).  HBM: the
+    # algorithmic bytes of a launch (input view, weights, output and residual, each touched once - fp32 activations in either
+    # form) over its duration, against the guide's 8 TB/s (6.29 TB/s measured achievable).  The line's top-level
+    # bound / achieved / peak / frac are those of the roof the path sits CLOSER to (the binding one); both views are kept.
+    mfma_peak = FP32_MFMA_PEAK_TFLOPS if products == 0 else F16_MFMA_PEAK_TFLOPS / products
+    gbs = alg / (ms * 1e-3) / 1e9
+    mfma = {"achieved": round(ach, 2), "peak": round(mfma_peak, 1), "unit": "TFLOP/s", "frac": round(ach / mfma_peak, 4),
+            "peak_note": ("dense fp32 MFMA (v_mfma_f32_32x32x2_f32)" if products == 0 else
+                          f"dense 16-bit MFMA {F16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {products} MFMA products per fp32-grade product = fp32-equivalent "
+                          f"TFLOP/s; the same `achieved` is {ach / FP32_MFMA_PEAK_TFLOPS:.3f} of the exact-fp32 MFMA roof (157.3) of the round-3 line")}
+    hbm = {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+           "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 4),
+           "peak_note": f"HBM3E {HBM_PEAK_GBS:.0f} GB/s spec; {HBM_ACHIEVABLE_GBS:.0f} GB/s measured achievable (MI355X_MICROARCH.md); algorithmic bytes, not PMC traffic"}
+    top = dict(hbm, bound="hbm") if hbm["frac"] > mfma["frac"] else dict(mfma, bound="mfma")
     return {
-        "bound": "mfma", "kernel": kernel_desc, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-        "frac": round(ach / peak, 4), "traffic": None,
-        "peak_note": ("dense fp32 MFMA" if products == 0 else
-                      f"dense 16-bit MFMA {F16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {products} MFMA products per fp32-grade product (fp32-equivalent "
-                      f"TFLOP/s); the same `achieved` is {ach / FP32_MFMA_PEAK_TFLOPS:.3f} of the exact-fp32 MFMA roof the round-3 line was priced against"),
+        "bound": top["bound"], "kernel": kernel_desc, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
+        "frac": top["frac"], "traffic": None, "mfma": mfma, "hbm": hbm, "achieved_tflops": round(ach, 2),
         "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
         "algorithmic_bytes_per_launch": int(alg // max(1, ln)),
         f"launches_per_{unit_name}": round(ln / units, 2), "avg_launch_us": round(ms * 1e3 / max(1, ln), 2),
@@ -555,6 +565,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=4, help="waves between upload and aggregation (analyzer workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary metrics leg (recogniser lines/s, default model set)")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the serial roofline pass (pipeline sweeps: only the timed region)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="skip the timed region: only the serial roofline pass (the command profiles/ runs under rocprofv3)")
     args = ap.parse_args()
@@ -690,7 +701,7 @@ def main():
     # one wave at a time, the two chains of a wave one after the other on one stream - so that a launch's event pair
     # brackets that kernel alone.  `python bench.py --roofline-only` under rocprofv3 is the same pass (profiles/).
     roof = None
-    if rank == 0 and not DRY:
+    if rank == 0 and not DRY and not args.no_roofline:
         kern = ("conv_igemm_split (fp16-split MFMA implicit GEMM: the chip-filling conv / linear launches of the four nets) + conv_igemm / "
                 "conv_splitk (exact fp32 MFMA: the stems and the grid-starved launches), max|x| passes included" if split_mode() else
                 "conv_igemm / conv_splitk (fp32 MFMA implicit GEMM: every conv / linear layer of the four nets)")
@@ -722,7 +733,7 @@ def main():
         if roof is not None and dt is not None:
             # the same FLOPs over the WALL clock of the timed region (all kernels, host gaps and overlap included)
             wall_tf = roof["gflop_per_page"] * 1e-3 * pages_job * args.steps / dt / max(1, world)
-            roof["wall_implied"] = {"achieved": round(wall_tf, 2), "frac": round(wall_tf / FP32_MFMA_PEAK_TFLOPS, 4),
+            roof["wall_implied"] = {"achieved_tflops": round(wall_tf, 2), "frac_of_fp32_mfma_peak": round(wall_tf / FP32_MFMA_PEAK_TFLOPS, 4),
                                     "note": "gflop_per_page x pages/s per GPU: lower than `achieved` because the wall clock also holds "
                                             "the non-conv kernels, copies and host gaps; kernel_ms_per_page x pages_per_step <= ms_per_step "
                                             "is checked below (`self_consistent`)"}
@@ -735,7 +746,8 @@ def main():
             # the north star quotes MFMA utilisation "on DBNet conv": the same measurement over the detector's launches alone
             det = an.text_detector
             d_roof = conv_roofline(lib, lambda: det.forward_pages(prof_pages[: args.wave]), len(prof_pages[: args.wave]), "page", kern)
-            roof["dbnet_conv"] = {k: d_roof[k] for k in ("achieved", "frac", "launches_per_page", "kernel_ms_per_page", "gflop_per_page")}
+            roof["dbnet_conv"] = {k: d_roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "achieved_tflops", "mfma", "hbm", "launches_per_page",
+                                                         "kernel_ms_per_page", "gflop_per_page")}
             roof["dbnet_conv"]["batch"] = len(prof_pages[: args.wave])
             st = an.stats
             extra["measured_units_per_page"] = {

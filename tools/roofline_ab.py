@@ -53,8 +53,8 @@ def main():
             same = sum(a == b for a, b in zip(first, dumped))
         roof = bench.conv_roofline(lib, lambda: an.analyze_pages(resident, wave=args.wave), len(resident), "page", "conv")
         det = bench.conv_roofline(lib, lambda: an.text_detector.forward_pages(resident[: args.wave]), args.wave, "page", "conv")
-        print(json.dumps({"setting": setting, "conv_ms_per_page": roof["kernel_ms_per_page"], "tflops": roof["achieved"], "frac": roof["frac"],
-                          "passes": roof["serial_passes_tflops"], "dbnet_tflops": det["achieved"], "dbnet_frac": det["frac"],
+        print(json.dumps({"setting": setting, "conv_ms_per_page": roof["kernel_ms_per_page"], "tflops": roof["achieved_tflops"], "frac": roof["mfma"]["frac"],
+                          "passes": roof["serial_passes_tflops"], "dbnet_tflops": det["achieved_tflops"], "dbnet_frac": det["mfma"]["frac"],
                           "pages_equal_to_first_setting": same, "of": len(dumped)}), flush=True)
         if args.dump:
             os.makedirs(args.dump, exist_ok=True)

@@ -107,7 +107,7 @@ def main(argv):
         "conv_dispatches_in_trace": total, "timed_block_launches": launches, "pages_in_block": pages,
         "rocprof_avg_launch_us": round(sum(dur) / len(dur) / 1e3, 2), "bench_avg_launch_us": roof["avg_launch_us"],
         "rocprof_conv_ms_per_page": round(sum(dur) / 1e6 / pages, 4), "bench_kernel_ms_per_page": roof["kernel_ms_per_page"],
-        "rocprof_tflops": round(roof["gflop_per_page"] * pages / (sum(dur) / 1e9) / 1e3, 2), "bench_tflops": roof["achieved"],
+        "rocprof_tflops": round(roof["gflop_per_page"] * pages / (sum(dur) / 1e9) / 1e3, 2), "bench_tflops": roof.get("achieved_tflops", roof["achieved"]),
         "all_kernels_ms_per_page_in_block": round(all_kernels_ns / 1e6 / pages, 4),
         "conv_share_of_gpu_time_in_block": round(sum(dur) / all_kernels_ns, 4),
         "block_span_ms_per_page": round(span / 1e6 / pages, 4),
