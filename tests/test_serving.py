@@ -171,3 +171,50 @@ def test_full_collections_are_deferred_during_a_job_and_restored_after():
     pipe.serve([page(i) for i in range(2)])
     assert seen == [before]
     pipe.close()
+
+
+def test_switch_interval_is_shortened_for_the_job_and_restored_after():
+    """The stage threads are launch-latency-bound: serve() runs the job with a 0.2 ms thread switch interval (the bench used
+    to set it process-wide for the product) and puts the interpreter's own value back, also when a page fails."""
+    import sys
+
+    before = sys.getswitchinterval()
+    seen = []
+
+    class Spy(StubAnalyzer):
+        def _stage_detect(self, wave):
+            seen.append(sys.getswitchinterval())
+            super()._stage_detect(wave)
+
+    pipe = PagePipeline(Spy(), wave=2, in_flight=2)
+    res = pipe.serve([page(0), page(1, poison_stage=3), page(2)])
+    assert isinstance(res[1], BaseException) and not isinstance(res[0], BaseException)
+    assert seen and all(abs(v - 2e-4) < 1e-9 for v in seen)
+    assert sys.getswitchinterval() == before
+    pipe.switch_interval = 0  # leave the interpreter alone
+    seen.clear()
+    pipe.serve([page(3)])
+    assert seen == [before]
+    pipe.close()
+
+
+def test_reserve_once_falls_back_to_grow_on_demand(monkeypatch):
+    """the worst-case workspace reservation of a live handle is attempted once; a failing hipMalloc is
+    logged and the model keeps growing its workspace on demand (not retried per call: a retry frees the working slab); a
+    rebuilt handle starts over."""
+    from yomitoku_amd import _lib, nets
+
+    calls = []
+
+    class Net(nets.HipNet):
+        def reserve(self, n, h, w, device=None):
+            calls.append((n, h, w))
+            if len(calls) == 1:
+                raise _lib.YmkError("hipMalloc failed: out of memory")
+
+    net = Net()
+    net._h = 1234  # a live handle
+    assert net.reserve_once(8, 1600, 1280) is False and net.reserve_once(8, 1600, 1280) is False and len(calls) == 1
+    net._h, net._reserve_tried_for = 5678, None  # what _build() does: a new handle has no reservation
+    assert net.reserve_once(8, 1600, 1280) is True and net.reserve_once(8, 1600, 1280) is True and len(calls) == 2
+    net._h = None  # nothing to destroy

@@ -28,11 +28,14 @@ def main():
     an.layout.layout_parser.model.load_state_dict(rtdetr_state_dict(1240, num_classes=6, score_bias=-2.0))
     an.layout.table_structure_recognizer.model.load_state_dict(rtdetr_state_dict(1241, num_classes=3, score_bias=-1.0))
     pages = [synthetic_page_with_truth(100 + i, *((1600, 1200) if i % 3 else (1200, 1600)))[0] for i in range(n)]
+    every = [an.text_detector.model, an.layout.layout_parser.model, an.layout.table_structure_recognizer.model, an.text_recognizer.model]
+    for m in every:
+        m.set_conv_split(0)  # the yardstick: EXACT fp32 in all four nets (the models' default is the fp16 split since round 4)
     base = [r.model_dump() for r in an.serve(pages)]
     code = int(os.environ.get("SPLIT", "16"))
-    nets = [an.text_detector.model, an.layout.layout_parser.model, an.layout.table_structure_recognizer.model]
+    nets = every[:3]
     if os.environ.get("ALL") == "1":
-        nets.append(an.text_recognizer.model)
+        nets = every
     for m in nets:
         m.set_conv_split(code)
     split = [r.model_dump() for r in an.serve(pages)]
