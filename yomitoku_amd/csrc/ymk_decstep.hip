@@ -555,7 +555,7 @@ void parseq_dec_step(hipStream_t s, const DecStepW& W, const int* tok, int ld_to
   // still open (profiles/README.md): 1 row 175 / 120 / 58 us, 2 rows 148 / 84 / 72 us, 4 rows 183 / 122 / 109 us - with
   // four rows the block's own chain of phases is twice as long, so that variant stays a test / A-B option.
   int rows = g_dec_rows.load(std::memory_order_relaxed);
-  if (rows == 0) rows = B > 288 ? 2 : 1;
+  if (rows == 0) rows = B > 1152 ? 4 : (B > 288 ? 2 : 1);  // (> 1152 rows - waves of 16 pages - even two rows per block queue up 2.5 deep)
   if (rows >= 4 && launch_rows<4>(s, W, tok, ld_tok, step, skv, NS, memkv, L, mem_off, mem_len, out, prev_not_done, B, gid, gopen, ng))
     return;
   if (rows >= 2 && launch_rows<2>(s, W, tok, ld_tok, step, skv, NS, memkv, L, mem_off, mem_len, out, prev_not_done, B, gid, gopen, ng))

@@ -195,8 +195,9 @@ class LayoutParser(BaseModule):
         oh, ow = (int(v) for v in self._cfg.data.img_size)
         self.model.reserve_once(self.MAX_PAGES_PER_FORWARD, oh, ow, self.device)  # any wave size: no reallocation later (once per live handle)
         raw = []
-        for start in range(0, len(pages), self.MAX_PAGES_PER_FORWARD):
-            chunk = pages[start : start + self.MAX_PAGES_PER_FORWARD]
+        per = -(-len(pages) // max(1, -(-len(pages) // self.MAX_PAGES_PER_FORWARD))) if pages else 1  # forwards of equal size
+        for start in range(0, len(pages), per):
+            chunk = pages[start : start + per]
             x = torch.empty((len(chunk), 3, oh, ow), dtype=torch.float32, device=chunk[0].device)
             for k, page in enumerate(chunk):
                 imaging.rtdetr_tensor(page, None, (oh, ow), out=x[k])

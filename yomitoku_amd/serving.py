@@ -129,7 +129,7 @@ def _switch_interval(seconds):
 
 
 class PagePipeline:
-    def __init__(self, analyzer, wave: int = 8, in_flight: int = 4, defer_full_gc: bool = True, stage_priority=None,
+    def __init__(self, analyzer, wave: int = 16, in_flight: int = 4, defer_full_gc: bool = True, stage_priority=None,
                  rec_lanes: int = 2):
         """rec_lanes: recogniser forwards in flight.  The grouped PARSeq forward is two phases with opposite appetites - the
         ViT encoder (large GEMMs) and the greedy loop (~100 dependent, nearly empty launches) - and it is the longest stage;

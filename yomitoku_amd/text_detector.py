@@ -130,8 +130,9 @@ class TextDetector(BaseModule):
         maps = [None] * len(pages)
         slot = 0
         for (oh, ow), members in by_size.items():
-            for start in range(0, len(members), self.MAX_PAGES_PER_FORWARD):
-                idx = members[start : start + self.MAX_PAGES_PER_FORWARD]
+            per = -(-len(members) // -(-len(members) // self.MAX_PAGES_PER_FORWARD))  # forwards of equal size: 12 pages run as 6 + 6
+            for start in range(0, len(members), per):
+                idx = members[start : start + per]
                 x = torch.empty((len(idx), 3, oh, ow), dtype=torch.float32, device=pages[idx[0]].device)
                 for k, i in enumerate(idx):
                     imaging.detector_tensor(pages[i], cfg.shortest_size, cfg.limit_size, out=x[k])

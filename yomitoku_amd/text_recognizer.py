@@ -192,7 +192,7 @@ class TextRecognizer(BaseModule):
         return imaging.build_crop_batch(dataset.page, plans, out_h=int(self._cfg.data.img_size[0]), batch_w=batch_w)
 
     # ------------------------------------------------------------------ inference + decode
-    MAX_LINES_PER_FORWARD = 1024  # bounds the logits workspace of one grouped forward (101 x num_tokens floats per line)
+    MAX_LINES_PER_FORWARD = 2048  # bounds the logits workspace of one grouped forward (101 x num_tokens floats per line)
 
     def _run_inference(self, data: torch.Tensor, model=None):
         model = model or self.model
@@ -215,10 +215,13 @@ class TextRecognizer(BaseModule):
 
     def _forward_chunks(self, jobs):
         """jobs -> [(first job, one past the last)]: consecutive mini-batches that share a forward (<= MAX_LINES_PER_FORWARD)."""
+        total = sum(len(plans) for _, plans in jobs)
+        n_fwd = max(1, -(-total // self.MAX_LINES_PER_FORWARD))
+        target = min(self.MAX_LINES_PER_FORWARD, -(-total // n_fwd))  # forwards of about equal size: 1100 lines run as 550 + 550, not 1024 + 76
         chunks, start = [], 0
         while start < len(jobs):
             stop, lines = start, 0
-            while stop < len(jobs) and (stop == start or lines + len(jobs[stop][1]) <= self.MAX_LINES_PER_FORWARD):
+            while stop < len(jobs) and (stop == start or (lines < target and lines + len(jobs[stop][1]) <= self.MAX_LINES_PER_FORWARD)):
                 lines += len(jobs[stop][1])
                 stop += 1
             chunks.append((start, stop))
