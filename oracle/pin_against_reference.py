@@ -587,6 +587,179 @@ def pin_export():
     print(f"[export] wrote {len(cases)} cases")
 
 
+def _pdf_documents(n=10, seed=909, page=(1000, 1400)):
+    """Seeded pages for the searchable-PDF text layer: horizontal and vertical paragraphs, a table, a figure, words inside /
+    outside / across containers, contents with ASCII, digits, half-width katakana (with voiced marks), yen sign, spaces."""
+    from yomitoku_amd.schemas import (DocumentAnalyzerSchema, FigureSchema, ParagraphSchema, TableCellSchema, TableLineSchema,
+                                      TableStructureRecognizerSchema, WordPrediction)
+
+    rng = np.random.default_rng(seed)
+    W, H = page
+    texts = ["請求書", "total 123", "ｶﾞｷﾞｸﾞ ﾊﾟﾋﾟ", "ｱｲｳｴｵ｡｢｣､･ｰ", "¥1,200", "a·b", "東京都千代田区1-2-3", "ABC abc 012", "縦書きのテキスト", "ﾞﾟ", "",
+              "x", "〒100-0001", "Tel: 03(1234)5678", "表 3", "ｳﾞｧｲｵﾘﾝ", "１２３ＡＢＣ", "~!@#$%^&*()_+{}|:<>?"]
+
+    def word(box, direction):
+        x1, y1, x2, y2 = box
+        jit = lambda: int(rng.integers(-2, 3))  # a quadrangle, not a rectangle: the hull of its corners is what counts
+        pts = [[x1 + jit(), y1 + jit()], [x2 + jit(), y1 + jit()], [x2 + jit(), y2 + jit()], [x1 + jit(), y2 + jit()]]
+        return WordPrediction(points=pts, content=texts[int(rng.integers(0, len(texts)))], direction=direction,
+                              rec_score=0.9, det_score=0.9)
+
+    docs = []
+    for _ in range(n):
+        order = 0
+        paragraphs, tables, figures, words = [], [], [], []
+        for _p in range(int(rng.integers(2, 6))):
+            vertical = bool(rng.integers(0, 3) == 0)
+            x, y = int(rng.integers(20, W - 320)), int(rng.integers(20, H - 320))
+            w, h = (int(rng.integers(60, 160)), int(rng.integers(200, 300))) if vertical else (int(rng.integers(200, 300)), int(rng.integers(60, 160)))
+            direction = "vertical" if vertical else "horizontal"
+            paragraphs.append(ParagraphSchema(box=[x, y, x + w, y + h], contents="", direction=direction, order=order, role=None))
+            order += 1
+            for k in range(int(rng.integers(1, 4))):  # lines of the paragraph
+                if vertical:
+                    lx = x + w - (k + 1) * (w // 3)
+                    words.append(word([lx, y + 2, lx + w // 3 - 4, y + h - int(rng.integers(2, 60))], direction))
+                else:
+                    ly = y + k * (h // 3)
+                    words.append(word([x + 2, ly, x + w - int(rng.integers(2, 60)), ly + h // 3 - 4], direction))
+        # words outside every container, straddling one, of zero height
+        words.append(word([W - 200, H - 40, W - 20, H - 12], "horizontal"))
+        p0 = paragraphs[0].box
+        words.append(word([p0[0] - 30, p0[1] + 5, p0[0] + 60, p0[1] + 35], "horizontal"))
+        words.append(WordPrediction(points=[[p0[0] + 5, p0[1] + 5], [p0[0] + 80, p0[1] + 5], [p0[0] + 80, p0[1] + 5], [p0[0] + 5, p0[1] + 5]],
+                                    content="flat", direction="horizontal", rec_score=0.9, det_score=0.9))
+        for _t in range(int(rng.integers(0, 2))):
+            tx, ty = int(rng.integers(20, W - 420)), int(rng.integers(20, H - 220))
+            n_row, n_col = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+            cw, ch = 400 // n_col, 200 // n_row
+            cells = []
+            for r in range(n_row, 0, -1):  # cells listed backwards: the sub-order has to sort them
+                for c in range(n_col, 0, -1):
+                    box = [tx + (c - 1) * cw, ty + (r - 1) * ch, tx + c * cw, ty + r * ch]
+                    cells.append(TableCellSchema(col=c, row=r, col_span=1, row_span=1, box=box, contents=""))
+                    words.append(word([box[0] + 3, box[1] + 3, box[2] - 3, box[3] - 3], "horizontal"))
+            line = TableLineSchema(box=[0, 0, 1, 1], score=0.9)
+            tables.append(TableStructureRecognizerSchema(box=[tx, ty, tx + 400, ty + 200], n_row=n_row, n_col=n_col, rows=[line] * n_row,
+                                                         cols=[line] * n_col, spans=[], cells=cells, order=order))
+            order += 1
+        for _f in range(int(rng.integers(0, 2))):
+            fx, fy = int(rng.integers(20, W - 320)), int(rng.integers(20, H - 220))
+            inner = []
+            for k in range(2):
+                box = [fx + 10, fy + 10 + k * 80, fx + 250, fy + 70 + k * 80]
+                inner.append(ParagraphSchema(box=box, contents="", direction="horizontal", order=k, role=None))
+                words.append(word([box[0] + 2, box[1] + 2, box[2] - 2, box[3] - 2], "horizontal"))
+            figures.append(FigureSchema(box=[fx, fy, fx + 300, fy + 200], order=order, paragraphs=inner, direction="horizontal"))
+            order += 1
+        perm = rng.permutation(len(words))
+        docs.append(DocumentAnalyzerSchema(paragraphs=paragraphs, tables=tables, words=[words[int(k)] for k in perm], figures=figures))
+    return docs
+
+
+def pin_searchable_pdf():
+    """utils/searchable_pdf.py: create_searchable_pdf and its helpers, the reference's own code lifted by ast, run against a
+    canvas that RECORDS what reportlab would have been asked to draw -> tests/golden/searchable_pdf.json.  What this pins:
+    which words are written, in which order, with which font size, at which text matrix.  What it cannot: reportlab's
+    stringWidth of the MPLUS face and jaconv.h2z are not installed - both sides use yomitoku_amd's width model and h2z."""
+    import json
+    import tempfile
+    from io import BytesIO
+    from types import SimpleNamespace
+    from typing import List, Optional
+
+    from PIL import Image
+
+    from yomitoku_amd.schemas import DocumentAnalyzerSchema
+    from yomitoku_amd.utils.searchable_pdf import h2z, string_width
+
+    calc_intersection, calc_overlap_ratio, is_contained = _ref_functions("utils/misc.py", ["calc_intersection", "calc_overlap_ratio", "is_contained"], {})
+    env_misc = {"calc_intersection": calc_intersection}
+    (calc_overlap_ratio,) = _ref_functions("utils/misc.py", ["calc_overlap_ratio"], env_misc)
+    (is_contained,) = _ref_functions("utils/misc.py", ["is_contained"], {"calc_overlap_ratio": calc_overlap_ratio})
+
+    pages = []
+
+    class RecordingCanvas:
+        def __init__(self, packet):
+            self.ctm, self.stack, self.ops = np.eye(3), [], []
+
+        def _cm(self, m):
+            self.ctm = np.array(m, dtype=np.float64) @ self.ctm
+
+        def setPageSize(self, size):
+            self.size = [int(size[0]), int(size[1])]
+
+        def drawImage(self, path, x, y, width, height):
+            with Image.open(path) as im:
+                assert im.format == "JPEG" and im.size == (width, height) and (x, y) == (0, 0)
+
+        def setFillColor(self, color):
+            assert color == ("color", 1, 1, 1, 0)
+
+        def setFont(self, name, size):
+            self.ops.append(["font", float(size)])
+
+        def saveState(self):
+            self.stack.append(self.ctm.copy())
+
+        def restoreState(self):
+            self.ctm = self.stack.pop()
+
+        def translate(self, dx, dy):
+            self._cm([[1, 0, 0], [0, 1, 0], [float(dx), float(dy), 1]])
+
+        def rotate(self, theta):
+            c, s = np.cos(np.radians(theta)), np.sin(np.radians(theta))
+            self._cm([[c, s, 0], [-s, c, 0], [0, 0, 1]])
+
+        def drawString(self, x, y, text):
+            m = np.array([[1, 0, 0], [0, 1, 0], [float(x), float(y), 1]]) @ self.ctm
+            self.ops.append(["text"] + [round(float(v), 9) + 0.0 for v in (m[0, 0], m[0, 1], m[1, 0], m[1, 1], m[2, 0], m[2, 1])] + [text])
+
+        def showPage(self):
+            assert not self.stack
+            pages.append({"size": self.size, "ops": self.ops})
+            self.ctm, self.ops = np.eye(3), []
+
+        def save(self):
+            pass
+
+    env = {"np": np, "os": os, "BytesIO": BytesIO, "Image": Image, "List": List, "Optional": Optional,
+           "DocumentAnalyzerSchema": DocumentAnalyzerSchema, "is_contained": is_contained,
+           "stringWidth": lambda text, font, size: string_width(text, size),
+           "jaconv": SimpleNamespace(h2z=lambda text, kana, ascii, digit: h2z(text)),
+           "pdfmetrics": SimpleNamespace(registerFont=lambda font: None), "TTFont": lambda name, path: (name, path),
+           "canvas": SimpleNamespace(Canvas=RecordingCanvas), "Color": lambda r, g, b, alpha: ("color", r, g, b, alpha),
+           "FONT_PATH": "unused.ttf",
+           "IMAGE_QUALITY_PRESETS": {"high": {"max_long_side": None, "jpeg_quality": 85}, "middle": {"max_long_side": 2000, "jpeg_quality": 80},
+                                     "low": {"max_long_side": 1500, "jpeg_quality": 60}}}
+    names = ["_poly2rect", "_calc_font_size", "to_full_width", "create_searchable_pdf"]
+    env.update(zip(names, _ref_functions("utils/searchable_pdf.py", names, env)))
+    create = _ref_functions("utils/searchable_pdf.py", names, env)[3]
+    docs = _pdf_documents()
+    rng = np.random.default_rng(5)
+    images = [Image.fromarray(rng.integers(0, 255, (1400, 1000, 3), dtype=np.uint8)) for _ in docs]
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)  # the reference writes tmp_<i>.png into the working directory
+        try:
+            create(images, docs, os.path.join(tmp, "out.pdf"))
+        finally:
+            os.chdir(cwd)
+    assert len(pages) == len(docs)
+    to_fw = _ref_functions("utils/searchable_pdf.py", names, env)[2]
+    samples = ["ｶﾞｷﾞ ABC 012", "¥100·200", "ｱﾞ ﾞ ﾟ", "mixed 全角 ﾊﾝｶｸ", ""]
+    out = {"pages": [{"doc": d.model_dump(), "size": p["size"], "ops": p["ops"]} for d, p in zip(docs, pages)],
+           "to_full_width": [[s_, to_fw(s_)] for s_ in samples]}
+    with open(os.path.join(GOLDEN, "searchable_pdf.json"), "w") as f:
+        json.dump(out, f, ensure_ascii=False)
+    n_text = sum(1 for p in pages for op in p["ops"] if op[0] == "text")
+    n_rot = sum(1 for p in pages for op in p["ops"] if op[0] == "text" and op[2] == -1.0)
+    print(f"[searchable_pdf] wrote {len(pages)} pages, {n_text} strings ({n_rot} turned characters of vertical words), "
+          f"{sum(len(d.words) for d in docs)} words in")
+
+
 def _ref_methods(relpath, cls, names, env):
     """Like _ref_functions for methods of a reference class: returned as plain functions taking `self` first."""
     import ast
@@ -732,7 +905,7 @@ def main(argv):
     os.makedirs(GOLDEN, exist_ok=True)
     todo = {"dbnet": pin_dbnet, "parseq": pin_parseq, "rtdetr": pin_rtdetr, "host": pin_host_logic, "aggregate": pin_aggregate,
             "filters": pin_filters, "geometry": pin_geometry, "cells": pin_cells, "export": pin_export,
-            "configs": pin_configs}
+            "configs": pin_configs, "searchable_pdf": pin_searchable_pdf}
     for k, fn in todo.items():
         if what in (k, "all"):
             fn()
