@@ -57,50 +57,71 @@ def gather_in_order(local: Sequence, n_items: int, rank: int, world: int) -> lis
     return merged
 
 
+_WIRE = {"f32": torch.float32, "f64": torch.float64, "i64": torch.int64}
+
+
+def _wire_kind(dtype_name: str) -> str:
+    """Which flat message a tensor travels in: fp32 (incl. f16 / bf16, widened losslessly), fp64, or int64."""
+    dt = getattr(torch, dtype_name)
+    return "f64" if dt == torch.float64 else ("f32" if dt.is_floating_point else "i64")
+
+
+def _checkpoint_meta(sd: Mapping[str, torch.Tensor]) -> list:
+    return [(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in sd.items()]
+
+
+def _flat_buffers(meta, device, sd: Mapping[str, torch.Tensor] | None = None) -> dict:
+    """One flat buffer per wire type on `device`, sized from `meta`; filled from `sd` where one is given (the sender)."""
+    numel = {c: sum(int(torch.Size(s).numel()) for _, s, d in meta if _wire_kind(d) == c) for c in _WIRE}
+    bufs = {c: torch.empty(max(numel[c], 1), dtype=dt, device=device) for c, dt in _WIRE.items()}
+    if sd is not None:
+        off = dict.fromkeys(_WIRE, 0)
+        for k, s, d in meta:
+            v, c = sd[k], _wire_kind(d)
+            n = v.numel()
+            bufs[c][off[c] : off[c] + n] = v.reshape(-1).to(device=device, dtype=_WIRE[c])
+            off[c] += n
+    return {c: (b, numel[c]) for c, b in bufs.items()}
+
+
+def _unflatten(bufs: dict, meta) -> "OrderedDict[str, torch.Tensor]":
+    """The receiver's side: CPU tensors of the sender's shapes and dtypes out of the flat buffers."""
+    out = OrderedDict()
+    host = {c: b.cpu() for c, (b, _) in bufs.items()}
+    off = dict.fromkeys(_WIRE, 0)
+    for k, s, d in meta:
+        n, c = int(torch.Size(s).numel()), _wire_kind(d)
+        out[k] = host[c][off[c] : off[c] + n].reshape(s).to(getattr(torch, d)).clone()
+        off[c] += n
+    return out
+
+
+def _collective_device():
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
 def broadcast_state_dict(sd: Mapping[str, torch.Tensor] | None, src: int = 0, device=None):
     """Broadcast a checkpoint from `src` as ONE flat fp32 message (+ a tiny int64 one).
 
     Rank `src` passes the state dict, the others pass None and receive an identical copy (CPU
     tensors).  The flat buffer lives on `device` during the collective: with the nccl backend that
     is the rank's GPU, so the ~0.1-0.5 GB message travels over xGMI, not through the host.
+    Without a process group there is nobody to send to and `sd` comes straight back; a group of ONE
+    rank still runs the collective (that is how the RCCL path is exercised on a single-GPU box).
     """
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return sd
     rank = dist.get_rank()
-    meta = [None]
-    if rank == src:
-        meta[0] = [(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in sd.items()]
+    meta = [_checkpoint_meta(sd) if rank == src else None]
     dist.broadcast_object_list(meta, src=src)
     meta = meta[0]
     if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    def kind(d):  # which flat message a tensor travels in: fp32 (incl. f16 / bf16, widened losslessly), fp64, or int64
-        dt = getattr(torch, d)
-        return "f64" if dt == torch.float64 else ("f32" if dt.is_floating_point else "i64")
-
-    wire = {"f32": torch.float32, "f64": torch.float64, "i64": torch.int64}
-    numel = {k: sum(int(torch.Size(s).numel()) for _, s, d in meta if kind(d) == k) for k in wire}
-    bufs = {k: torch.empty(max(numel[k], 1), dtype=dt, device=device) for k, dt in wire.items()}
-    if rank == src:
-        off = dict.fromkeys(wire, 0)
-        for k, s, d in meta:
-            v, c = sd[k], kind(d)
-            n = v.numel()
-            bufs[c][off[c] : off[c] + n] = v.reshape(-1).to(device=device, dtype=wire[c])
-            off[c] += n
-    for c in wire:
-        if numel[c]:
-            dist.broadcast(bufs[c], src=src)
-    if rank == src:
-        return sd
-    out = OrderedDict()
-    host = {c: b.cpu() for c, b in bufs.items()}
-    off = dict.fromkeys(wire, 0)
-    for k, s, d in meta:
-        n, c = int(torch.Size(s).numel()), kind(d)
-        out[k] = host[c][off[c] : off[c] + n].reshape(s).to(getattr(torch, d)).clone()
-        off[c] += n
-    return out
+        device = _collective_device()
+    bufs = _flat_buffers(meta, device, sd if rank == src else None)
+    for c, (buf, numel) in bufs.items():
+        if numel:
+            dist.broadcast(buf, src=src)
+    return sd if rank == src else _unflatten(bufs, meta)
 
 
 def state_dict_crc(sd: Mapping[str, torch.Tensor]) -> int:
@@ -121,10 +142,10 @@ def all_gather_scalars(values: Sequence[float], device=None) -> List[List[float]
     """Every rank's `values` on every rank (one tiny all-gather; world size 1: [[values]]).  float64 on the wire, so
     32-bit CRCs and counters travel exactly."""
     vals = [float(v) for v in values]
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return [vals]
     if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        device = _collective_device()
     mine = torch.tensor(vals, dtype=torch.float64, device=device)
     parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(parts, mine)
