@@ -38,6 +38,11 @@ SHAPES = [
     ("parseq head 192->7119", 1, 1, 66155, 192, 7119, 1, 1, 0, 1, 0, 0),
     ("parseq AR head 655 rows", 1, 1, 655, 192, 7119, 1, 1, 0, 1, 0, 0),
     ("parseq AR head 200 rows", 1, 1, 200, 192, 7119, 1, 1, 0, 1, 0, 0),
+    # the reference's default recogniser (parseq-large-v4_1: D = 768, 400 tokens per line), 128 lines per forward
+    ("parseq-large qkv 768->2304", 1, 1, 51200, 768, 2304, 1, 1, 0, 1, 0, 0),
+    ("parseq-large proj 768->768 +res", 1, 1, 51200, 768, 768, 1, 1, 0, 1, 0, 1),
+    ("parseq-large fc1 768->3072 gelu", 1, 1, 51200, 768, 3072, 1, 1, 0, 1, 4, 0),
+    ("parseq-large fc2 3072->768 +res", 1, 1, 51200, 3072, 768, 1, 1, 0, 1, 0, 1),
 ]
 # "v", "v/f" or "v/f/key=val;key=val": conv_variant v with conv_fast f (bit 0: index shortcut, bit 1: residual prefetch,
 # bit 2: direct epilogue everywhere, bit 3: swizzled K tiles, bit 4: direct epilogue for ragged Cout; 3 = round 2, default 27)
