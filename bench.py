@@ -305,11 +305,11 @@ def conv_roofline(lib, run_once, units, unit_name, kernel_desc, reps=3, split=No
         alg = ctypes.c_double()
         _lib.check(lib.ymk_prof_bytes(ctypes.byref(alg)))
         if ms.value > 0:
-            passes.append((ms.value, fl.value, ln.value, alg.value))
+            passes.append((ms.value, fl.value, ln.value, alg.value, _lib.prof_launch_table()))
     if not passes:
         return None
-    passes.sort()
-    ms, fl, ln, alg = passes[len(passes) // 2]
+    passes.sort(key=lambda p: p[0])
+    ms, fl, ln, alg, table = passes[len(passes) // 2]
     ach = fl / (ms * 1e-3) / 1e12
     products = SPLIT_MODES[split if split is not None else split_mode()][0]
     # the two roofs of the implicit-GEMM kernels.  MFMA: exact fp32 MFMA, or the 16-bit MFMA rate over the MFMA products one
@@ -334,8 +334,36 @@ def conv_roofline(lib, run_once, units, unit_name, kernel_desc, reps=3, split=No
         "algorithmic_bytes_per_launch": int(alg // max(1, ln)),
         f"launches_per_{unit_name}": round(ln / units, 2), "avg_launch_us": round(ms * 1e3 / max(1, ln), 2),
         f"kernel_ms_per_{unit_name}": round(ms / units, 4), f"gflop_per_{unit_name}": round(fl / units / 1e9, 2),
-        "serial_passes_tflops": [round(f / (m * 1e-3) / 1e12, 2) for m, f, _, _ in passes],
+        "serial_passes_tflops": [round(p[1] / (p[0] * 1e-3) / 1e12, 2) for p in passes],
+        "per_launch": two_roof_bound(table),
     }
+
+
+def two_roof_bound(table):
+    """Every launch of the pass priced against ITS binding roof: t_bound = max(FLOPs / MFMA peak of the kernel it ran on,
+    algorithmic bytes / HBM peak); sum of the bounds over sum of the measured launch times = how far the path as a whole
+    is from the two roofs taken together (the single-roof fractions above divide totals, which undersells a mix of
+    HBM-bound 1 x 1 layers and MFMA-bound k x k layers).  `table`: _lib.prof_launch_table() rows."""
+    if not table:
+        return None
+    t_meas = t_bound = t_bound_ach = t_hbm_side = 0.0
+    n_hbm = 0
+    for ms, flop, nbytes, products in table:
+        peak = FP32_MFMA_PEAK_TFLOPS if products == 0 else F16_MFMA_PEAK_TFLOPS / products
+        t_m = flop / (peak * 1e12) * 1e3
+        t_h = nbytes / (HBM_PEAK_GBS * 1e9) * 1e3
+        t_meas += ms
+        t_bound += max(t_m, t_h)
+        t_bound_ach += max(t_m, nbytes / (HBM_ACHIEVABLE_GBS * 1e9) * 1e3)
+        if t_h > t_m:
+            n_hbm += 1
+            t_hbm_side += ms
+    return {"launches": len(table), "measured_ms": round(t_meas, 3), "two_roof_bound_ms": round(t_bound, 3),
+            "frac_of_two_roof_bound": round(t_bound / t_meas, 4),
+            "frac_with_achievable_hbm": round(t_bound_ach / t_meas, 4),
+            "hbm_bound_launches": n_hbm, "hbm_bound_share_of_measured_time": round(t_hbm_side / t_meas, 4),
+            "note": "per launch: max(algorithmic FLOPs / MFMA peak of the kernel that ran it, algorithmic bytes / 8 TB/s); "
+                    "frac = sum of those bounds / sum of the measured launch times"}
 
 
 def cpu_timed(fn, n_warm, n_timed, budget_s):

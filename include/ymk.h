@@ -177,6 +177,12 @@ int ymk_debug_option(const char* key, int value);
 int ymk_amax_check_counters(int64_t* out4);
 int ymk_prof_end(double* conv_ms, double* conv_flop, int64_t* conv_launches);
 int ymk_prof_bytes(double* conv_bytes);
+/* The launches of the span ymk_prof_end closed last, one row each in launch order: kernel time (ms), algorithmic FLOPs,
+ * algorithmic HBM bytes (as above) and the MFMA products the kernel spends per fp32-grade product (0: exact fp32 MFMA,
+ * 3: two fp16 or two bf16 planes, 6: three bf16 planes).  *count = how many there are; rows beyond `capacity` are not
+ * written (capacity 0 with null arrays asks for the count).  What bench.py prices launch by launch against the closer
+ * of the two roofs. */
+int ymk_prof_launch_table(double* ms, double* flop, double* bytes, double* mfma_products, int64_t capacity, int64_t* count);
 
 /* ---- single operators (exported for the parity tests; same kernels the models use) -----
  * NHWC fp32 tensors; weight in PyTorch OIHW order on the host. */

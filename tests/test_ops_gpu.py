@@ -177,3 +177,46 @@ def test_bilinear(dev, shape, size):
     add = torch.randn(shape[0], shape[1], *size, generator=g)
     ref = F.interpolate(x, size=size, mode="bilinear", align_corners=False) + add
     _close(hipops.upsample_bilinear(x.to(dev), size, add.to(dev)), ref, 1e-6)
+
+
+def test_prof_launch_table_has_one_row_per_launch(dev):
+    """ymk_prof_launch_table (the per-launch rows bench.py prices against the two roofs): as many rows as ymk_prof_end counted,
+    FLOPs and bytes summing to the span's totals, and the kernel family of each launch (exact fp32 / fp16 planes)."""
+    import ctypes
+
+    from tests import hipops
+    from yomitoku_amd import _lib
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(4)
+    x_big = torch.randn(2, 64, 200, 160, generator=g).to(dev)     # 64 000 output pixels x 128 channels: fills the chip
+    w_big = torch.randn(128, 64, 3, 3, generator=g) / 24
+    x_small = torch.randn(1, 32, 20, 20, generator=g).to(dev)
+    w_small = torch.randn(48, 32, 1, 1, generator=g) / 6
+    res = torch.randn(1, 48, 20, 20, generator=g).to(dev)
+    try:
+        _lib.check(lib.ymk_prof_begin())
+        hipops.conv2d(x_big, w_big, padding=1)                      # ymk_op_conv2d: exact fp32 unless asked
+        _lib.debug_option("conv_split", 16)
+        hipops.conv2d(x_big, w_big, padding=1)                      # two fp16 planes
+        hipops.conv2d(x_small, w_small, residual=res)               # grid-starved: stays on the exact kernels
+        _lib.debug_option("conv_split", -1)
+        torch.cuda.synchronize()
+        ms, fl, ln, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        _lib.check(lib.ymk_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(ln)))
+        _lib.check(lib.ymk_prof_bytes(ctypes.byref(by)))
+    finally:
+        _lib.debug_option("conv_split", -1)
+    rows = _lib.prof_launch_table()
+    assert len(rows) == ln.value == 3
+    assert sum(r[1] for r in rows) == pytest.approx(fl.value, rel=1e-12) and sum(r[2] for r in rows) == pytest.approx(by.value, rel=1e-12)
+    assert sum(r[0] for r in rows) == pytest.approx(ms.value, rel=1e-6) and all(r[0] > 0 for r in rows)
+    flop_big = 2.0 * 2 * 200 * 160 * 128 * 64 * 9
+    assert rows[0][1] == rows[1][1] == flop_big and rows[2][1] == 2.0 * 400 * 48 * 32
+    bytes_big = 4.0 * (2 * 200 * 160 * 64 + 128 * 64 * 9 + 2 * 200 * 160 * 128)
+    assert rows[0][2] == bytes_big and rows[2][2] == 4.0 * (400 * 32 + 48 * 32 + 2 * 400 * 48)   # the residual is read as well
+    assert [r[3] for r in rows] == [0.0, 3.0, 0.0]
+    # a second span starts from nothing
+    _lib.check(lib.ymk_prof_begin())
+    _lib.check(lib.ymk_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(ln)))
+    assert _lib.prof_launch_table() == [] and ln.value == 0

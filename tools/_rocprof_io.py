@@ -42,7 +42,9 @@ def counter_rows(out_dir):
         for path in files:
             with open(path, newline="") as f:
                 rows += [{"Kernel_Name": r["Kernel_Name"], "Dispatch_Id": int(r["Dispatch_Id"]), "Counter_Name": r["Counter_Name"],
-                          "Counter_Value": float(r["Counter_Value"])} for r in csv.DictReader(f)]
+                          "Counter_Value": float(r["Counter_Value"]), "Grid_Size": r.get("Grid_Size", ""),
+                          "Duration_Ns": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) if r.get("End_Timestamp") and r.get("Start_Timestamp") else 0}
+                         for r in csv.DictReader(f)]
     else:
         dbs = _find(out_dir, "*_results.db")
         if not dbs:

@@ -3,6 +3,10 @@
     python tools/pmc_aggregate.py sum <rocprof_out_dir> <out.csv>
         every *counter_collection.csv under the directory -> one row per (kernel, counter): dispatch rows and the sum
 
+    python tools/pmc_aggregate.py bygrid <rocprof_out_dir> <out.csv>
+        the same per (kernel, grid size, counter): one kernel instantiation serving several layer shapes is told apart by
+        its grid (CSV output of rocprofv3 only); with the mean dispatch duration where the file carries timestamps
+
     python tools/pmc_aggregate.py traffic <fetch.csv> <write.csv> <out.json> "<command the passes profiled>"
         the two per-kernel files of separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes -> the JSON bench.py reads as
         `roofline.traffic` (profiles/r02_<workload>_pmc_conv_traffic.json).  Units and the gfx950 correction follow
@@ -36,6 +40,21 @@ def _sum(out_dir, dst):
         for (kernel, counter), (n, total) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
             w.writerow([kernel, counter, n, round(total, 1)])
     print(f"{dst}: {len(acc)} (kernel, counter) rows")
+
+
+def _by_grid(out_dir, dst):
+    acc = defaultdict(lambda: [0, 0.0, 0])
+    for row in counter_rows(out_dir):
+        a = acc[(row["Kernel_Name"], row.get("Grid_Size", ""), row["Counter_Name"])]
+        a[0] += 1
+        a[1] += float(row["Counter_Value"])
+        a[2] += int(row.get("Duration_Ns", 0))
+    with open(dst, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "grid", "counter", "dispatches", "sum", "mean_per_dispatch", "mean_duration_us"])
+        for (kernel, grid, counter), (n, total, dur) in sorted(acc.items(), key=lambda kv: (kv[0][0], kv[0][1], kv[0][2])):
+            w.writerow([kernel, grid, counter, n, round(total, 1), round(total / n, 1), round(dur / n / 1e3, 1)])
+    print(f"{dst}: {len(acc)} (kernel, grid, counter) rows")
 
 
 def _conv_rows(path, counter):
@@ -74,6 +93,8 @@ def _traffic(fetch_csv, write_csv, dst, command):
 if __name__ == "__main__":
     if len(sys.argv) >= 4 and sys.argv[1] == "sum":
         _sum(sys.argv[2], sys.argv[3])
+    elif len(sys.argv) >= 4 and sys.argv[1] == "bygrid":
+        _by_grid(sys.argv[2], sys.argv[3])
     elif len(sys.argv) >= 6 and sys.argv[1] == "traffic":
         _traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
     else:

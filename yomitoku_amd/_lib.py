@@ -61,6 +61,7 @@ SIGNATURES = {
     "ymk_prof_begin": (c_int, []),
     "ymk_prof_end": (c_int, [POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
     "ymk_prof_bytes": (c_int, [POINTER(c_double)]),
+    "ymk_prof_launch_table": (c_int, [POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double), c_int64, POINTER(c_int64)]),
     "ymk_op_conv2d": (
         c_int,
         [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
@@ -136,6 +137,17 @@ def amax_check_counters():
     out = (ctypes.c_int64 * 4)()
     check(load().ymk_amax_check_counters(out), "ymk_amax_check_counters")
     return tuple(int(v) for v in out)
+
+
+def prof_launch_table():
+    """[(ms, flop, bytes, mfma_products)] of the launches between the last ymk_prof_begin / ymk_prof_end (include/ymk.h)."""
+    import ctypes
+
+    lib, n = load(), ctypes.c_int64()
+    check(lib.ymk_prof_launch_table(None, None, None, None, 0, ctypes.byref(n)), "ymk_prof_launch_table")
+    cols = [(ctypes.c_double * max(1, n.value))() for _ in range(4)]
+    check(lib.ymk_prof_launch_table(*cols, n.value, ctypes.byref(n)), "ymk_prof_launch_table")
+    return [tuple(float(c[i]) for c in cols) for i in range(n.value)]
 
 
 def ptr(t):

@@ -17,6 +17,7 @@ void row_maxprob(hipStream_t s, const float* logits, int rows, int C, int* ids, 
 void prof_begin();
 void prof_end(double* ms, double* flop, int64_t* launches);
 double prof_bytes();
+int64_t prof_launch_table(double* ms, double* flop, double* bytes, double* products, int64_t capacity);
 bool conv_debug_option(const std::string& key, int value);
 bool parseq_debug_option(const std::string& key, int value);
 bool decstep_debug_option(const std::string& key, int value);
@@ -201,6 +202,13 @@ int ymk_prof_bytes(double* conv_bytes) {
   YMK_API_BEGIN
   YMK_CHECK(conv_bytes, "null argument");
   *conv_bytes = ymk::prof_bytes();
+  YMK_API_END
+}
+
+int ymk_prof_launch_table(double* ms, double* flop, double* bytes, double* mfma_products, int64_t capacity, int64_t* count) {
+  YMK_API_BEGIN
+  YMK_CHECK(count != nullptr && capacity >= 0 && (capacity == 0 || (ms && flop && bytes && mfma_products)), "null argument");
+  *count = ymk::prof_launch_table(ms, flop, bytes, mfma_products, capacity);
   YMK_API_END
 }
 

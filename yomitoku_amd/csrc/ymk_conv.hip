@@ -447,7 +447,7 @@ struct ProfState {
   double flop = 0.0;
   double bytes = 0.0;  // algorithmic HBM bytes: input view, weights, output and residual, each touched once
   std::vector<std::string> desc;
-  std::vector<double> lflop;
+  std::vector<double> lflop, lbytes, lms, lprod;  // per launch (lms filled by prof_end): what ymk_prof_launch_table hands out
 };
 static ProfState g_prof;
 
@@ -513,14 +513,27 @@ void prof_end(double* ms, double* flop, int64_t* launches) {
     float t = 0.f;
     YMK_HIP(hipEventElapsedTime(&t, g_prof.ev[i].first, g_prof.ev[i].second));
     total += t;
+    g_prof.lms[i] = t;
     if (g_prof_dump.load(std::memory_order_relaxed))
-      fprintf(stderr, "[ymk-prof] %3zu %s  %8.1f us  %6.1f TFLOP/s\n", i, g_prof.desc[i].c_str(), t * 1e3,
-              g_prof.lflop[i] / (t * 1e-3) / 1e12);
+      fprintf(stderr, "[ymk-prof] %3zu %s  %8.1f us  %6.1f TFLOP/s  %7.1f MB\n", i, g_prof.desc[i].c_str(), t * 1e3,
+              g_prof.lflop[i] / (t * 1e-3) / 1e12, g_prof.lbytes[i] / 1e6);
   }
   *ms = total;
   *flop = g_prof.flop;
   *launches = (int64_t)g_prof.used;
   g_prof.on = false;
+}
+// the launches of the span prof_end closed last, one row each; returns how many there are (rows beyond `capacity` are not written)
+int64_t prof_launch_table(double* ms, double* flop, double* bytes, double* products, int64_t capacity) {
+  std::lock_guard<std::mutex> lock(g_prof.mu);
+  const int64_t n = g_prof.on ? 0 : (int64_t)g_prof.used;
+  for (int64_t i = 0; i < n && i < capacity; ++i) {
+    ms[i] = g_prof.lms[i];
+    flop[i] = g_prof.lflop[i];
+    bytes[i] = g_prof.lbytes[i];
+    products[i] = g_prof.lprod[i];
+  }
+  return n;
 }
 
 // open a timed span for one launch when profiling is on (returns the event pair to close it with)
@@ -538,17 +551,27 @@ std::pair<hipEvent_t, hipEvent_t>* conv_prof_open(hipStream_t s, const ConvK& k,
     const int creal = k.mode == 0 ? k.C : 3;
     const double fl = 2.0 * (double)k.M * (double)k.Cout * (double)(k.KH * k.KW * creal);
     g_prof.flop += fl;
-    {
-      const double images = (double)k.M / ((double)k.OH * k.OW);
-      const double outs = (double)k.M * k.Cout * (k.epi == EPI_DECONV2X2 ? 1.0 : 1.0);
-      g_prof.bytes += 4.0 * (images * k.H * k.W * creal + (double)k.Cout * k.KH * k.KW * creal + outs * (k.res ? 2.0 : 1.0));
+    const double images = (double)k.M / ((double)k.OH * k.OW);
+    const double outs = (double)k.M * k.Cout;
+    const double by = 4.0 * (images * k.H * k.W * creal + (double)k.Cout * k.KH * k.KW * creal + outs * (k.res ? 2.0 : 1.0));
+    g_prof.bytes += by;
+    char buf[176];
+    snprintf(buf, sizeof buf, "M=%7d Cin=%4d Cout=%4d k=%dx%d s=%d d=%d res=%d tile=%dx%d ksplit=%d grid=%d", k.M, k.C, k.Cout,
+             k.KH, k.KW, k.stride, k.dil, k.res ? 1 : 0, BM, BN, ksplit, grid);
+    if (g_prof.desc.size() < g_prof.used) {
+      g_prof.desc.resize(g_prof.used);
+      g_prof.lflop.resize(g_prof.used);
+      g_prof.lbytes.resize(g_prof.used);
+      g_prof.lms.resize(g_prof.used);
+      g_prof.lprod.resize(g_prof.used);
     }
-    char buf[160];
-    snprintf(buf, sizeof buf, "M=%7d Cin=%4d Cout=%4d k=%dx%d s=%d d=%d tile=%dx%d ksplit=%d grid=%d", k.M, k.C, k.Cout, k.KH,
-             k.KW, k.stride, k.dil, BM, BN, ksplit, grid);
-    if (g_prof.desc.size() < g_prof.used) { g_prof.desc.resize(g_prof.used); g_prof.lflop.resize(g_prof.used); }
     g_prof.desc[g_prof.used - 1] = buf;
     g_prof.lflop[g_prof.used - 1] = fl;
+    g_prof.lbytes[g_prof.used - 1] = by;
+    g_prof.lms[g_prof.used - 1] = 0.0;
+    // MFMA products behind one fp32-grade product: the split kernels tag their spans through `ksplit` (160 / 161: two fp16
+    // planes, 20 / 30: two / three bf16 planes); everything else is the exact fp32 MFMA
+    g_prof.lprod[g_prof.used - 1] = ksplit >= 160 ? 3.0 : (ksplit == 30 ? 6.0 : (ksplit == 20 ? 3.0 : 0.0));
     YMK_HIP(hipEventRecord(e->first, s));
   }
   return e;
