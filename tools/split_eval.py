@@ -61,7 +61,7 @@ def main():
     from oracle.dbnet import dbnet_forward
     from oracle.preprocess import detector_preprocess
     from yomitoku_amd import DocumentAnalyzer, imaging
-    from yomitoku_amd.nets import DBNet, PARSeq, RTDETRv2
+    from yomitoku_amd.nets import DBNet, RTDETRv2
     from yomitoku_amd.utils.synth import dbnet_state_dict, parseq_state_dict, synthetic_line_batch, synthetic_page, synthetic_page_with_truth
     from yomitoku_amd.utils.synth_rtdetr import rtdetr_state_dict
     sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _lib, imaging
-from .base import BaseModelCatalog, BaseModule, load_config, logger
+from .base import BaseModelCatalog, BaseModule, load_config
 from .configs import TableCellParserRTDETRv2Config
 from .geometry import adjacency_matrices, calc_iou, containment_matrix, filter_by_flag, is_contained
 from .layout_parser import RTDETRPostProcessor, load_local_checkpoint

@@ -11,7 +11,7 @@ from __future__ import annotations
 import logging
 import threading
 import unicodedata
-from typing import List, Optional
+from typing import List
 
 import numpy as np
 import torch
