@@ -1,0 +1,240 @@
+// DRAFT - NOT part of libymk_hip.so, never launched: the A-stationary form of the fp16-split 1 x 1 convolution that
+// DESIGN.md section 9 (item 1) proposes for the short-K layers (K <= 256: the PARSeq encoder's qkv / fc1 / proj, the ResNet
+// expands, the DBNet decoder's 256 -> 256).  It is kept here, outside the library, for what the compiler says about it
+// (registers, spills, LDS: tools/drafts/README.md) and as the starting point of the next round; it becomes a kernel when
+// it has a green bit-identity test against conv_igemm_split<.., FMT = 1> and a line in tools/conv_sweep.py.
+//
+// Same arithmetic as conv_f16_dma (yomitoku_amd/csrc/ymk_conv_dma.hip): two scaled fp16 planes per fp32 operand, the three
+// MFMAs of a product tile in the same order, the same K order - so the results must equal that kernel's bit for bit.
+// What changes is who waits for what:
+//   * a block owns 128 rows (4 waves x 32) for ALL column blocks of the layer.  Each wave loads ITS 32 rows of A once,
+//     straight into registers (buffer loads, a row past M or a channel past C is an out-of-range offset -> zeros), and
+//     converts them to the two planes once: 8 VGPRs per 16-k step, 16 KT VGPRs for K = 32 KT (96 at K = 192).  No LDS, no
+//     barrier and no second conversion for A, whatever the number of column blocks (6 for fc1: today its A rows are fetched
+//     and converted six times);
+//   * the weight slabs (BN columns x 32 k x 2 planes = 16 KB at BN = 128) flow through three LDS stages by LDS-DMA as ONE
+//     sequence over (column block, K tile) - the pipeline never drains between column blocks;
+//   * a column block's accumulators go out straight from registers (epilogue_direct: 128-byte row segments) while the next
+//     block's slabs are already landing; with two blocks per CU the other block's MFMAs cover this one's epilogue arithmetic.
+#include "../../yomitoku_amd/csrc/ymk_conv_kernel.h"
+
+namespace ymk {
+
+typedef _Float16 as_hf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 as_hf16x8_t __attribute__((ext_vector_type(8)));
+typedef float as_hf32x2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void as_lds_void;
+
+__device__ __forceinline__ float2 astat_scales(unsigned amax_bits) {  // f16_scales of ymk_conv_split.hip
+  int e = (int)(amax_bits >> 23);
+  e = e < 27 ? 27 : (e > 227 ? 227 : e);
+  float2 r;
+  r.x = __uint_as_float((unsigned)(268 - e) << 23);
+  r.y = __uint_as_float((unsigned)(e - 14) << 23);
+  return r;
+}
+
+__device__ __forceinline__ void astat_split8(const f32x4 u, const f32x4 v, float sa, as_hf16x8_t& hi, as_hf16x8_t& lo) {
+  as_hf32x2_t x[4] = {{u.x, u.y}, {u.z, u.w}, {v.x, v.y}, {v.z, v.w}};
+  as_hf16x2_t h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    x[i] *= sa;
+    h[i] = __builtin_convertvector(x[i], as_hf16x2_t);
+    x[i] -= __builtin_convertvector(h[i], as_hf32x2_t);  // exact
+    l[i] = __builtin_convertvector(x[i], as_hf16x2_t);
+  }
+  hi = as_hf16x8_t{h[0].x, h[0].y, h[1].x, h[1].y, h[2].x, h[2].y, h[3].x, h[3].y};
+  lo = as_hf16x8_t{l[0].x, l[0].y, l[1].x, l[1].y, l[2].x, l[2].y, l[3].x, l[3].y};
+}
+
+// one column block of a wave (32 rows x 32 TN columns) out of the accumulators: scale / bias / residual / activation as
+// epilogue_tile does (same expression per value), through buffer descriptors with 32-bit offsets, four rows at a time -
+// the direct epilogue of ymk_conv_kernel.h keeps sixteen 64-bit addresses and sixteen residual values live, which is
+// what pushed the first form of this draft past 256 registers
+template <int ACT, int TN>
+__device__ __forceinline__ void astat_store(const ConvK& p, const f32x16 (&acc)[TN], float inv_sa, int mw, int n0, int li, int lh,
+                                            __amdgpu_buffer_rsrc_t rsrc_o, __amdgpu_buffer_rsrc_t rsrc_r, unsigned& am) {
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int co = n0 + 32 * b + li;
+    const bool cok = co < p.Cout;
+    const float sc = (p.scale && cok) ? p.scale[co] : 1.f;
+    const float bi = (p.bias && cok) ? p.bias[co] : 0.f;
+    const int row0 = mw + 4 * lh;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      unsigned oo[4];
+      float rr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = row0 + 8 * g + i;
+        const bool ok = cok && row < p.M;
+        oo[i] = ok ? ((unsigned)row * (unsigned)p.out_ld + (unsigned)co) * 4u : OOB_OFFSET;
+        const unsigned ro = ok ? ((unsigned)row * (unsigned)p.res_ld + (unsigned)co) * 4u : OOB_OFFSET;
+        rr[i] = p.res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_r, (int)ro, 0, 0)) : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = (acc[b][4 * g + i] * inv_sa) * sc + bi;
+        if (p.res && !p.res_post) v += rr[i];
+        v = apply_act(v, ACT);
+        if (p.res_post) v += rr[i];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_o, (int)oo[i], 0, 0);
+        if (oo[i] != OOB_OFFSET) amax_fold(am, v);
+      }
+      // four rows at a time: without the fence the scheduler hoists every residual load of the tile, and without pinning
+      // `am` the max-chain is re-associated into a tree over all 16 TN values of the wave (56 registers: measured)
+      asm volatile("" : "+v"(am));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// 1 x 1, stride 1, no padding (the caller checks); KT = Kpad / 32 K tiles (compile time: the A planes live in registers);
+// BN columns per column block; grid = ceil(M / 128) x column groups (p.ntiles_n column blocks are dealt to gridDim.y groups)
+template <int BN, int KT>
+__global__ __launch_bounds__(256, 2) void conv_f16_astat(ConvK p, const uint4* __restrict__ wsplit, unsigned w_bytes) {
+  constexpr int TN = BN / 32;
+  constexpr int NST = 3, PD = 2;
+  constexpr int B_STAGE = BN * 128;  // bytes: BN rows x 2 planes x 32 halves
+  constexpr int BROWS = BN / 4;      // B rows a wave loads per slab
+  constexpr int BI = BROWS / 8;      // its LDS-DMA instructions per slab
+  __shared__ __attribute__((aligned(16))) char lds[NST * B_STAGE];
+
+  const int t = threadIdx.x, wv = t >> 6, lane = t & 63, li = lane & 31, lh = lane >> 5;
+  const float2 sc = astat_scales((unsigned)__builtin_amdgcn_readfirstlane((int)amax_read(p.amax, t)));
+  const float sa = sc.x, inv_sa = sc.y;
+  int tile_m;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+    tile_m = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = tile_m * 128;
+  // column blocks of this block: [nb0, nb1)
+  const int per = (p.ntiles_n + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int nb0 = (int)blockIdx.y * per, nb1 = min(p.ntiles_n, nb0 + per);
+  if (nb0 >= nb1) return;
+
+  // ---- A: the lane's fragments of all KT tiles, loaded once.  MFMA 32x32x16 A operand: row li, k = 8 lh .. + 7 of the step
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+  const int m = m0 + 32 * wv + li;
+  const unsigned row_off = m < p.M ? (unsigned)m * (unsigned)p.in_ld * 4u : OOB_OFFSET;
+  as_hf16x8_t ah[KT][2], al[KT][2];
+  {
+    f32x4 u[KT][2], v[KT][2];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int c = kt * 32 + s * 16 + lh * 8;  // first channel of the lane's 8
+        const unsigned o0 = (row_off != OOB_OFFSET && c < p.C) ? row_off + (unsigned)c * 4u : OOB_OFFSET;
+        const unsigned o1 = (row_off != OOB_OFFSET && c + 4 < p.C) ? row_off + (unsigned)(c + 4) * 4u : OOB_OFFSET;
+        u[kt][s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)o0, 0, 0));
+        v[kt][s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)o1, 0, 0));
+      }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) astat_split8(u[kt][s], v[kt][s], sa, ah[kt][s], al[kt][s]);
+  }
+
+  // ---- B: slab q = (nb - nb0) KT + kt of this block's sequence -> stage q % 3, two slabs ahead
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wsplit), 0, w_bytes, 0x00020000);
+  const int jr = lane >> 3, js = lane & 7;
+  unsigned boff[BI];  // the lane's 16 bytes within column block 0, K tile 0 (panel rows are KT x 128 bytes)
+#pragma unroll
+  for (int j = 0; j < BI; ++j) {
+    const int row = BROWS * wv + 8 * j + jr;
+    boff[j] = (unsigned)row * (unsigned)(KT * 128) + (unsigned)((js ^ ((row >> 1) & 7)) * 16);
+  }
+  auto issue = [&](int nb, int kt, int st) {
+    char* Bs = lds + st * B_STAGE + (BROWS * wv) * 128;
+    const int soff = nb * BN * (KT * 128) + kt * 128;
+#pragma unroll
+    for (int j = 0; j < BI; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (as_lds_void*)(Bs + j * 1024), 16, (int)boff[j], soff, 0, 0);
+  };
+
+  const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (unsigned)p.M * (unsigned)p.out_ld * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.out), 0,
+                                                                          (unsigned)p.M * (unsigned)(p.res ? p.res_ld : p.out_ld) * 4u, 0x00020000);
+  unsigned am = 0u;
+  f32x16 acc[TN];
+#pragma unroll
+  for (int b = 0; b < TN; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+  const int bswz = (li >> 1) & 7;
+
+  const int total = (nb1 - nb0) * KT;
+  // the slab after (nb, kt) in the sequence
+  int inb = nb0, ikt = 0;
+  auto advance = [&]() {
+    if (++ikt == KT) {
+      ikt = 0;
+      ++inb;
+    }
+  };
+  issue(inb, ikt, 0);
+  advance();
+  if (total > 1) {
+    issue(inb, ikt, 1);
+    advance();
+  }
+  int st = 0, stp = PD, issued = total > 1 ? 2 : 1;
+  for (int nb = nb0; nb < nb1; ++nb) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const int q = (nb - nb0) * KT + kt;
+      // the counted wait assumes that everything outstanding is a slab DMA (loads return in order).  Right after a column
+      // block's epilogue the wave also has STORES in flight, which may return out of order with the loads: drain there
+      if (q + 1 < total && !(kt == 0 && nb > nb0)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const char* Bs = lds + st * B_STAGE + li * 128;
+        as_hf16x8_t bh[TN], bl[TN];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          bh[b] = *reinterpret_cast<const as_hf16x8_t*>(Bs + b * 32 * 128 + (((s * 2 + lh) ^ bswz) * 16));
+          bl[b] = *reinterpret_cast<const as_hf16x8_t*>(Bs + b * 32 * 128 + (((4 + s * 2 + lh) ^ bswz) * 16));
+        }
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kt][s], bh[b], acc[b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kt][s], bl[b], acc[b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kt][s], bh[b], acc[b], 0, 0, 0);
+        if (s == 0 && issued < total) {  // the slab two ahead, behind the first step's MFMAs
+          issue(inb, ikt, stp);
+          advance();
+          ++issued;
+        }
+      }
+      st = st == NST - 1 ? 0 : st + 1;
+      stp = stp == NST - 1 ? 0 : stp + 1;
+    }
+    // ---- this column block's outputs, straight from the accumulators; the stores drain under the next block's MFMAs
+    switch (p.act) {  // block-uniform
+      case ACT_RELU: astat_store<ACT_RELU, TN>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
+      case ACT_GELU: astat_store<ACT_GELU, TN>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
+      case ACT_SILU: astat_store<ACT_SILU, TN>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
+      default: astat_store<ACT_NONE, TN>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+  }
+  if (p.amax_out) amax_commit(p.amax_out, am, t);  // once per wave, over all its column blocks
+}
+
+template __global__ void conv_f16_astat<128, 2>(ConvK, const uint4*, unsigned);
+template __global__ void conv_f16_astat<128, 4>(ConvK, const uint4*, unsigned);
+template __global__ void conv_f16_astat<128, 6>(ConvK, const uint4*, unsigned);
+template __global__ void conv_f16_astat<128, 8>(ConvK, const uint4*, unsigned);
+template __global__ void conv_f16_astat<64, 8>(ConvK, const uint4*, unsigned);
+
+}  // namespace ymk
