@@ -117,3 +117,83 @@ def test_gpu_timeline_finds_the_job_and_its_busy_fraction(tmp_path):
     assert abs(out["sum_of_kernel_time_over_wall"] - 130.0 / 95.0) < 1e-2
     assert out["idle_ms_by_gap_size"][">1ms"] == 5.0 and out["largest_gaps"][0]["ms"] == 5.0
     assert set(out["kernel_time_ms_by_family"]) == {"conv_igemm", "k_layernorm"}
+
+
+def test_pmc_aggregate_by_grid_tells_the_shapes_of_one_kernel_apart(tmp_path):
+    d = str(tmp_path / "pmc")
+    os.makedirs(d)
+    with open(os.path.join(d, "x_counter_collection.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Dispatch_Id", "Grid_Size", "Kernel_Name", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"])
+        for i in range(4):  # two layer shapes on the same instantiation: 3 dispatches of one, 1 of the other
+            grid = 1024 if i < 3 else 4096
+            w.writerow([i + 1, grid, CONV, "SQ_WAVES", 100 * (i + 1), 1000 * i, 1000 * i + 200 + 100 * i])
+    out = str(tmp_path / "bygrid.csv")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_aggregate.py"), "bygrid", d, out], check=True, capture_output=True)
+    with open(out, newline="") as f:
+        rows = {r["grid"]: r for r in csv.DictReader(f)}
+    assert rows["1024"]["dispatches"] == "3" and float(rows["1024"]["sum"]) == 600 and float(rows["1024"]["mean_per_dispatch"]) == 200
+    assert float(rows["1024"]["mean_duration_us"]) == 0.3 and rows["4096"]["dispatches"] == "1" and float(rows["4096"]["mean_duration_us"]) == 0.5
+
+
+def test_two_roof_table_prices_each_shape_against_its_binding_roof(tmp_path):
+    lines = []
+    def dump(i, shape, tile, ksplit, us, flop, mb):
+        lines.append(f"[ymk-prof] {i:3d} {shape} tile={tile} ksplit={ksplit} grid=100  {us:8.1f} us  {flop / (us * 1e-6) / 1e12:6.1f} TFLOP/s  {mb:7.1f} MB\n")
+    for span in range(3):  # three repetitions of the pass, then a foreign span that must be ignored
+        # MFMA-bound on the fp16-plane kernel: 833.3 TFLOP/s-equivalent -> 83.33 GFLOP take 100 us at the roof; measured 400
+        dump(0, "M=  59200 Cin= 512 Cout= 512 k=3x3 s=1 d=2 res=0", "128x128", 161, 400.0, 83.3333e9, 100.0)
+        # HBM-bound: 1600 MB at 8 TB/s = 200 us; measured 500
+        dump(1, "M= 947200 Cin=  64 Cout= 256 k=1x1 s=1 d=1 res=1", "128x128", 160, 500.0, 1e9, 1600.0)
+        # exact fp32 kernel: 157.3 TFLOP/s -> 15.73 GFLOP take 100 us; measured 100 (on the roof)
+        dump(2, "M=   4400 Cin= 256 Cout= 256 k=3x3 s=1 d=1 res=0", "64x32", 4, 100.0, 15.73e9, 1.0)
+    dump(0, "M=      1 Cin=   4 Cout=   4 k=1x1 s=1 d=1 res=0", "64x64", 1, 9999.0, 1.0, 1.0)
+    src, dst = tmp_path / "dump.txt", tmp_path / "out.md"
+    src.write_text("noise\n" + "".join(lines))
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "two_roof.py"), str(src), str(dst), "3"], check=True, capture_output=True)
+    text = dst.read_text().splitlines()
+    assert text[0].startswith("3 launches per pass, 1.00 ms measured, 0.40 ms at the binding roofs (= 0.400)")
+    body = [ln for ln in text if ln.startswith("| `M=")]
+    assert len(body) == 3
+    first = [c.strip() for c in body[0].strip("|").split("|")]    # sorted by the time above the bound: the 3 x 3 layer and the expand tie at 300 us
+    by_shape = {ln.split("`")[1]: [c.strip() for c in ln.strip("|").split("|")] for ln in body}
+    conv3 = by_shape["M=59200 Cin=512 Cout=512 k=3x3 s=1 d=2 res=0"]
+    assert conv3[2] == "f16" and conv3[7] == "mfma" and conv3[8] == "0.25" and conv3[9] == "0.300"
+    expand = by_shape["M=947200 Cin=64 Cout=256 k=1x1 s=1 d=1 res=1"]
+    assert expand[7] == "hbm" and expand[8] == "0.40" and expand[6] == "3.20"
+    exact = by_shape["M=4400 Cin=256 Cout=256 k=3x3 s=1 d=1 res=0"]
+    assert exact[2] == "f32" and exact[8] == "1.00" and first[1] in ("128x128",)
+
+
+def test_two_roof_bound_of_the_bench_line():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    table = [(0.4, 83.3333e9, 100e6, 3.0), (0.5, 1e9, 1600e6, 3.0), (0.1, 15.73e9, 1e6, 0.0)]
+    r = bench.two_roof_bound(table)
+    assert r["launches"] == 3 and r["measured_ms"] == 1.0 and abs(r["two_roof_bound_ms"] - 0.4) < 1e-3
+    assert abs(r["frac_of_two_roof_bound"] - 0.4) < 1e-3 and r["hbm_bound_launches"] == 1 and r["hbm_bound_share_of_measured_time"] == 0.5
+    # with the achievable HBM rate the HBM-bound launch's bound grows by 8 / 6.29
+    assert abs(r["frac_with_achievable_hbm"] - (0.1 + 0.2 * 8000.0 / 6290.0 + 0.1)) < 2e-3
+    assert bench.two_roof_bound([]) is None
+
+
+def test_hbm_table_divides_bytes_by_kernel_time(tmp_path):
+    stats, fetch, write, out = (str(tmp_path / n) for n in ("stats.csv", "fetch.csv", "write.csv", "out.md"))
+    with open(stats, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs"])
+        w.writerow([CONV, 10, 1_000_000, 100_000])
+        w.writerow([OTHER, 5, 100, 20])  # below 0.05 % of the time: left out
+    for path, counter, kb in ((fetch, "FETCH_SIZE", 1_000_000.0), (write, "WRITE_SIZE", 500_000.0)):
+        with open(path, "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "counter", "dispatch_rows", "sum"])
+            w.writerow([CONV, counter, 10, kb])
+            w.writerow([OTHER, counter, 5, 1.0])
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hbm_table.py"), stats, fetch, write, out], check=True, capture_output=True)
+    rows = [ln for ln in open(out).read().splitlines() if ln.startswith("| `")]
+    assert len(rows) == 1
+    cells = [c.strip() for c in rows[0].strip("|").split("|")]
+    # (2 x 1e6 KB + 0.5e6 KB) x 1024 B over 1 ms = 2.56 TB/s; 256 MB per call
+    assert cells[1] == "10" and cells[4] == "256.0" and cells[5] == "2.56" and cells[6] == "0.41"
