@@ -193,6 +193,14 @@ int ymk_op_conv2d(const float* x_dev, int n, int h, int w, int c, /* c % 4 == 0,
 /* rows x d LayerNorm (eps as given); attention over contiguous [b][l][heads*hd] q/k/v with optional
  * boolean masks (non-zero = blocked): mask_qk [lq][lk], kpm [b][lk]; use_small selects the masked
  * small-query kernel even without masks (otherwise the fp32-MFMA flash kernel runs). */
+/* CANDIDATE kernel, not dispatched by the models (yomitoku_amd/csrc/ymk_conv_astat.hip): a 1 x 1
+ * layer with K = c <= 256 through the A-stationary fp16-split kernel - y[m][cout] = act(scale * (x[m][c] . w^T) + bias + res),
+ * w_host_oc: [cout][c] on the host, x / res / y on the device.  Same arithmetic as the fp16-split kernels ymk_op_conv2d runs
+ * under ymk_debug_option("conv_split", 16): the results are compared bit for bit (tests/test_conv_astat_gpu.py).  The launch
+ * is repeated `reps` times; *kernel_ms = HIP-event time of the last one (the planes and the max|x| pass are outside it). */
+int ymk_op_conv1x1_astat(const float* x_dev, int m, int c, const float* w_host_oc, int cout, const float* scale_host,
+                         const float* bias_host, const float* res_dev, int act, float* y_dev, int reps, float* kernel_ms, void* stream);
+
 int ymk_op_layernorm(const float* x_dev, int rows, int d, const float* g_dev, const float* b_dev, float eps,
                      float* y_dev, void* stream);
 int ymk_op_attention(const float* q_dev, const float* k_dev, const float* v_dev, float* o_dev, int b, int heads, int lq,

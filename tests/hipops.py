@@ -54,6 +54,28 @@ def conv2d(x, weight, scale=None, bias=None, residual=None, stride=1, padding=0,
     return _nchw(y)
 
 
+def conv1x1_astat(x, weight, scale=None, bias=None, residual=None, act="none", reps=1):
+    """The candidate A-stationary kernel (ymk_op_conv1x1_astat): x [M, C] on the device, weight [Cout, C] -> (y [M, Cout], ms of
+    the last of `reps` launches)."""
+    import ctypes
+
+    lib = _lib.load()
+    assert x.is_cuda and x.dim() == 2
+    m, c = x.shape
+    cout = weight.shape[0]
+    xh = x.float().contiguous()
+    wh = weight.detach().float().cpu().contiguous()
+    sh = scale.detach().float().cpu().contiguous() if scale is not None else None
+    bh = bias.detach().float().cpu().contiguous() if bias is not None else None
+    rh = residual.float().contiguous() if residual is not None else None
+    y = torch.empty((m, cout), dtype=torch.float32, device=x.device)
+    ms = ctypes.c_float()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.ymk_op_conv1x1_astat(xh.data_ptr(), m, c, wh.data_ptr(), cout, _lib.ptr(sh), _lib.ptr(bh), _lib.ptr(rh), ACT[act],
+                                            y.data_ptr(), reps, ctypes.byref(ms), _lib.current_stream_ptr()), "ymk_op_conv1x1_astat")
+    return y, float(ms.value)
+
+
 def maxpool3x3s2(x):
     lib = _lib.load()
     n, c, h, w = x.shape

@@ -1,0 +1,80 @@
+"""The candidate A-stationary fp16-split 1 x 1 kernel (yomitoku_amd/csrc/ymk_conv_astat.hip, reachable through
+ymk_op_conv1x1_astat only) against (a) an fp64 product on the CPU, with the tolerance of the other fp16-split kernels, and
+(b) the fp16-split kernels the models run (ymk_op_conv2d under ymk_debug_option("conv_split", 16)), bit for bit - the
+arithmetic is meant to be the same, only the schedule differs."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+M = 33000  # 258 row blocks of 128: the library's own fp16 path takes every case (>= 256 tiles), and the last block is ragged
+
+# (C, Cout, act, scale, bias, residual)
+CASES = [
+    (192, 576, "none", False, True, False),   # PARSeq-tiny qkv: six K tiles, 4.5 column blocks
+    (64, 256, "relu", True, True, True),      # ResNet layer1 expand
+    (128, 512, "relu", True, True, True),     # layer2 expand
+    (192, 768, "gelu", False, True, False),   # ViT fc1
+    (256, 192, "silu", True, False, False),   # eight K tiles: the 64-column form
+    (96, 100, "none", False, True, True),     # ragged Cout, three K tiles
+    (32, 64, "relu", True, True, False),      # one K tile, one narrow column block
+    (72, 130, "sigmoid", False, False, False),  # C not a multiple of 32: the K padding is read as zeros
+]
+
+
+def _reference(x, w, scale, bias, res, act):
+    y = x.double().cpu() @ w.double().t()
+    if scale is not None:
+        y = y * scale.double()
+    if bias is not None:
+        y = y + bias.double()
+    if res is not None:
+        y = y + res.double().cpu()
+    if act == "relu":
+        y = y.clamp(min=0)
+    elif act == "gelu":
+        y = torch.nn.functional.gelu(y)
+    elif act == "silu":
+        y = torch.nn.functional.silu(y)
+    elif act == "sigmoid":
+        y = torch.sigmoid(y)
+    return y
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}to{c[1]}_{c[2]}")
+def test_astat_matches_fp64_and_the_library_kernels(dev, case):
+    from tests import hipops
+    from yomitoku_amd import _lib
+
+    c, cout, act, use_scale, use_bias, use_res = case
+    g = torch.Generator().manual_seed(c * 1000 + cout)
+    x = (torch.randn(M, c, generator=g) * 3.0).to(dev)
+    w = torch.randn(cout, c, generator=g) / c ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5 if use_scale else None
+    bias = torch.randn(cout, generator=g) if use_bias else None
+    res = torch.randn(M, cout, generator=g).to(dev) if use_res else None
+    y, ms = hipops.conv1x1_astat(x, w, scale, bias, res, act)
+    assert ms > 0
+    ref = _reference(x, w, scale, bias, res, act)
+    err = (y.double().cpu() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    assert err < 3e-6, err
+    # the kernels the models run, on the same operands: NCHW views of the same rows
+    lib = _lib.load()
+    try:
+        _lib.debug_option("conv_split", 16)
+        _lib.check(lib.ymk_prof_begin())
+        y_lib = hipops.conv2d(x.t().reshape(1, c, 1, M), w.reshape(cout, c, 1, 1), scale, bias,
+                              res.t().reshape(1, cout, 1, M) if res is not None else None, act=act)
+        ms_l, fl, ln = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        _lib.check(lib.ymk_prof_end(ctypes.byref(ms_l), ctypes.byref(fl), ctypes.byref(ln)))
+    finally:
+        _lib.debug_option("conv_split", -1)
+    rows = _lib.prof_launch_table()
+    assert len(rows) == 1 and rows[0][3] == 3.0, rows  # the library did take its fp16-plane path
+    y_lib = y_lib.reshape(cout, M).t()
+    if cout % 4 == 0:  # the library's 16-byte epilogue: the same expression per value
+        assert torch.equal(y, y_lib), (y - y_lib).abs().max().item()
+    else:  # ragged Cout: the library stores through another epilogue form; same values to rounding
+        assert (y - y_lib).abs().max().item() <= 2e-6 * max(1.0, y_lib.abs().max().item())

@@ -67,6 +67,10 @@ SIGNATURES = {
         [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
          c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     ),
+    "ymk_op_conv1x1_astat": (
+        c_int,
+        [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, POINTER(c_float), c_void_p],
+    ),
     "ymk_op_layernorm": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "ymk_op_attention": (
         c_int,

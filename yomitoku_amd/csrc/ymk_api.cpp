@@ -18,6 +18,8 @@ void prof_begin();
 void prof_end(double* ms, double* flop, int64_t* launches);
 double prof_bytes();
 int64_t prof_launch_table(double* ms, double* flop, double* bytes, double* products, int64_t capacity);
+void conv1x1_f16_astat(hipStream_t s, const float* x, int M, int C, const ConvW& w, const float* res, int act, float* y, int reps,
+                       float* kernel_ms);  // ymk_conv_astat.hip
 bool conv_debug_option(const std::string& key, int value);
 bool parseq_debug_option(const std::string& key, int value);
 bool decstep_debug_option(const std::string& key, int value);
@@ -244,6 +246,24 @@ int ymk_op_conv2d(const float* x_dev, int n, int h, int w, int c, const float* w
   ConvSplitScope scope(-1, split_ctx.get(), 0);  // single operators: exact fp32 unless the process-wide option says otherwise
   conv2d((hipStream_t)stream, in, cw, a, out);
   YMK_HIP(hipStreamSynchronize((hipStream_t)stream));  // pool frees the panel on return
+  YMK_API_END
+}
+
+int ymk_op_conv1x1_astat(const float* x_dev, int m, int c, const float* w_host_oc, int cout, const float* scale_host,
+                         const float* bias_host, const float* res_dev, int act, float* y_dev, int reps, float* kernel_ms, void* stream) {
+  YMK_API_BEGIN
+  using namespace ymk;
+  YMK_CHECK(x_dev && w_host_oc && y_dev && m > 0 && c > 0 && cout > 0, "bad argument");
+  DevicePool pool;
+  ConvW cw;
+  cw.cout = cout;
+  cw.cin = c;
+  std::vector<float> panel;
+  pack_conv_weight(w_host_oc, cout, c, 1, 1, false, panel, cw.kpad, cw.ctiles);
+  cw.w = pool.upload(panel);
+  if (scale_host) cw.scale = pool.upload(scale_host, cout);
+  if (bias_host) cw.bias = pool.upload(bias_host, cout);
+  conv1x1_f16_astat((hipStream_t)stream, x_dev, m, c, cw, res_dev, act, y_dev, reps, kernel_ms);
   YMK_API_END
 }
 

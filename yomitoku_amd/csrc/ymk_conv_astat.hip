@@ -1,22 +1,26 @@
-// DRAFT - NOT part of libymk_hip.so, never launched: the A-stationary form of the fp16-split 1 x 1 convolution that
-// DESIGN.md section 9 (item 1) proposes for the short-K layers (K <= 256: the PARSeq encoder's qkv / fc1 / proj, the ResNet
-// expands, the DBNet decoder's 256 -> 256).  It is kept here, outside the library, for what the compiler says about it
-// (registers, spills, LDS: tools/drafts/README.md) and as the starting point of the next round; it becomes a kernel when
-// it has a green bit-identity test against conv_igemm_split<.., FMT = 1> and a line in tools/conv_sweep.py.
+// A-stationary fp16-split 1 x 1 convolution for short K (K <= 256): CANDIDATE kernel - conv2d does not dispatch to it; it
+// is reachable only through ymk_op_conv1x1_astat (include/ymk.h), where tests/test_conv_astat_gpu.py compares it with the
+// kernels the models run and tools/conv_sweep.py times it.  Why it exists: DESIGN.md section 9 item 1,
+// profiles/r04_conv_two_roof_by_layer.md (the K = 192 linear layers of the PARSeq encoder at 0.22-0.45 of their HBM roof, the
+// ResNet expands at 0.38-0.57) and profiles/r04_conv_f16_short_k_pmc_pass*.csv (their waves wait two thirds of their cycles,
+// 16 VALU + 12.6 SALU instructions per MFMA: every 128 x 128 tile pays the A fetch, the fp32 -> (h, l) conversion and the
+// prologue again for a K loop of 2-8 steps).  References for the layers: models/layers/parseq_transformer.py:188-204 (timm ViT
+// blocks), models/dbnet_plus.py:33-38 (ResNet-50 bottlenecks).
 //
-// Same arithmetic as conv_f16_dma (yomitoku_amd/csrc/ymk_conv_dma.hip): two scaled fp16 planes per fp32 operand, the three
-// MFMAs of a product tile in the same order, the same K order - so the results must equal that kernel's bit for bit.
-// What changes is who waits for what:
-//   * a block owns 128 rows (4 waves x 32) for ALL column blocks of the layer.  Each wave loads ITS 32 rows of A once,
-//     straight into registers (buffer loads, a row past M or a channel past C is an out-of-range offset -> zeros), and
-//     converts them to the two planes once: 8 VGPRs per 16-k step, 16 KT VGPRs for K = 32 KT (96 at K = 192).  No LDS, no
-//     barrier and no second conversion for A, whatever the number of column blocks (6 for fc1: today its A rows are fetched
-//     and converted six times);
+// Same arithmetic as conv_f16_dma (ymk_conv_dma.hip): two scaled fp16 planes per fp32 operand, the three MFMAs of a product
+// tile in the same order, the same K order - the results must equal that kernel's bit for bit.  What changes is who waits:
+//   * a block owns 128 rows (4 waves x 32) for ALL column blocks of the layer (or of its column group).  Each wave loads ITS
+//     32 rows of A once, straight into registers (buffer loads; a row past M or a channel past C is an out-of-range offset ->
+//     zeros), and converts them to the two planes once: 8 VGPRs per 16-k step, 16 KT VGPRs for K = 32 KT (96 at K = 192).
+//     No LDS, no barrier and no second conversion for A, whatever the number of column blocks (6 for fc1: the tiled kernels
+//     fetch and convert its A rows six times);
 //   * the weight slabs (BN columns x 32 k x 2 planes = 16 KB at BN = 128) flow through three LDS stages by LDS-DMA as ONE
-//     sequence over (column block, K tile) - the pipeline never drains between column blocks;
-//   * a column block's accumulators go out straight from registers (epilogue_direct: 128-byte row segments) while the next
-//     block's slabs are already landing; with two blocks per CU the other block's MFMAs cover this one's epilogue arithmetic.
-#include "../../yomitoku_amd/csrc/ymk_conv_kernel.h"
+//     sequence over (column block, K tile) - the pipeline does not drain between column blocks;
+//   * a column block's accumulators go out straight from registers, four rows at a time through buffer descriptors; with two
+//     blocks per CU (K = 192 at 128 columns: 255 VGPRs, 48 KB of LDS) the other block's MFMAs cover this one's epilogue.
+#include <string>
+
+#include "ymk_conv_kernel.h"
 
 namespace ymk {
 
@@ -51,7 +55,7 @@ __device__ __forceinline__ void astat_split8(const f32x4 u, const f32x4 v, float
 // one column block of a wave (32 rows x 32 TN columns) out of the accumulators: scale / bias / residual / activation as
 // epilogue_tile does (same expression per value), through buffer descriptors with 32-bit offsets, four rows at a time -
 // the direct epilogue of ymk_conv_kernel.h keeps sixteen 64-bit addresses and sixteen residual values live, which is
-// what pushed the first form of this draft past 256 registers
+// what pushed the first form of this kernel past 256 registers
 template <int ACT, int TN>
 __device__ __forceinline__ void astat_store(const ConvK& p, const f32x16 (&acc)[TN], float inv_sa, int mw, int n0, int li, int lh,
                                             __amdgpu_buffer_rsrc_t rsrc_o, __amdgpu_buffer_rsrc_t rsrc_r, unsigned& am) {
@@ -221,6 +225,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_astat(ConvK p, const uint4* _
       case ACT_RELU: astat_store<ACT_RELU, TN>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
       case ACT_GELU: astat_store<ACT_GELU, TN>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
       case ACT_SILU: astat_store<ACT_SILU, TN>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
+      case ACT_SIGMOID: astat_store<ACT_SIGMOID, TN>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
       default: astat_store<ACT_NONE, TN>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
     }
 #pragma unroll
@@ -231,10 +236,108 @@ __global__ __launch_bounds__(256, 2) void conv_f16_astat(ConvK p, const uint4* _
   if (p.amax_out) amax_commit(p.amax_out, am, t);  // once per wave, over all its column blocks
 }
 
-template __global__ void conv_f16_astat<128, 2>(ConvK, const uint4*, unsigned);
-template __global__ void conv_f16_astat<128, 4>(ConvK, const uint4*, unsigned);
-template __global__ void conv_f16_astat<128, 6>(ConvK, const uint4*, unsigned);
-template __global__ void conv_f16_astat<128, 8>(ConvK, const uint4*, unsigned);
-template __global__ void conv_f16_astat<64, 8>(ConvK, const uint4*, unsigned);
+
+// ymk_conv_split.hip: builds the two fp16 planes of a packed fp32 panel (channel-major K order) and the epilogue scale
+__global__ void k_split_panel_f16(const float* __restrict__ w, unsigned short* __restrict__ out, int kpad, const float* __restrict__ scale,
+                                  int cout, float* __restrict__ scale_out, int taps, int ctiles);
+
+template <int BN, int KT>
+static void launch_astat(hipStream_t s, ConvK& k, const void* planes, size_t w_bytes, int groups) {
+  k.ntiles_n = (k.Cout + BN - 1) / BN;
+  hipLaunchKernelGGL((conv_f16_astat<BN, KT>), dim3((k.M + 127) / 128, groups), dim3(256), 0, s, k, reinterpret_cast<const uint4*>(planes), (unsigned)w_bytes);
+}
+
+// y[M][Cout] = act(scale * (x[M][C] . W^T) + bias + res) through the A-stationary kernel; w: packed fp32 panel of a 1 x 1
+// layer (pack_conv_weight), planes and max|x| record built here per call (a test operator: nothing is cached).
+// kernel_ms: HIP-event time of the convolution launch alone (the last of `reps` launches).
+void conv1x1_f16_astat(hipStream_t s, const float* x, int M, int C, const ConvW& w, const float* res, int act, float* y, int reps,
+                       float* kernel_ms) {
+  YMK_CHECK(w.kh == 1 && w.kw == 1 && w.mode == 0 && w.cin == C && C % 4 == 0, "astat: a packed 1 x 1 layer with C % 4 == 0");
+  YMK_CHECK(w.kpad % 32 == 0 && w.kpad >= 32 && w.kpad <= 256, "astat: K <= 256");
+  YMK_CHECK(M > 0 && (size_t)M * (size_t)std::max(C, w.cout) * 4 < (size_t)OOB_OFFSET, "astat: views below 4 GiB");
+  const size_t rows = (size_t)((w.cout + 255) / 256 * 256), real = (size_t)((w.cout + 127) / 128 * 128);
+  const size_t w_bytes = rows * w.kpad * 2 * 2;
+  YMK_CHECK(w_bytes < (size_t)OOB_OFFSET, "astat: weight planes below 4 GiB");
+  void* planes = nullptr;
+  float* wscale = nullptr;
+  unsigned* rec = nullptr;
+  YMK_HIP(hipMalloc(&planes, w_bytes));
+  YMK_HIP(hipMalloc(reinterpret_cast<void**>(&wscale), real * sizeof(float)));
+  YMK_HIP(hipMalloc(reinterpret_cast<void**>(&rec), AMAX_REC_WORDS * sizeof(unsigned)));
+  hipEvent_t e0, e1;
+  YMK_HIP(hipEventCreate(&e0));
+  YMK_HIP(hipEventCreate(&e1));
+  YMK_HIP(hipMemsetAsync(planes, 0, w_bytes, s));
+  YMK_HIP(hipMemsetAsync(rec, 0, AMAX_REC_WORDS * sizeof(unsigned), s));
+  hipLaunchKernelGGL(k_split_panel_f16, dim3((unsigned)real), dim3(256), 0, s, w.w, reinterpret_cast<unsigned short*>(planes), w.kpad, w.scale,
+                     w.cout, wscale, 1, w.ctiles);
+  absmax_record(s, x, (size_t)M * C, rec);
+  ConvK k{};
+  k.in = x;
+  k.scale = wscale;
+  k.bias = w.bias;
+  k.res = res;
+  k.res_ld = res ? w.cout : 0;
+  k.out = y;
+  k.H = 1;
+  k.W = M;
+  k.C = C;
+  k.in_ld = C;
+  k.KH = k.KW = 1;
+  k.stride = k.stride_w = 1;
+  k.dil = 1;
+  k.OH = 1;
+  k.OW = M;
+  k.Cout = w.cout;
+  k.out_ld = w.cout;
+  k.Kpad = w.kpad;
+  k.ctiles = w.ctiles;
+  k.M = M;
+  k.act = act;
+  k.epi = EPI_STORE;
+  k.in_bytes = (unsigned)((size_t)M * C * 4);
+  k.amax = rec;
+  // few row blocks: deal the column blocks to groups so that the launch still covers the chip (A is then loaded per group)
+  const int mblocks = (M + 127) / 128;
+  const bool narrow = w.kpad > 192 || w.cout <= 64;
+  const int nt = (w.cout + (narrow ? 63 : 127)) / (narrow ? 64 : 128);
+  int groups = 1;
+  while (mblocks * groups < 512 && groups * 2 <= nt) groups *= 2;
+  for (int r = 0; r < std::max(1, reps); ++r) {
+    YMK_HIP(hipEventRecord(e0, s));
+    if (narrow) {
+      switch (w.kpad / 32) {
+        case 1: launch_astat<64, 1>(s, k, planes, w_bytes, groups); break;
+        case 2: launch_astat<64, 2>(s, k, planes, w_bytes, groups); break;
+        case 3: launch_astat<64, 3>(s, k, planes, w_bytes, groups); break;
+        case 4: launch_astat<64, 4>(s, k, planes, w_bytes, groups); break;
+        case 5: launch_astat<64, 5>(s, k, planes, w_bytes, groups); break;
+        case 6: launch_astat<64, 6>(s, k, planes, w_bytes, groups); break;
+        case 7: launch_astat<64, 7>(s, k, planes, w_bytes, groups); break;
+        default: launch_astat<64, 8>(s, k, planes, w_bytes, groups); break;
+      }
+    } else {
+      switch (w.kpad / 32) {
+        case 1: launch_astat<128, 1>(s, k, planes, w_bytes, groups); break;
+        case 2: launch_astat<128, 2>(s, k, planes, w_bytes, groups); break;
+        case 3: launch_astat<128, 3>(s, k, planes, w_bytes, groups); break;
+        case 4: launch_astat<128, 4>(s, k, planes, w_bytes, groups); break;
+        case 5: launch_astat<128, 5>(s, k, planes, w_bytes, groups); break;
+        default: launch_astat<128, 6>(s, k, planes, w_bytes, groups); break;
+      }
+    }
+    YMK_HIP(hipEventRecord(e1, s));
+  }
+  YMK_HIP(hipGetLastError());
+  YMK_HIP(hipStreamSynchronize(s));
+  float ms = 0.f;
+  YMK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  if (kernel_ms) *kernel_ms = ms;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(planes);
+  (void)hipFree(wscale);
+  (void)hipFree(rec);
+}
 
 }  // namespace ymk
