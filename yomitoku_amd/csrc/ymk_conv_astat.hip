@@ -56,7 +56,7 @@ __device__ __forceinline__ void astat_split8(const f32x4 u, const f32x4 v, float
 // epilogue_tile does (same expression per value), through buffer descriptors with 32-bit offsets, four rows at a time -
 // the direct epilogue of ymk_conv_kernel.h keeps sixteen 64-bit addresses and sixteen residual values live, which is
 // what pushed the first form of this kernel past 256 registers
-template <int ACT, int TN>
+template <int ACT, int TN, int RG>
 __device__ __forceinline__ void astat_store(const ConvK& p, const f32x16 (&acc)[TN], float inv_sa, int mw, int n0, int li, int lh,
                                             __amdgpu_buffer_rsrc_t rsrc_o, __amdgpu_buffer_rsrc_t rsrc_r, unsigned& am) {
 #pragma unroll
@@ -67,27 +67,27 @@ __device__ __forceinline__ void astat_store(const ConvK& p, const f32x16 (&acc)[
     const float bi = (p.bias && cok) ? p.bias[co] : 0.f;
     const int row0 = mw + 4 * lh;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      unsigned oo[4];
-      float rr[4];
+    for (int r0 = 0; r0 < 16; r0 += RG) {  // RG accumulator rows at a time: their residual values are fetched together
+      float rr[RG];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = row0 + 8 * g + i;
-        const bool ok = cok && row < p.M;
-        oo[i] = ok ? ((unsigned)row * (unsigned)p.out_ld + (unsigned)co) * 4u : OOB_OFFSET;
-        const unsigned ro = ok ? ((unsigned)row * (unsigned)p.res_ld + (unsigned)co) * 4u : OOB_OFFSET;
+      for (int i = 0; i < RG; ++i) {
+        const int r = r0 + i, row = row0 + (r & 3) + 8 * (r >> 2);
+        const unsigned ro = (cok && row < p.M) ? ((unsigned)row * (unsigned)p.res_ld + (unsigned)co) * 4u : OOB_OFFSET;
         rr[i] = p.res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_r, (int)ro, 0, 0)) : 0.f;
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float v = (acc[b][4 * g + i] * inv_sa) * sc + bi;
+      for (int i = 0; i < RG; ++i) {
+        const int r = r0 + i, row = row0 + (r & 3) + 8 * (r >> 2);
+        const bool ok = cok && row < p.M;
+        const unsigned oo = ok ? ((unsigned)row * (unsigned)p.out_ld + (unsigned)co) * 4u : OOB_OFFSET;
+        float v = (acc[b][r] * inv_sa) * sc + bi;
         if (p.res && !p.res_post) v += rr[i];
         v = apply_act(v, ACT);
         if (p.res_post) v += rr[i];
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_o, (int)oo[i], 0, 0);
-        if (oo[i] != OOB_OFFSET) amax_fold(am, v);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_o, (int)oo, 0, 0);
+        if (ok) amax_fold(am, v);
       }
-      // four rows at a time: without the fence the scheduler hoists every residual load of the tile, and without pinning
+      // a group at a time: without the fence the scheduler hoists every residual load of the tile, and without pinning
       // `am` the max-chain is re-associated into a tree over all 16 TN values of the wave (56 registers: measured)
       asm volatile("" : "+v"(am));
       __builtin_amdgcn_sched_barrier(0);
@@ -100,6 +100,7 @@ __device__ __forceinline__ void astat_store(const ConvK& p, const f32x16 (&acc)[
 template <int BN, int KT>
 __global__ __launch_bounds__(256, 2) void conv_f16_astat(ConvK p, const uint4* __restrict__ wsplit, unsigned w_bytes) {
   constexpr int TN = BN / 32;
+  constexpr int RG = KT * 16 + TN * 24 <= 160 ? 16 : 4;  // residual values in flight per lane: as many as the registers allow
   constexpr int NST = 3, PD = 2;
   constexpr int B_STAGE = BN * 128;  // bytes: BN rows x 2 planes x 32 halves
   constexpr int BROWS = BN / 4;      // B rows a wave loads per slab
@@ -222,11 +223,11 @@ __global__ __launch_bounds__(256, 2) void conv_f16_astat(ConvK p, const uint4* _
     }
     // ---- this column block's outputs, straight from the accumulators; the stores drain under the next block's MFMAs
     switch (p.act) {  // block-uniform
-      case ACT_RELU: astat_store<ACT_RELU, TN>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
-      case ACT_GELU: astat_store<ACT_GELU, TN>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
-      case ACT_SILU: astat_store<ACT_SILU, TN>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
-      case ACT_SIGMOID: astat_store<ACT_SIGMOID, TN>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
-      default: astat_store<ACT_NONE, TN>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
+      case ACT_RELU: astat_store<ACT_RELU, TN, RG>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
+      case ACT_GELU: astat_store<ACT_GELU, TN, RG>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
+      case ACT_SILU: astat_store<ACT_SILU, TN, RG>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
+      case ACT_SIGMOID: astat_store<ACT_SIGMOID, TN, RG>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
+      default: astat_store<ACT_NONE, TN, RG>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
     }
 #pragma unroll
     for (int b = 0; b < TN; ++b)
