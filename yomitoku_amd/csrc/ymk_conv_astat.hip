@@ -1,6 +1,6 @@
 // A-stationary fp16-split 1 x 1 convolution for short K (K <= 256): CANDIDATE kernel - conv2d does not dispatch to it; it
 // is reachable only through ymk_op_conv1x1_astat (include/ymk.h), where tests/test_conv_astat_gpu.py compares it with the
-// kernels the models run and tools/conv_sweep.py times it.  Why it exists: DESIGN.md section 9 item 1,
+// kernels the models run (bit for bit) and tools/astat_timing.py times it (profiles/r04_conv_astat_candidate_timing.jsonl).  Why it exists: DESIGN.md section 9 item 1,
 // profiles/r04_conv_two_roof_by_layer.md (the K = 192 linear layers of the PARSeq encoder at 0.22-0.45 of their HBM roof, the
 // ResNet expands at 0.38-0.57) and profiles/r04_conv_f16_short_k_pmc_pass*.csv (their waves wait two thirds of their cycles,
 // 16 VALU + 12.6 SALU instructions per MFMA: every 128 x 128 tile pays the A fetch, the fp32 -> (h, l) conversion and the
