@@ -78,3 +78,42 @@ def test_astat_matches_fp64_and_the_library_kernels(dev, case):
         assert torch.equal(y, y_lib), (y - y_lib).abs().max().item()
     else:  # ragged Cout: the library stores through another epilogue form; same values to rounding
         assert (y - y_lib).abs().max().item() <= 2e-6 * max(1.0, y_lib.abs().max().item())
+
+
+# (M, C, Cout, act, bias, residual): ragged and tiny launches - a single row, a second row block with two rows, four
+# channels, more column groups than column blocks can fill, the vocabulary head's width
+EDGE_CASES = [
+    (1, 192, 576, "none", True, False),
+    (130, 64, 256, "relu", True, True),
+    (127, 4, 8, "none", False, False),
+    (200, 192, 7119, "none", True, False),
+    (4099, 256, 64, "relu", True, True),
+]
+
+
+@pytest.mark.parametrize("case", EDGE_CASES, ids=lambda c: f"{c[0]}x{c[1]}to{c[2]}")
+def test_astat_edge_shapes_match_fp64(dev, case):
+    from tests import hipops
+
+    m, c, cout, act, use_bias, use_res = case
+    g = torch.Generator().manual_seed(m + c + cout)
+    x = torch.randn(m, c, generator=g).to(dev)
+    w = torch.randn(cout, c, generator=g) / c ** 0.5
+    bias = torch.randn(cout, generator=g) if use_bias else None
+    res = torch.randn(m, cout, generator=g).to(dev) if use_res else None
+    y, _ = hipops.conv1x1_astat(x, w, None, bias, res, act)
+    assert y.shape == (m, cout) and torch.isfinite(y).all()
+    ref = _reference(x, w, None, bias, res, act)
+    err = (y.double().cpu() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    assert err < 3e-6, err
+
+
+def test_astat_refuses_what_it_cannot_run(dev):
+    from tests import hipops
+    from yomitoku_amd._lib import YmkError
+
+    x = torch.randn(64, 288).to(dev)  # K = 288 > 256
+    with pytest.raises(YmkError):
+        hipops.conv1x1_astat(x, torch.randn(32, 288))
+    with pytest.raises(YmkError):
+        hipops.conv1x1_astat(torch.randn(64, 30).to(dev), torch.randn(32, 30))  # channels not a multiple of 4
