@@ -74,7 +74,9 @@ def split_mode():
 
 
 def kernel_source_sha():
-    """Hash of the convolution kernels' sources: stamps PMC-derived numbers kept under profiles/ (stale once a kernel changes)."""
+    """Hash of the convolution kernels' sources: stamps PMC-derived numbers kept under profiles/ (stale once a kernel changes).
+    ymk_conv_astat.hip is not in the list while no model dispatches to it (a candidate behind ymk_op_conv1x1_astat): it joins
+    the list in the commit that routes a layer to it."""
     import hashlib
 
     h = hashlib.sha256()
