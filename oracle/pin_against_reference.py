@@ -760,6 +760,119 @@ def pin_searchable_pdf():
           f"{sum(len(d.words) for d in docs)} words in")
 
 
+REFERENCE_UNIT_TESTS = ["test_extract_paragraph_within_figure", "test_combile_flags", "test_judge_page_direction",
+                        "test_extract_words_within_element", "test_is_vertical", "test_is_noise", "test_recursive_update",
+                        "test_extract_words_within_table", "test_calc_overlap_words_on_lines", "test_correct_vertical_word_boxes",
+                        "test_correct_horizontal_word_boxes", "test_split_text_across_cells"]
+REFERENCE_UNIT_FUNCTIONS = ["extract_paragraph_within_figure", "combine_flags", "judge_page_direction", "extract_words_within_element",
+                            "is_vertical", "is_noise", "recursive_update", "_extract_words_within_table", "_calc_overlap_words_on_lines",
+                            "_correct_vertical_word_boxes", "_correct_horizontal_word_boxes", "_split_text_across_cells"]
+
+
+def _plain(v):
+    """Arguments and results of the recorded calls as JSON: pydantic models tagged with their class name, tuples and arrays
+    tagged, everything else as it is."""
+    if hasattr(v, "model_dump"):
+        return {"__model__": type(v).__name__, "fields": v.model_dump()}
+    if isinstance(v, np.ndarray):
+        return {"__ndarray__": v.tolist()}
+    if isinstance(v, np.generic):
+        return v.item()
+    if isinstance(v, tuple):
+        return {"__tuple__": [_plain(x) for x in v]}
+    if isinstance(v, list):
+        return [_plain(x) for x in v]
+    if isinstance(v, dict):
+        return {k: _plain(x) for k, x in v.items()}
+    return v
+
+
+def pin_reference_unit_tests():
+    """The reference's OWN unit tests of the aggregation helpers (tests/test_document_analyzer.py:116-600), run here against
+    the reference's own functions with every call recorded: (function, arguments before the call, result) ->
+    tests/golden/reference_unit_cases.json.  tests/test_reference_unit_cases.py replays the calls on yomitoku_amd's
+    functions.  The test bodies are lifted by ast (the file's imports - cv2, omegaconf, the model classes - never run) and
+    their own asserts hold while recording, so the recorded results are the known answers the reference's authors wrote."""
+    import ast
+    import copy
+    import json
+
+    import pytest
+
+    from ._refstubs import REF_SRC
+
+    da = _ref_document_analyzer()
+    sch = __import__("yomitoku.schemas", fromlist=["x"])
+    records = []
+
+    def recorder(name, fn, module="document_analyzer"):
+        def wrapped(*args, **kwargs):
+            before = (_plain(copy.deepcopy(args)), _plain(copy.deepcopy(kwargs)))
+            out = fn(*args, **kwargs)
+            records.append({"module": module, "fn": name, "args": before[0]["__tuple__"], "kwargs": before[1], "result": _plain(copy.deepcopy(out)),
+                            "args_after": _plain(copy.deepcopy(args))["__tuple__"]})  # some helpers work in place
+            return out
+        return wrapped
+
+    env = {name: recorder(name, getattr(da, name)) for name in REFERENCE_UNIT_FUNCTIONS}
+    for cls in ("DocumentAnalyzerSchema", "ParagraphSchema", "FigureSchema", "TextDetectorSchema", "TableStructureRecognizerSchema",
+                "TableLineSchema", "TableCellSchema", "WordPrediction"):
+        env[cls] = getattr(sch, cls)
+    env.update(pytest=pytest, np=np)
+    path = os.path.join(os.path.dirname(REF_SRC), "tests", "test_document_analyzer.py")
+    tree = ast.parse(open(path, encoding="utf-8").read())
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in REFERENCE_UNIT_TESTS]
+    assert {n.name for n in body} == set(REFERENCE_UNIT_TESTS), sorted(set(REFERENCE_UNIT_TESTS) - {n.name for n in body})
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), env)
+    per_test = {}
+    for name in REFERENCE_UNIT_TESTS:
+        n0 = len(records)
+        env[name]()  # the reference's own asserts run against the reference's own functions
+        per_test[name] = len(records) - n0
+
+    # ---- tests/test_export.py:37-455: the converters of the four text exporters (their files import cv2 / lxml: lifted by ast)
+    import csv as csv_mod
+    import re as re_mod
+    from html import escape
+
+    env_csv = {"csv": csv_mod, "os": os, "save_image": None}
+    env_csv.update(zip(["table_to_csv", "paragraph_to_csv"], _ref_functions("export/export_csv.py", ["table_to_csv", "paragraph_to_csv"], env_csv)))
+    md_names = ["escape_markdown_special_chars", "paragraph_to_md", "table_to_md"]
+    env_md = {"re": re_mod, "os": os}
+    env_md.update(zip(md_names, _ref_functions("export/export_markdown.py", md_names, env_md)))
+    env_md.update(zip(md_names, _ref_functions("export/export_markdown.py", md_names, env_md)))
+    html_names = ["convert_text_to_html", "add_td_tag", "add_table_tag", "add_tr_tag", "add_p_tag", "add_h1_tag", "table_to_html", "paragraph_to_html"]
+    env_html = {"re": re_mod, "os": os, "escape": escape}
+    env_html.update(zip(html_names, _ref_functions("export/export_html.py", html_names, env_html)))
+    env_html.update(zip(html_names, _ref_functions("export/export_html.py", html_names, env_html)))
+    json_fns = dict(zip(["paragraph_to_json", "table_to_json"], _ref_functions("export/export_json.py", ["paragraph_to_json", "table_to_json"], {})))
+    export_fns = {"table_to_csv": env_csv["table_to_csv"], "paragraph_to_csv": env_csv["paragraph_to_csv"],
+                  **{k: env_md[k] for k in md_names}, "convert_text_to_html": env_html["convert_text_to_html"],
+                  "table_to_html": env_html["table_to_html"], "paragraph_to_html": env_html["paragraph_to_html"], **json_fns}
+    export_tests = ["test_convert_text_to_html", "test_table_to_html", "test_paragraph_to_html", "test_escape_markdown_special_chars",
+                    "test_paragraph_to_md", "test_table_to_md", "test_table_to_csv", "test_paragraph_to_csv", "test_paragraph_to_json",
+                    "test_table_to_json"]
+    env2 = {name: recorder(name, fn, "export") for name, fn in export_fns.items()}
+    for cls in ("DocumentAnalyzerSchema", "LayoutAnalyzerSchema", "LayoutParserSchema", "OCRSchema", "ParagraphSchema", "FigureSchema",
+                "TableCellSchema", "TableLineSchema", "TableStructureRecognizerSchema", "TextDetectorSchema", "TextRecognizerSchema",
+                "WordPrediction", "Element"):
+        env2[cls] = getattr(sch, cls)
+    env2.update(np=np, os=os, json=json)
+    path2 = os.path.join(os.path.dirname(REF_SRC), "tests", "test_export.py")
+    tree2 = ast.parse(open(path2, encoding="utf-8").read())
+    body2 = [n for n in tree2.body if isinstance(n, ast.FunctionDef) and n.name in export_tests]
+    assert {n.name for n in body2} == set(export_tests)
+    exec(compile(ast.Module(body=body2, type_ignores=[]), path2, "exec"), env2)
+    for name in export_tests:
+        n0 = len(records)
+        env2[name]()
+        per_test[name] = len(records) - n0
+    with open(os.path.join(GOLDEN, "reference_unit_cases.json"), "w") as f:
+        json.dump({"source": "tests/test_document_analyzer.py and tests/test_export.py of the reference, run against the reference's own functions",
+                   "calls_per_test": per_test, "calls": records}, f, ensure_ascii=False)
+    print(f"[reference unit tests] {len(per_test)} tests, {len(records)} recorded calls: {per_test}")
+
+
 def _ref_methods(relpath, cls, names, env):
     """Like _ref_functions for methods of a reference class: returned as plain functions taking `self` first."""
     import ast
@@ -905,7 +1018,7 @@ def main(argv):
     os.makedirs(GOLDEN, exist_ok=True)
     todo = {"dbnet": pin_dbnet, "parseq": pin_parseq, "rtdetr": pin_rtdetr, "host": pin_host_logic, "aggregate": pin_aggregate,
             "filters": pin_filters, "geometry": pin_geometry, "cells": pin_cells, "export": pin_export,
-            "configs": pin_configs, "searchable_pdf": pin_searchable_pdf}
+            "configs": pin_configs, "searchable_pdf": pin_searchable_pdf, "unit": pin_reference_unit_tests}
     for k, fn in todo.items():
         if what in (k, "all"):
             fn()

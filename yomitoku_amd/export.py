@@ -53,16 +53,27 @@ def _save_figures(figures, img, out_path, figure_dir):
 
 
 # ---------------------------------------------------------------------------------------------- JSON (export_json.py)
+def paragraph_to_json(paragraph, ignore_line_break):
+    """In place (export_json.py:7): the line breaks of a paragraph's text go when asked."""
+    if ignore_line_break:
+        paragraph.contents = paragraph.contents.replace("\n", "")
+
+
+def table_to_json(table, ignore_line_break):
+    """In place (export_json.py:12): the same for every cell of a table."""
+    if ignore_line_break:
+        for cell in table.cells:
+            cell.contents = cell.contents.replace("\n", "")
+
+
 def convert_json(inputs, out_path, ignore_line_break, img, export_figure, figure_dir):
     from .schemas import DocumentAnalyzerSchema
 
     if isinstance(inputs, DocumentAnalyzerSchema):
-        if ignore_line_break:
-            for table in inputs.tables:
-                for cell in table.cells:
-                    cell.contents = cell.contents.replace("\n", "")
-            for paragraph in inputs.paragraphs:
-                paragraph.contents = paragraph.contents.replace("\n", "")
+        for table in inputs.tables:
+            table_to_json(table, ignore_line_break)
+        for paragraph in inputs.paragraphs:
+            paragraph_to_json(paragraph, ignore_line_break)
         if export_figure:
             for _, figure, name in _save_figures(inputs.figures, img, out_path, figure_dir):
                 figure.figure_path = os.path.join(figure_dir, name)
