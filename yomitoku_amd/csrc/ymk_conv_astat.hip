@@ -259,15 +259,28 @@ void conv1x1_f16_astat(hipStream_t s, const float* x, int M, int C, const ConvW&
   const size_t rows = (size_t)((w.cout + 255) / 256 * 256), real = (size_t)((w.cout + 127) / 128 * 128);
   const size_t w_bytes = rows * w.kpad * 2 * 2;
   YMK_CHECK(w_bytes < (size_t)OOB_OFFSET, "astat: weight planes below 4 GiB");
-  void* planes = nullptr;
-  float* wscale = nullptr;
-  unsigned* rec = nullptr;
-  YMK_HIP(hipMalloc(&planes, w_bytes));
-  YMK_HIP(hipMalloc(reinterpret_cast<void**>(&wscale), real * sizeof(float)));
-  YMK_HIP(hipMalloc(reinterpret_cast<void**>(&rec), AMAX_REC_WORDS * sizeof(unsigned)));
-  hipEvent_t e0, e1;
-  YMK_HIP(hipEventCreate(&e0));
-  YMK_HIP(hipEventCreate(&e1));
+  struct Scratch {  // freed on every way out (a failing HIP call throws)
+    void* planes = nullptr;
+    float* wscale = nullptr;
+    unsigned* rec = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Scratch() {
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+      (void)hipFree(planes);
+      (void)hipFree(wscale);
+      (void)hipFree(rec);
+    }
+  } sc;
+  YMK_HIP(hipMalloc(&sc.planes, w_bytes));
+  YMK_HIP(hipMalloc(reinterpret_cast<void**>(&sc.wscale), real * sizeof(float)));
+  YMK_HIP(hipMalloc(reinterpret_cast<void**>(&sc.rec), AMAX_REC_WORDS * sizeof(unsigned)));
+  YMK_HIP(hipEventCreate(&sc.e0));
+  YMK_HIP(hipEventCreate(&sc.e1));
+  void* const planes = sc.planes;
+  float* const wscale = sc.wscale;
+  unsigned* const rec = sc.rec;
+  const hipEvent_t e0 = sc.e0, e1 = sc.e1;
   YMK_HIP(hipMemsetAsync(planes, 0, w_bytes, s));
   YMK_HIP(hipMemsetAsync(rec, 0, AMAX_REC_WORDS * sizeof(unsigned), s));
   hipLaunchKernelGGL(k_split_panel_f16, dim3((unsigned)real), dim3(256), 0, s, w.w, reinterpret_cast<unsigned short*>(planes), w.kpad, w.scale,
@@ -334,11 +347,6 @@ void conv1x1_f16_astat(hipStream_t s, const float* x, int M, int C, const ConvW&
   float ms = 0.f;
   YMK_HIP(hipEventElapsedTime(&ms, e0, e1));
   if (kernel_ms) *kernel_ms = ms;
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  (void)hipFree(planes);
-  (void)hipFree(wscale);
-  (void)hipFree(rec);
 }
 
 }  // namespace ymk
