@@ -1,5 +1,8 @@
+import json
 import os
 import sys
+import threading
+import time
 
 import pytest
 
@@ -10,6 +13,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: the largest GPU cases (full BASELINE sizes); part of -m gpu, deselect with -m 'gpu and not slow'")
+    config._ymk_highwater = None
 
 
 @pytest.fixture(scope="session")
@@ -19,3 +24,133 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     return torch.device("cuda:0")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# High-water record of a GPU run of the suite (VERDICT round 4, weak point 8): device memory in use (hipMemGetInfo, i.e.
+# everything on the GPU - torch's caching allocator AND the library's own hipMalloc'ed arenas), the process's resident set
+# and the host's available memory, sampled every 50 ms by a side thread and folded per test module, plus each module's
+# wall time.  Written to $YMK_HIGHWATER (default gpurun_out/suite_highwater.json) at session end; only when a HIP device
+# is present, so the CPU suite pays nothing.
+# ---------------------------------------------------------------------------------------------------------------------
+def _rss_bytes():
+    try:
+        with open("/proc/self/statm") as f:
+            return int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE")
+    except OSError:
+        return 0
+
+
+def _host_available_bytes():
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return 0
+
+
+class _HighWater:
+    def __init__(self):
+        import torch
+
+        self.torch = torch
+        self.current = None
+        self.modules = {}
+        self.stop = threading.Event()
+        self.lock = threading.Lock()
+        free, total = torch.cuda.mem_get_info(0)
+        self.total = int(total)
+        self.base_used = int(total - free)
+        self.host_total = 0
+        try:
+            with open("/proc/meminfo") as f:
+                self.host_total = int(f.readline().split()[1]) * 1024
+        except OSError:
+            pass
+        self.thread = threading.Thread(target=self._loop, name="ymk-highwater", daemon=True)
+        self.thread.start()
+
+    def _sample(self):
+        try:
+            free, total = self.torch.cuda.mem_get_info(0)
+        except Exception:  # noqa: BLE001 - a faulted device must not take the sampler thread down with a traceback
+            return
+        used, rss, avail = int(total - free), _rss_bytes(), _host_available_bytes()
+        with self.lock:
+            m = self.modules.get(self.current)
+            if m is not None:
+                m["vram_peak"] = max(m["vram_peak"], used)
+                m["rss_peak"] = max(m["rss_peak"], rss)
+                m["host_available_min"] = min(m["host_available_min"], avail) if m["host_available_min"] else avail
+
+    def _loop(self):
+        while not self.stop.wait(0.05):
+            self._sample()
+
+    def enter(self, module):
+        with self.lock:
+            self.current = module
+            self.modules.setdefault(module, {"vram_peak": 0, "rss_peak": 0, "host_available_min": 0, "seconds": 0.0, "tests": 0,
+                                             "torch_peak_allocated": 0})
+
+    def leave(self, module, seconds):
+        self._sample()
+        with self.lock:
+            m = self.modules[module]
+            m["seconds"] += seconds
+            m["tests"] += 1
+            m["torch_peak_allocated"] = max(m["torch_peak_allocated"], int(self.torch.cuda.max_memory_allocated(0)))
+            m["vram_after"] = int(self.total - self.torch.cuda.mem_get_info(0)[0])
+
+    def report(self):
+        self.stop.set()
+        self.thread.join(timeout=2)
+        gb = 1 << 30
+        mods = {k: {"vram_peak_gb": round(v["vram_peak"] / gb, 2), "vram_after_gb": round(v.get("vram_after", 0) / gb, 2),
+                    "torch_peak_allocated_gb": round(v["torch_peak_allocated"] / gb, 2), "rss_peak_gb": round(v["rss_peak"] / gb, 2),
+                    "host_available_min_gb": round(v["host_available_min"] / gb, 1), "seconds": round(v["seconds"], 1), "tests": v["tests"]}
+                for k, v in self.modules.items()}
+        return {"device_total_gb": round(self.total / gb, 1), "device_used_before_gb": round(self.base_used / gb, 2),
+                "host_total_gb": round(self.host_total / gb, 1),
+                "vram_peak_gb": max((m["vram_peak_gb"] for m in mods.values()), default=0.0),
+                "rss_peak_gb": max((m["rss_peak_gb"] for m in mods.values()), default=0.0),
+                "seconds": round(sum(m["seconds"] for m in mods.values()), 1), "modules": mods}
+
+
+def pytest_sessionstart(session):
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            session.config._ymk_highwater = _HighWater()
+    except Exception:  # noqa: BLE001 - measuring must never fail the suite
+        session.config._ymk_highwater = None
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_protocol(item, nextitem):
+    hw = getattr(item.config, "_ymk_highwater", None)
+    if hw is None:
+        yield
+        return
+    module = item.nodeid.split("::")[0]
+    hw.enter(module)
+    t0 = time.perf_counter()
+    yield
+    hw.leave(module, time.perf_counter() - t0)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    hw = getattr(session.config, "_ymk_highwater", None)
+    if hw is None or not hw.modules:
+        return
+    path = os.environ.get("YMK_HIGHWATER", os.path.join(ROOT, "gpurun_out", "suite_highwater.json"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(dict(hw.report(), exitstatus=int(exitstatus)), f, indent=1)
+    except OSError:
+        pass

@@ -164,3 +164,96 @@ def test_thread_budget_follows_the_core_slice():
     assert thread_budget(128) == {"stage_threads": 9, "box_threads": 4, "rec_lanes": 2}
     assert thread_budget(16) == {"stage_threads": 9, "box_threads": 4, "rec_lanes": 2}   # 8 ranks on a 128-core host
     assert thread_budget(6) == {"stage_threads": 9, "box_threads": 1, "rec_lanes": 1}
+
+
+class _PickyError(Exception):
+    """An exception whose constructor wants two arguments: pickles, then fails to UNpickle (args holds one string)."""
+
+    def __init__(self, code, what):
+        super().__init__(f"{what} ({code})")
+        self.code = code
+
+
+class _FailingAnalyzer(_StubAnalyzer):
+    def __init__(self, device, checkpoints, budget):
+        super().__init__(device, checkpoints, budget)
+        mode = os.environ["YMK_TEST_FAIL"]
+        if mode == "build" and int(os.environ["RANK"]) == 1:
+            raise _PickyError(7, "no such device")
+        self.mode = mode
+
+    def serve(self, sources, **kw):
+        if self.mode == "serve" and int(os.environ["RANK"]) == 1:
+            raise _PickyError(9, "serve blew up")
+        out = super().serve(sources, **kw)
+        if self.mode == "entry":
+            out = [(si, fi, _PickyError(3, "page") if not isinstance(e, tuple) else e) for si, fi, e in out]
+        return out
+
+
+def _failing_worker(rank, world, port, q, mode):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), YMK_TEST_FAIL=mode)
+    from yomitoku_amd import distributed as yd
+
+    def ck():
+        if mode == "checkpoints":
+            raise FileNotFoundError("model.safetensors")
+        return {"net": {"w": torch.arange(6, dtype=torch.float32)}}
+
+    sources = [10, 11, -1, 13]
+    try:
+        res = yd.serve_sharded(sources, _FailingAnalyzer, ck if rank == 0 else None, backend="gloo", wave=2)
+        outcome = ("ok", [e if isinstance(e, tuple) else f"{type(e).__name__}: {e}" for e in res] if res is not None else None)
+    except yd.ShardedJobError as exc:
+        outcome = ("job-error", sorted(exc.failures), str(exc))
+    q.put((rank, outcome, torch.distributed.is_initialized()))
+
+
+def _run_failing(mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]  # a rank left waiting in a collective would time this out
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return {r: (o, init) for r, o, init in got}
+
+
+def test_a_failing_rank_reaches_every_collective_and_all_ranks_raise():
+    """whatever fails on one rank - rank 0's checkpoint source, a rank's analyzer constructor, `serve` itself -
+    no rank is left blocked in a collective; every rank raises ShardedJobError naming the culprit and leaves the group."""
+    res = _run_failing("checkpoints")
+    for rank in (0, 1):
+        (kind, ranks, text), still_init = res[rank]
+        assert kind == "job-error" and ranks == [0] and "FileNotFoundError" in text and not still_init
+    res = _run_failing("build")
+    for rank in (0, 1):
+        (kind, ranks, text), still_init = res[rank]
+        assert kind == "job-error" and ranks == [1] and "_PickyError: no such device (7)" in text and not still_init
+    res = _run_failing("serve")
+    for rank in (0, 1):
+        (kind, ranks, text), still_init = res[rank]
+        assert kind == "job-error" and ranks == [1] and "serve blew up (9)" in text and not still_init
+
+
+def test_an_exception_entry_that_cannot_be_unpickled_still_arrives():
+    res = _run_failing("entry")
+    (kind, entries), still_init = res[0]
+    assert kind == "ok" and not still_init
+    assert len(entries) == 4 and entries[2] == "RuntimeError: _PickyError: page (3)"
+    assert [e[0] for i, e in enumerate(entries) if i != 2] == [10, 11, 13]
+    assert res[1][0] == ("ok", None)
+
+
+def test_portable_entry_keeps_what_pickles():
+    from yomitoku_amd.distributed import portable_entry
+
+    e = ValueError("bad page")
+    assert portable_entry(e) is e and portable_entry({"a": 1}) == {"a": 1}
+    p = portable_entry(_PickyError(3, "page"))
+    assert type(p) is RuntimeError and str(p) == "_PickyError: page (3)"

@@ -74,6 +74,52 @@ def test_mini_batch_compositions(gold):
     assert seen_budget >= 10 and seen_fixed >= 10
 
 
+def test_forward_chunks_respect_the_line_and_token_row_bounds():
+    """TextRecognizer._forward_chunks: consecutive mini-batches share a forward up to MAX_LINES_PER_FORWARD
+    lines AND up to the token-row budget of the model's width; forwards come out about equal in size; an oversize mini-batch
+    runs alone; the reservation bounds cover every forward the rule can form."""
+    import random
+
+    from yomitoku_amd.text_recognizer import TextRecognizer
+
+    def fake(dim, patch, dynamic, width=800):
+        cfg = SimpleNamespace(data=SimpleNamespace(img_size=[32, width]), encoder=SimpleNamespace(patch_size=list(patch), embed_dim=dim))
+        f = SimpleNamespace(_cfg=cfg, dynamic_width=dynamic, MAX_LINES_PER_FORWARD=TextRecognizer.MAX_LINES_PER_FORWARD,
+                            FORWARD_WORKSPACE_BYTES=TextRecognizer.FORWARD_WORKSPACE_BYTES)
+        for name in ("_token_geometry", "_job_token_rows", "_forward_chunks", "_reserve_bounds"):
+            setattr(f, name, getattr(TextRecognizer, name).__get__(f))
+        return f
+
+    rng = random.Random(5)
+    for dim, patch, dynamic in ((192, (4, 8), True), (768, (8, 8), False), (512, (8, 8), True)):
+        rec = fake(dim, patch, dynamic)
+        full, budget = rec._token_geometry()
+        assert full == (32 // patch[0]) * (800 // patch[1]) and budget == (16 << 30) // (52 * dim)
+        lines, h, w = rec._reserve_bounds()
+        assert lines == 2048 and h == 32 and w % patch[1] == 0 and w <= 800
+        assert lines * (32 // patch[0]) * (w // patch[1]) <= budget or w == patch[1]
+        for trial in range(30):
+            jobs = []
+            for _ in range(rng.randint(1, 90)):
+                n = rng.randint(1, 128)
+                jobs.append((None, [SimpleNamespace(canvas_width=rng.choice((64, 160, 320, 800))) for _ in range(n)]))
+            chunks = rec._forward_chunks(jobs)
+            assert chunks[0][0] == 0 and chunks[-1][1] == len(jobs) and all(a[1] == b[0] for a, b in zip(chunks, chunks[1:]))
+            for lo, hi in chunks:
+                nl = sum(len(p) for _, p in jobs[lo:hi])
+                nr = sum(rec._job_token_rows(p) for _, p in jobs[lo:hi])
+                assert hi > lo and (hi - lo == 1 or (nl <= 2048 and nr <= budget))
+    # the default recogniser's fixed 800 px canvas: 16 pages x 100 lines no longer land in ONE forward of 1600 lines
+    rec = fake(768, (8, 8), False)
+    jobs = [(None, [SimpleNamespace(canvas_width=800)] * 100) for _ in range(16)]
+    sizes = [sum(len(p) for _, p in jobs[lo:hi]) for lo, hi in rec._forward_chunks(jobs)]
+    assert sizes == [800, 800]
+    # the --lite recogniser keeps its 2048-line forwards (the line bound is the tighter one)
+    rec = fake(192, (4, 8), True)
+    jobs = [(None, [SimpleNamespace(canvas_width=800)] * 128) for _ in range(20)]
+    assert [sum(len(p) for _, p in jobs[lo:hi]) for lo, hi in rec._forward_chunks(jobs)] == [1280, 1280]
+
+
 def test_tokenizer_decode(gold):
     from yomitoku_amd.text_recognizer import ParseqTokenizer
 

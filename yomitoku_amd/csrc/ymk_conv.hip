@@ -460,6 +460,8 @@ static std::atomic<int> g_conv_fast{27};     // ConvK::fast
 static std::atomic<int> g_conv_variant{0};   // conv_igemm schedule selector for A/B runs, see launch_wide()
 static std::atomic<int> g_prof_dump{0};      // 1: ymk_prof_end prints one line per launch to stderr
 static std::atomic<int> g_conv_split{-1};     // -1: unset (a model runs its own default); 0: exact fp32 MFMA everywhere; 2 / 3 / 16: split operands (ymk_conv_split.hip)
+static std::atomic<int> g_gemm_row_limit{0};  // > 0: gemm() cuts its rows into chunks of at most this many (tests of the 4 GiB chunking)
+static int gemm_row_limit() { return g_gemm_row_limit.load(std::memory_order_relaxed); }
 static int splitk_forced() { return g_splitk_force.load(std::memory_order_relaxed); }
 static bool no_splitk() { return g_no_splitk.load(std::memory_order_relaxed) != 0; }
 static thread_local int t_conv_split = -1;  // >= 0: set by a ConvSplitScope on this thread (a model's own parameter)
@@ -490,6 +492,7 @@ bool conv_debug_option(const std::string& key, int value) {
   else if (key == "conv_fast") g_conv_fast = value;
   else if (key == "prof_dump") g_prof_dump = value;
   else if (key == "conv_split") g_conv_split = value;
+  else if (key == "gemm_row_limit") g_gemm_row_limit = value;
   else return false;
   return true;
 }
@@ -796,18 +799,29 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
 void gemm(hipStream_t s, const float* A, int M, int K, int lda, const ConvW& w, int act, const float* res, int res_ld,
           float* out, int out_ld, const int* row_group, const int* group_open, int epi, const unsigned* amax_in, unsigned* amax_out) {
   YMK_CHECK(K == w.cin, "gemm: K " + std::to_string(K) + " != weight in-features " + std::to_string(w.cin));
-  Tensor in{const_cast<float*>(A), 1, 1, M, K, lda};
-  Tensor o{out, 1, 1, M, w.cout, out_ld};
-  Tensor r{const_cast<float*>(res), 1, 1, M, w.cout, res_ld};
-  ConvArgs a;
-  a.act = act;
-  a.res = res ? &r : nullptr;
-  a.row_group = row_group;
-  a.group_open = group_open;
-  a.epi = epi;
-  a.amax_in = amax_in;
-  a.amax_out = amax_out;
-  conv2d(s, in, w, a, o);
+  // The kernels address their A operand through a buffer descriptor with 32-bit byte offsets (conv2d: "input view must stay
+  // below 4 GiB"); a row-major GEMM has no such natural bound - the fc2 input of a 2048-line PARSeq forward is 1.6 M rows x
+  // 3 KB - so rows are processed in chunks whose view fits.  Rows are independent and a chunk is a multiple of 1024 rows
+  // (every tile height divides it), so the chunked result is the unchunked one bit for bit; the max|y| record is a maximum.
+  const size_t in_row = (size_t)std::max(lda, 1) * sizeof(float);
+  size_t max_rows = ((size_t)OOB_OFFSET - 4096) / in_row;
+  if (gemm_row_limit() > 0) max_rows = std::min(max_rows, (size_t)gemm_row_limit());
+  max_rows = std::max<size_t>(max_rows / 1024 * 1024, 1024);
+  for (size_t m0 = 0; m0 < (size_t)std::max(M, 0); m0 += max_rows) {
+    const int rows = (int)std::min(max_rows, (size_t)M - m0);
+    Tensor in{const_cast<float*>(A) + m0 * lda, 1, 1, rows, K, lda};
+    Tensor o{out + m0 * out_ld, 1, 1, rows, w.cout, out_ld};
+    Tensor r{res ? const_cast<float*>(res) + m0 * res_ld : nullptr, 1, 1, rows, w.cout, res_ld};
+    ConvArgs a;
+    a.act = act;
+    a.res = res ? &r : nullptr;
+    a.row_group = row_group ? row_group + m0 : nullptr;
+    a.group_open = group_open;
+    a.epi = epi;
+    a.amax_in = amax_in;
+    a.amax_out = amax_out;
+    conv2d(s, in, w, a, o);
+  }
 }
 
 // ------------------------------------------------------------------ host packing

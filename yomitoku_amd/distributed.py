@@ -187,6 +187,39 @@ def thread_budget(cores: int) -> dict:
     return {"stage_threads": 9, "box_threads": max(1, min(4, cores // 4)), "rec_lanes": 2 if cores >= 8 else 1}
 
 
+class ShardedJobError(RuntimeError):
+    """A sharded job that failed as a whole (not a page: pages fail in place): raised on EVERY rank after the collective the
+    failure was carried through, so no rank is left waiting in one.  `failures`: {rank: "ExceptionType: message"}."""
+
+    def __init__(self, what: str, failures: Mapping[int, str]):
+        self.failures = dict(failures)
+        super().__init__(f"{what}: " + "; ".join(f"rank {r}: {m}" for r, m in sorted(self.failures.items())))
+
+    def __reduce__(self):
+        return (RuntimeError, (str(self),))
+
+
+def _describe(exc: BaseException) -> str:
+    return f"{type(exc).__name__}: {exc}"
+
+
+def portable_entry(entry):
+    """A per-page entry as it can cross a process boundary: schemas pickle; an exception object is kept when it survives a
+    pickle round trip and becomes RuntimeError("Type: message") otherwise (an exception class with a custom __init__ -
+    a C-ABI error carrying a code, say - may pickle and then fail to UNpickle on rank 0, inside gather_object)."""
+    if not isinstance(entry, BaseException):
+        return entry
+    import pickle
+
+    try:
+        back = pickle.loads(pickle.dumps(entry))
+        if type(back) is type(entry):
+            return entry
+    except Exception:  # noqa: BLE001 - anything the round trip throws means "not portable"
+        pass
+    return RuntimeError(_describe(entry))
+
+
 class ShardedServer:
     """The page loop of cli/main.py:116-120 over the GPUs of one node - what north_star calls "pages shard naturally (one page
     per GPU) ... with RCCL broadcast of weights": ONE process per GPU (torchrun, or any launcher that sets RANK / LOCAL_RANK /
@@ -199,10 +232,17 @@ class ShardedServer:
     make_analyzer(device, checkpoints, budget) builds this rank's DocumentAnalyzer from the broadcast checkpoints ({name:
     state dict}; `checkpoints` is that mapping - or a callable returning it - on rank 0 and ignored elsewhere).  Sources are
     dealt round-robin BY SOURCE (a multi-frame file stays on one rank); an entry that failed stays an exception object in
-    its place, exactly as `serve` reports it, and cannot hold the other ranks (nothing on the per-page path communicates)."""
+    its place, exactly as `serve` reports it, and cannot hold the other ranks (nothing on the per-page path communicates).
+
+    Failures of the JOB (rank 0 cannot produce the checkpoints, a rank cannot build its analyzer, `serve` itself raises on a
+    rank) are carried THROUGH the next collective instead of skipping it: every rank reaches the same broadcast / all-gather /
+    gather, then every rank raises `ShardedJobError` naming the ranks that failed - nobody is left blocked in a collective
+    its peer never enters, and `close()` after such a failure tears the group down without a barrier."""
 
     def __init__(self, make_analyzer, checkpoints=None, backend: str | None = None, device=None, pin_cores: bool = True):
         self.rank, self.local_rank, self.world = init(backend)
+        self.failed = False
+        self.analyzer = None
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", self.world))
         self.cores = claim_core_slice(self.local_rank, local_world) if pin_cores else (os.cpu_count() or 1)
         self.budget = thread_budget(self.cores)
@@ -211,20 +251,41 @@ class ShardedServer:
         self.device = torch.device(device)
         if self.device.type == "cuda":
             torch.cuda.set_device(self.device)
-        sds = None
+        sds, head = None, [None]
         if self.rank == 0:
-            sds = checkpoints() if callable(checkpoints) else checkpoints
-        names = [None]
-        if self.rank == 0:
-            names[0] = list(sds) if sds is not None else None
+            try:
+                sds = checkpoints() if callable(checkpoints) else checkpoints
+                head[0] = ("names", list(sds) if sds is not None else None)
+            except Exception as exc:  # noqa: BLE001 - carried to the other ranks through the broadcast they are waiting in
+                head[0] = ("error", _describe(exc))
         if self.world > 1:
-            dist.broadcast_object_list(names, src=0)
+            dist.broadcast_object_list(head, src=0)
+        if head[0][0] == "error":
+            self.failed = True
+            raise ShardedJobError("rank 0 could not produce the checkpoints", {0: head[0][1]})
+        names = head[0][1]
         self.checkpoints = None
-        if names[0] is not None:
+        if names is not None:
             self.checkpoints = OrderedDict((k, broadcast_state_dict(sds[k] if self.rank == 0 else None, src=0, device=self.device))
-                                           for k in names[0])
+                                           for k in names)
         self.replicas = replica_report(self.checkpoints, self.device) if self.checkpoints else None
-        self.analyzer = make_analyzer(self.device, self.checkpoints, self.budget)
+        error = None
+        try:
+            self.analyzer = make_analyzer(self.device, self.checkpoints, self.budget)
+        except Exception as exc:  # noqa: BLE001 - reported to every rank below
+            error = _describe(exc)
+        self._agree("building the analyzer", error)
+
+    def _agree(self, what: str, error: str | None):
+        """One tiny all-gather of every rank's (ok | error text): raises ShardedJobError on ALL ranks when any rank failed."""
+        reports = [error]
+        if self.world > 1:
+            reports = [None] * self.world
+            dist.all_gather_object(reports, error)
+        failures = {r: m for r, m in enumerate(reports) if m is not None}
+        if failures:
+            self.failed = True
+            raise ShardedJobError(f"{what} failed", failures)
 
     def shard(self, n_sources: int) -> List[int]:
         return shard_indices(n_sources, self.rank, self.world)
@@ -234,23 +295,32 @@ class ShardedServer:
         mine = self.shard(len(sources))
         serve_kwargs.setdefault("rec_lanes", self.budget["rec_lanes"])
         local = self.analyzer.serve([sources[i] for i in mine], with_source=True, **serve_kwargs)
-        return [(mine[si], fi, entry) for si, fi, entry in local]
+        return [(mine[si], fi, portable_entry(entry)) for si, fi, entry in local]
 
-    def gather(self, local: Sequence) -> list | None:
+    def gather(self, local) -> list | None:
         """Every rank's (source, frame, entry) triples on rank 0, ordered by (source, frame): the entries alone are returned
         there, None elsewhere.  A host-side gather of Python objects (schemas and exception objects pickle), not a data-path
-        collective."""
-        parts = [list(local)]
+        collective.  `local` may also be {"error": text} - a rank whose share failed as a whole: the gather still runs on
+        every rank and then all of them raise ShardedJobError."""
+        parts = [local if isinstance(local, dict) else list(local)]
         if self.world > 1:
+            # all ranks learn about a failed rank (all_gather of one short string), rank 0 alone receives the results
+            self._agree("serving this rank's share", local.get("error") if isinstance(local, dict) else None)
             parts = [None] * self.world if self.rank == 0 else None
             dist.gather_object(list(local), parts, dst=0)
             if self.rank != 0:
                 return None
+        elif isinstance(local, dict):
+            self._agree("serving this rank's share", local.get("error"))
         merged = sorted((t for part in parts for t in part), key=lambda t: (t[0], t[1]))
         return [entry for _, _, entry in merged]
 
     def run(self, sources: Sequence, **serve_kwargs) -> list | None:
-        return self.gather(self.serve_local(sources, **serve_kwargs))
+        try:
+            local = self.serve_local(sources, **serve_kwargs)
+        except Exception as exc:  # noqa: BLE001 - the job failed on this rank: say so IN the collective the others will enter
+            local = {"error": _describe(exc)}
+        return self.gather(local)
 
     def barrier(self):
         if self.world > 1:
@@ -261,15 +331,24 @@ class ShardedServer:
         if close is not None:
             close()
         if destroy_group and self.world > 1 and dist.is_initialized():
-            dist.barrier()
+            if not self.failed:  # after a job failure the peers may already be gone: no rendezvous, just leave
+                dist.barrier()
             dist.destroy_process_group()
 
 
 def serve_sharded(sources: Sequence, make_analyzer, checkpoints=None, backend: str | None = None, **serve_kwargs):
     """One call per rank: the whole sharded job (ShardedServer: init -> broadcast -> shard -> serve -> ordered gather).
     Returns every page's entry in source order on rank 0, None on the other ranks."""
-    server = ShardedServer(make_analyzer, checkpoints, backend=backend)
+    server = None
     try:
+        server = ShardedServer(make_analyzer, checkpoints, backend=backend)
         return server.run(sources, **serve_kwargs)
+    except ShardedJobError:
+        if server is not None:
+            server.failed = True
+        raise
     finally:
-        server.close()
+        if server is not None:
+            server.close()
+        elif dist.is_initialized():  # the constructor raised on every rank (ShardedJobError): nobody waits in a barrier
+            dist.destroy_process_group()

@@ -193,6 +193,32 @@ class TextRecognizer(BaseModule):
 
     # ------------------------------------------------------------------ inference + decode
     MAX_LINES_PER_FORWARD = 2048  # bounds the logits workspace of one grouped forward (101 x num_tokens floats per line)
+    # ... and its activation workspace: a forward keeps ~13 fp32 copies of its [token rows] x [embed dim] stream (the q|k|v and
+    # MLP hidden buffers included), so the token rows of a forward are bounded such that 13 x 4 x D x rows stays below this many
+    # bytes - 1.7 M rows for the 192-wide --lite recogniser (2048 lines of 800 px: the line bound is the tighter one), 430 k for
+    # parseq-large-v4_1 (1075 lines of its fixed 800 px canvas).  The same two bounds size the one-off workspace reservation.
+    FORWARD_WORKSPACE_BYTES = 16 << 30
+
+    def _token_geometry(self):
+        """(token rows per line at the full canvas width, token-row budget of one forward)."""
+        ph, pw = (int(v) for v in self._cfg.encoder.patch_size)
+        h, w = (int(v) for v in self._cfg.data.img_size)
+        dim = int(self._cfg.encoder.embed_dim)
+        return (h // ph) * (w // pw), max(1, self.FORWARD_WORKSPACE_BYTES // (13 * 4 * dim))
+
+    def _job_token_rows(self, plans):
+        ph, pw = (int(v) for v in self._cfg.encoder.patch_size)
+        h, w = (int(v) for v in self._cfg.data.img_size)
+        width = max(p.canvas_width for p in plans) if self.dynamic_width else w
+        return len(plans) * (h // ph) * (width // pw)
+
+    def _reserve_bounds(self):
+        """(lines, height, width) for ymk_model_reserve: MAX_LINES_PER_FORWARD lines as wide as the token-row budget allows."""
+        ph, pw = (int(v) for v in self._cfg.encoder.patch_size)
+        h, w = (int(v) for v in self._cfg.data.img_size)
+        _, budget = self._token_geometry()
+        cols = max(1, min(w // pw, budget // (self.MAX_LINES_PER_FORWARD * (h // ph))))
+        return self.MAX_LINES_PER_FORWARD, h, cols * pw
 
     def _run_inference(self, data: torch.Tensor, model=None):
         model = model or self.model
@@ -214,15 +240,23 @@ class TextRecognizer(BaseModule):
         return pred, score, directions
 
     def _forward_chunks(self, jobs):
-        """jobs -> [(first job, one past the last)]: consecutive mini-batches that share a forward (<= MAX_LINES_PER_FORWARD)."""
-        total = sum(len(plans) for _, plans in jobs)
-        n_fwd = max(1, -(-total // self.MAX_LINES_PER_FORWARD))
-        target = min(self.MAX_LINES_PER_FORWARD, -(-total // n_fwd))  # forwards of about equal size: 1100 lines run as 550 + 550, not 1024 + 76
+        """jobs -> [(first job, one past the last)]: consecutive mini-batches that share a forward - at most
+        MAX_LINES_PER_FORWARD lines and at most the token-row budget of `_token_geometry` (a single mini-batch over either
+        bound still runs, alone; the library cuts any GEMM whose operand view would pass 4 GiB into row chunks itself)."""
+        _, budget = self._token_geometry()
+        lines = [len(plans) for _, plans in jobs]
+        rows = [self._job_token_rows(plans) for _, plans in jobs]
+        n_fwd = max(1, -(-sum(lines) // self.MAX_LINES_PER_FORWARD), -(-sum(rows) // budget))
+        # forwards of about equal size: 1100 lines run as 550 + 550, not 1024 + 76
+        line_target = min(self.MAX_LINES_PER_FORWARD, -(-sum(lines) // n_fwd))
+        row_target = min(budget, -(-sum(rows) // n_fwd))
         chunks, start = [], 0
         while start < len(jobs):
-            stop, lines = start, 0
-            while stop < len(jobs) and (stop == start or (lines < target and lines + len(jobs[stop][1]) <= self.MAX_LINES_PER_FORWARD)):
-                lines += len(jobs[stop][1])
+            stop, nl, nr = start, 0, 0
+            while stop < len(jobs) and (stop == start or (nl < line_target and nr < row_target
+                                                          and nl + lines[stop] <= self.MAX_LINES_PER_FORWARD and nr + rows[stop] <= budget)):
+                nl += lines[stop]
+                nr += rows[stop]
                 stop += 1
             chunks.append((start, stop))
             start = stop
@@ -320,9 +354,10 @@ class TextRecognizer(BaseModule):
     def plan_pages(self, imgs, points_list):
         """The mini-batches of every page are formed per page exactly as in `__call__` (bucketing, width budget, padding)
         and their crop tensors built; a page's result never depends on its neighbours (mini-batches never mix pages)."""
-        # multi-page serving: size the PARSeq workspace once per live handle for the largest grouped forward, so that no wave -
-        # however its lines fall into mini-batches - reaches hipMalloc / hipFree (tiny: ~12 GB, large-v4_1: ~23 GB of 288 GB)
-        self.model.reserve_once(self.MAX_LINES_PER_FORWARD, int(self._cfg.data.img_size[0]), int(self._cfg.data.img_size[1]), self.device)
+        # multi-page serving: size the PARSeq workspace once per live handle for the largest grouped forward `_forward_chunks`
+        # forms (line bound and token-row bound), so that no wave - however its lines fall into mini-batches - reaches
+        # hipMalloc / hipFree (~18 GB for the --lite recogniser, ~20 GB for parseq-large-v4_1, of 288 GB)
+        self.model.reserve_once(*self._reserve_bounds(), self.device)
         preps = [self.preprocess(img, pts) for img, pts in zip(imgs, points_list)]
         jobs, spans = [], []
         for batches, _, dataset, _ in preps:
@@ -352,7 +387,7 @@ class TextRecognizer(BaseModule):
                 rep = type(self.model)(self.model.cfg).load_state_dict(self.model._sd).to(self.device)
                 rep._source_sd = self.model._sd
                 rep.tokenizer = self.tokenizer
-                rep.reserve_once(self.MAX_LINES_PER_FORWARD, int(self._cfg.data.img_size[0]), int(self._cfg.data.img_size[1]), self.device)
+                rep.reserve_once(*self._reserve_bounds(), self.device)
                 self._replicas[lane] = rep
             if rep._conv_split != self.model._conv_split:
                 rep.set_conv_split(self.model._conv_split)
