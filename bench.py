@@ -91,6 +91,78 @@ def kernel_source_sha():
 DRY = os.environ.get("YMK_BENCH_DRY") == "1"
 
 
+class HighWater:
+    """Device memory in use (hipMemGetInfo: torch's allocator AND the library's own arenas), this process's resident set and
+    the host's available memory, sampled every 50 ms by a side thread and folded per bench leg (VERDICT round 4, weak point 8:
+    "no VRAM / RSS high-water measurement of bench.py's legs").  `mark(leg)` names what runs from now on."""
+
+    def __init__(self):
+        import threading
+
+        self.legs, self.order, self.leg = {}, [], None
+        self.lock, self.stop = threading.Lock(), threading.Event()
+        free, total = torch.cuda.mem_get_info()
+        self.total, self.before = int(total), int(total - free)
+        self.thread = threading.Thread(target=self._loop, name="ymk-bench-highwater", daemon=True)
+        self.thread.start()
+
+    @staticmethod
+    def _host():
+        rss = avail = 0
+        try:
+            with open("/proc/self/statm") as f:
+                rss = int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE")
+            with open("/proc/meminfo") as f:
+                for ln in f:
+                    if ln.startswith("MemAvailable:"):
+                        avail = int(ln.split()[1]) * 1024
+                        break
+        except OSError:
+            pass
+        return rss, avail
+
+    def _sample(self):
+        try:
+            free, total = torch.cuda.mem_get_info()
+        except Exception:  # noqa: BLE001
+            return
+        rss, avail = self._host()
+        with self.lock:
+            m = self.legs.get(self.leg)
+            if m is not None:
+                m["vram"] = max(m["vram"], int(total - free))
+                m["rss"] = max(m["rss"], rss)
+                m["avail"] = min(m["avail"], avail) if m["avail"] else avail
+
+    def _loop(self):
+        while not self.stop.wait(0.05):
+            self._sample()
+
+    def mark(self, leg):
+        self._sample()
+        with self.lock:
+            self.leg = leg
+            if leg not in self.legs:
+                self.legs[leg] = {"vram": 0, "rss": 0, "avail": 0, "t0": time.perf_counter()}
+                self.order.append(leg)
+        self._sample()
+
+    def report(self):
+        self.mark("end")
+        self.stop.set()
+        self.thread.join(timeout=2)
+        gb = float(1 << 30)
+        legs = {}
+        for a, b in zip(self.order, self.order[1:]):
+            m = self.legs[a]
+            legs[a] = {"vram_peak_gb": round(m["vram"] / gb, 2), "rss_peak_gb": round(m["rss"] / gb, 2),
+                       "host_available_min_gb": round(m["avail"] / gb, 1), "seconds": round(self.legs[b]["t0"] - m["t0"], 1)}
+        return {"device_total_gb": round(self.total / gb, 1), "device_used_before_gb": round(self.before / gb, 2),
+                "vram_peak_gb": max((v["vram_peak_gb"] for v in legs.values()), default=0.0),
+                "rss_peak_gb": max((v["rss_peak_gb"] for v in legs.values()), default=0.0), "legs": legs,
+                "note": "hipMemGetInfo (everything on the device) and /proc/self/statm, sampled every 50 ms; per leg of this process"}
+
+
 def rank_device(local_rank):
     if DRY:
         return torch.device("cpu")
@@ -502,7 +574,7 @@ def secondary_metrics(args, device, sds, pages):
                                             "failed_pages": sum(isinstance(r, BaseException) for r in res),
                                             "workload": "the analyzer workload with the reference's constructor defaults: dbnetv2_1 + "
                                                         "parseq-large-v4_1 (fixed 800 px canvas, batch 128) + RT-DETRv2 layout + table"}
-    an.close()
+    close_analyzer(an)
     return out
 
 
@@ -522,13 +594,21 @@ def analyzer_nets(an):
     return (an.text_detector.model, an.text_recognizer.model, an.layout.layout_parser.model, an.layout.table_structure_recognizer.model)
 
 
+def close_analyzer(an):
+    """The pipeline threads, the recogniser's replica handles AND the four nets' device memory (weights + reserved workspaces,
+    tens of GB per analyzer) - now, not when the garbage collector gets to the object (`serve` defers full collections)."""
+    an.close()
+    for n in analyzer_nets(an):
+        n.close()
+
+
 def exact_fp32_metrics(args, an, host_pages):
     """The SAME analyzer and pages with every net on the exact fp32 MFMA kernels ("conv_split" 0) - the round-3 headline
-    configuration, kept as the yardstick next to the fp16-split default.  Two warm-up waves, two timed passes as one job."""
+    configuration, kept as the yardstick next to the fp16-split default.  Two warm-up waves, FIVE timed passes over the pages as one job."""
     for n in analyzer_nets(an):
         n.set_conv_split(0)
     try:
-        res, dt = timed_serve(args, an, host_pages)
+        res, dt = timed_serve(args, an, host_pages, steps=5)
     finally:
         for n in analyzer_nets(an):
             n.set_conv_split(None)
@@ -554,7 +634,7 @@ def unmodified_serve_metrics(args, device, sds, host_pages):
             net.load_state_dict(sds[key])
         res, dt = timed_serve(args, an, host_pages)
     finally:
-        an.close()
+        close_analyzer(an)
     ok = [r for r in res if not isinstance(r, BaseException)]
     return {"value": round(len(res) / dt, 2), "unit": "pages/s", "steps": len(res) // len(host_pages), "pages": len(res), "failed_pages": len(res) - len(ok),
             "units_per_page": {"words": round(float(np.mean([len(r.words) for r in ok])), 1) if ok else None,
@@ -563,6 +643,65 @@ def unmodified_serve_metrics(args, device, sds, host_pages):
                                "cells": round(float(np.mean([sum(len(t.cells) for t in r.tables) for r in ok])), 1) if ok else None},
             "workload": "the unmodified product path: DocumentAnalyzer.serve(host pages) with the calibrated seeded checkpoints, every stage "
                         "fed by the previous stage's own output"}
+
+
+def stage_control_metrics(args, device, sds, pages):
+    """Control for the shaped headline workload (VERDICT round 4, weak point 5): the UNMODIFIED stage bodies of the product -
+    `_stage_boxes`, `_stage_crops`, `_stage_tables`, `_stage_cells`, `_stage_finish` exactly as `DocumentAnalyzer` ships them -
+    at the headline's unit counts.  Seeded weights cannot detect the pages' content, so what is substituted here is the two
+    NETWORK OUTPUTS a trained checkpoint would produce, after the networks have run at full cost: the detector's probability
+    map (the map rendered from the true lines, the headline's own) and the layout net's raw (logits, boxes) tensors (one
+    query per true paragraph / table, score 0.98).  Everything downstream is the product's own code on its own hand-overs:
+    DB box extraction -> its boxes to the crop planner and the recogniser, RTDETRPostProcessor + containment filters -> its
+    table boxes to the table-structure net, whose (noise, calibrated) rows / columns go through the product's filters and
+    cell grids, then aggregation.  Two warm-up waves, two timed passes over the pages as one job."""
+    from yomitoku_amd import DocumentAnalyzer
+
+    class NetOutputDrivenAnalyzer(DocumentAnalyzer):
+        truth = None
+
+        def _truth(self, wave):
+            return [self.truth[i % len(self.truth)] for i in wave.ids]
+
+        def _stage_detect(self, wave):
+            super()._stage_detect(wave)  # pre-processing, DBNet forwards, maps back to the host: full cost
+            truth = self._truth(wave)
+            assert all(m.shape == t.truth_map.shape for m, t in zip(wave.maps, truth))
+            wave.maps = [t.truth_map for t in truth]
+
+        def _stage_layout(self, wave):
+            super()._stage_layout(wave)  # the layout forward over the wave: full cost
+            lp = self.layout.layout_parser
+            cat = {c: i for i, c in lp.label_mapper.items()}
+            raw = []
+            for (logits, boxes, (h, w)), t in zip(wave.lay_raw, self._truth(wave)):
+                lg = np.full_like(logits, -12.0)
+                bx = np.zeros_like(boxes)
+                units = [(b, cat["paragraphs"]) for b in t.paragraphs] + [(b, cat["tables"]) for b in t.tables]
+                for q, ((x0, y0, x1, y1), c) in enumerate(units[: lg.shape[1]]):
+                    lg[0, q, c] = 4.0
+                    bx[0, q] = ((x0 + x1) / 2 / w, (y0 + y1) / 2 / h, (x1 - x0) / w, (y1 - y0) / h)
+                raw.append((lg, bx, (h, w)))
+            wave.lay_raw = raw
+
+    an = NetOutputDrivenAnalyzer(configs=MODEL_SETS[args.model_set], device=str(device))
+    try:
+        for net, key in zip(analyzer_nets(an), ("det", "rec", "lay", "tab")):
+            net.load_state_dict(sds[key])
+        an.truth = pages
+        res, dt = timed_serve(args, an, [p.img for p in pages])
+    finally:
+        close_analyzer(an)
+    ok = [r for r in res if not isinstance(r, BaseException)]
+    return {"value": round(len(res) / dt, 2), "unit": "pages/s", "steps": len(res) // len(pages), "pages": len(res), "failed_pages": len(res) - len(ok),
+            "units_per_page": {"words": round(float(np.mean([len(r.words) for r in ok])), 1) if ok else None,
+                               "paragraphs": round(float(np.mean([len(r.paragraphs) for r in ok])), 1) if ok else None,
+                               "tables": round(float(np.mean([len(r.tables) for r in ok])), 2) if ok else None,
+                               "cells": round(float(np.mean([sum(len(t.cells) for t in r.tables) for r in ok])), 1) if ok else None},
+            "workload": "control for the headline: the product's own stage bodies (box extraction -> crops, layout post-processing -> table "
+                        "crops, table filters and cell grids, aggregation) on their own hand-overs, with the detector map and the layout "
+                        "net's raw output replaced - after the forwards - by what a trained net would emit for the page's true lines, "
+                        "paragraphs and tables"}
 
 
 def self_spawn(argv, n):
@@ -621,6 +760,13 @@ def main():
     assert DRY or torch.cuda.is_available(), "bench.py needs a HIP device"
     device = rank_device(local_rank)
     lib = None if DRY else _lib.load()
+    hw = HighWater() if (rank == 0 and not DRY) else None
+
+    def leg(name):
+        if hw is not None:
+            hw.mark(name)
+
+    leg("setup: checkpoints, broadcast, analyzer, pages")
     if lib is not None and os.environ.get("YMK_DEC_ROWS"):  # A/B knob of the fused greedy step (rows per block)
         _lib.debug_option("dec_rows", int(os.environ["YMK_DEC_ROWS"]))
 
@@ -711,9 +857,11 @@ def main():
     out = None
     per_rank = None
     if not args.roofline_only:
+        leg("warm-up steps")
         if args.warmup:
             run_steps(args.warmup)
         failed = 0
+        leg("timed region")
         device_sync()
         if world > 1:
             torch.distributed.barrier()
@@ -740,6 +888,7 @@ def main():
     # one wave at a time, the two chains of a wave one after the other on one stream - so that a launch's event pair
     # brackets that kernel alone.  `python bench.py --roofline-only` under rocprofv3 is the same pass (profiles/).
     roof = None
+    leg("roofline: serial pass with per-launch events")
     if rank == 0 and not DRY and not args.no_roofline:
         kern = ("conv_igemm_split (fp16-split MFMA implicit GEMM: the chip-filling conv / linear launches of the four nets) + conv_igemm / "
                 "conv_splitk (exact fp32 MFMA: the stems and the grid-starved launches), max|x| passes included" if split_mode() else
@@ -803,16 +952,20 @@ def main():
     if rank == 0 and world == 1 and args.workload == "analyzer" and not (DRY or args.roofline_only or args.no_secondary):
         # a failing secondary leg must not cost the run its headline line: the error is reported in its place
         secondary = {}
-        for name, leg in (("pages_per_s_exact_fp32", lambda: {"pages_per_s_exact_fp32": exact_fp32_metrics(args, an, host_pages)}),
+        for name, fn in (("pages_per_s_exact_fp32", lambda: {"pages_per_s_exact_fp32": exact_fp32_metrics(args, an, host_pages)}),
+                          ("pages_per_s_stage_control", lambda: {"pages_per_s_stage_control": stage_control_metrics(args, device, sds, pages)}),
                           ("pages_per_s_unmodified_serve", lambda: {"pages_per_s_unmodified_serve": unmodified_serve_metrics(args, device, sds, host_pages)}),
                           ("recogniser_and_default_model_set", lambda: secondary_metrics(args, device, sds, pages))):
+            leg("secondary: " + name)
             try:
-                secondary.update(leg())
+                secondary.update(fn())
             except Exception as exc:  # noqa: BLE001
                 secondary[name] = {"error": f"{type(exc).__name__}: {exc}"}
+            torch.cuda.empty_cache()  # a finished leg's page / crop tensors go back to the device before the next one reserves
 
     # ---- CPU baseline leg (rank 0, N=1): oracle chain on the host cores, bounded sample
     cpu = None
+    leg("cpu_baseline: oracle chain on the host cores")
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not DRY and not args.roofline_only:
         if args.workload == "analyzer":
             charset = an.text_recognizer.charset
@@ -854,6 +1007,7 @@ def main():
             "rccl": rccl,
             "per_rank": per_rank,
             "secondary": secondary,
+            "highwater": hw.report() if hw is not None else None,
         }
         if args.total_pages:
             line["config"]["total_pages_per_step"] = args.total_pages

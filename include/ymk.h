@@ -169,6 +169,8 @@ int ymk_prof_begin(void);
  *   "conv_split_tile" (0) tile shape of that path for A/B runs: 0 = by format, 1 = 128 x 64, 2 = 256 x 128 (16 waves),
  *                        3 = 128 x 128 (16 waves), 4 = 128 x 128 (8 waves), 11 = 256 x 256 (16 waves; two planes);
  *                        5-10 / 12-14 (bf16 only): 64-k stages, loads two stages ahead, stores threaded through the MFMAs
+ *   "gemm_row_limit" (0) > 0: linear layers cut their rows into chunks of at most this many (rounded down to 1024s) - the chunking
+ *                        that keeps an A operand view below the 4 GiB a buffer descriptor addresses, forced at test sizes
  *   "amax_check" (0)     1: every fp16-split launch whose input came with a max|x| record from its producer ALSO measures the
  *                        input and compares (ymk_amax_check_counters) - the self-check of the record plumbing */
 int ymk_debug_option(const char* key, int value);

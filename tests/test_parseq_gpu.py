@@ -308,3 +308,27 @@ def test_row_max_head_gives_the_same_tokens_as_arg_max_over_stored_logits(dev):
     # form's in their last bits - tokens may not; the refined logits then agree to rounding
     assert torch.equal(a[0].argmax(-1), b[0].argmax(-1)) and (a[0] - b[0]).abs().max().item() < 1e-4
     assert torch.equal(a[3].argmax(-1), b[3].argmax(-1)) and (a[3] - b[3]).abs().max().item() < 1e-4
+
+
+def test_gemm_row_chunks_leave_the_forward_unchanged(dev):
+    """a GEMM whose A view would pass 4 GiB (the fc2 input of a 2048-line forward) is cut into row chunks
+    inside the library.  Forced here at 1024 rows per chunk on a forward of 3840 token rows and 2424 decoder rows: rows are
+    independent, so tokens and step counts are those of the unchunked forward; logits differ only by what a smaller launch's
+    tile / split-K choice reorders in its K sums."""
+    from yomitoku_amd import _lib
+    from yomitoku_amd.utils.synth import parseq_state_dict, synthetic_line_batch
+
+    sd = parseq_state_dict(1235, eos_bias=5.5)
+    _, net = _net(dev, sd)
+    x = synthetic_line_batch(11, 24, 160).to(dev)
+    whole = net(x).cpu()
+    steps = net.last_ar_steps
+    _lib.debug_option("gemm_row_limit", 1024)
+    try:
+        parts = net(x).cpu()
+        assert net.last_ar_steps == steps
+    finally:
+        _lib.debug_option("gemm_row_limit", 0)
+    assert torch.equal(parts.argmax(-1), whole.argmax(-1))
+    assert (parts - whole).abs().max().item() < 1e-4
+    assert torch.equal(net(x).cpu(), whole)  # and the option is off again
