@@ -93,8 +93,10 @@ DRY = os.environ.get("YMK_BENCH_DRY") == "1"
 
 class HighWater:
     """Device memory in use (hipMemGetInfo: torch's allocator AND the library's own arenas), this process's resident set and
-    the host's available memory, sampled every 50 ms by a side thread and folded per bench leg (VERDICT round 4, weak point 8:
-    "no VRAM / RSS high-water measurement of bench.py's legs").  `mark(leg)` names what runs from now on."""
+    the host's available memory, sampled at every leg boundary and twice a second in between by a side thread, folded per bench
+    leg (VERDICT round 4, weak point 8: "no VRAM / RSS high-water measurement of bench.py's legs").  `mark(leg)` names what
+    runs from now on.  The interval is coarse on purpose: hipMemGetInfo goes through the driver, and the peaks it is after are
+    the models' reserved workspaces, which stand for the whole leg.  YMK_HIGHWATER_INTERVAL=0 turns the side thread off."""
 
     def __init__(self):
         import threading
@@ -103,8 +105,10 @@ class HighWater:
         self.lock, self.stop = threading.Lock(), threading.Event()
         free, total = torch.cuda.mem_get_info()
         self.total, self.before = int(total), int(total - free)
+        self.interval = float(os.environ.get("YMK_HIGHWATER_INTERVAL", 0.5))
         self.thread = threading.Thread(target=self._loop, name="ymk-bench-highwater", daemon=True)
-        self.thread.start()
+        if self.interval > 0:
+            self.thread.start()
 
     @staticmethod
     def _host():
@@ -135,7 +139,7 @@ class HighWater:
                 m["avail"] = min(m["avail"], avail) if m["avail"] else avail
 
     def _loop(self):
-        while not self.stop.wait(0.05):
+        while not self.stop.wait(self.interval):
             self._sample()
 
     def mark(self, leg):
@@ -150,7 +154,8 @@ class HighWater:
     def report(self):
         self.mark("end")
         self.stop.set()
-        self.thread.join(timeout=2)
+        if self.interval > 0:
+            self.thread.join(timeout=2)
         gb = float(1 << 30)
         legs = {}
         for a, b in zip(self.order, self.order[1:]):
@@ -160,7 +165,8 @@ class HighWater:
         return {"device_total_gb": round(self.total / gb, 1), "device_used_before_gb": round(self.before / gb, 2),
                 "vram_peak_gb": max((v["vram_peak_gb"] for v in legs.values()), default=0.0),
                 "rss_peak_gb": max((v["rss_peak_gb"] for v in legs.values()), default=0.0), "legs": legs,
-                "note": "hipMemGetInfo (everything on the device) and /proc/self/statm, sampled every 50 ms; per leg of this process"}
+                "note": "hipMemGetInfo (everything on the device) and /proc/self/statm at every leg boundary and every "
+                        f"{self.interval:g} s in between; per leg of this process"}
 
 
 def rank_device(local_rank):

@@ -171,9 +171,22 @@ int ymk_prof_begin(void);
  *                        5-10 / 12-14 (bf16 only): 64-k stages, loads two stages ahead, stores threaded through the MFMAs
  *   "gemm_row_limit" (0) > 0: linear layers cut their rows into chunks of at most this many (rounded down to 1024s) - the chunking
  *                        that keeps an A operand view below the 4 GiB a buffer descriptor addresses, forced at test sizes
+ *   "astat" (1)          1: chip-filling pointwise layers with K <= 256 and Cout > 64 run on the A-stationary kernel; 0: the round-4
+ *                        routing (A/B runs).  "conv_split_tile" 30 forces that kernel for every launch it can run (tests)
+ *   "parseq_no_ln_fusion" (0)  1: the ViT blocks' LayerNorms as launches of their own (A/B runs, tests); 0: folded into the
+ *                        operand load of the q|k|v and fc1 GEMMs wherever the A-stationary kernel takes them
+ *   "act_planes" (1)     1: the tensor between a bottleneck's 1 x 1 reduction and its 3 x 3 convolution lives in HBM as the two fp16
+ *                        planes the 3 x 3 multiplies with (written by the reduction's epilogue under the bound
+ *                        max|x_in| x max row L1 norm + max|bias|, read by LDS-DMA without conversion) wherever both launches
+ *                        fill the chip; 0: fp32 activations everywhere (A/B runs)
  *   "amax_check" (0)     1: every fp16-split launch whose input came with a max|x| record from its producer ALSO measures the
- *                        input and compares (ymk_amax_check_counters) - the self-check of the record plumbing */
+ *                        input and compares (ymk_amax_check_counters) - the self-check of the record plumbing; 2: also names every
+ *                        launch whose record lies BELOW the measured maximum on stderr (serialises the stream) */
 int ymk_debug_option(const char* key, int value);
+/* Launch counters since the process started, for tests that must know a route was really taken: "astat_launches" (the
+ * A-stationary short-K kernel), "ln_fused_launches" (those of them that carried a LayerNorm in their operand load),
+ * "planes_written_launches" / "planes_read_launches" (convolutions whose output / input lives in HBM as fp16 planes). */
+int ymk_stat(const char* key, int64_t* value);
 /* out4 = {launches checked, records below the true max|x| (a bug), records more than 2^8 above it, largest record / truth
  * exponent distance} since the process started; synchronises the device. */
 int ymk_amax_check_counters(int64_t* out4);
@@ -195,13 +208,17 @@ int ymk_op_conv2d(const float* x_dev, int n, int h, int w, int c, /* c % 4 == 0,
 /* rows x d LayerNorm (eps as given); attention over contiguous [b][l][heads*hd] q/k/v with optional
  * boolean masks (non-zero = blocked): mask_qk [lq][lk], kpm [b][lk]; use_small selects the masked
  * small-query kernel even without masks (otherwise the fp32-MFMA flash kernel runs). */
-/* CANDIDATE kernel, not dispatched by the models (yomitoku_amd/csrc/ymk_conv_astat.hip): a 1 x 1
- * layer with K = c <= 256 through the A-stationary fp16-split kernel - y[m][cout] = act(scale * (x[m][c] . w^T) + bias + res),
- * w_host_oc: [cout][c] on the host, x / res / y on the device.  Same arithmetic as the fp16-split kernels ymk_op_conv2d runs
- * under ymk_debug_option("conv_split", 16): the results are compared bit for bit (tests/test_conv_astat_gpu.py).  The launch
- * is repeated `reps` times; *kernel_ms = HIP-event time of the last one (the planes and the max|x| pass are outside it). */
+/* A 1 x 1 layer with K = c <= 256 through the A-stationary fp16-split kernel (yomitoku_amd/csrc/ymk_conv_astat.hip; the models'
+ * short-K pointwise layers run on it since round 5) at ANY row count, where the library's own routing
+ * only takes chip-filling launches: y[m][cout] = act(scale * (x'[m][c] . w^T) + bias + res), x' = x - or, with ln_g_host /
+ * ln_b_host ([c], host), LayerNorm(x; gamma, beta, ln_eps) folded into the operand load (c = 128 or 192; the input's
+ * max|x| record is then the LayerNorm's static output bound, as in the models).  w_host_oc: [cout][c] on the host, x / res / y
+ * on the device.  Same arithmetic as the register-staged fp16-split kernel (ymk_op_conv2d under "conv_split" 16 and
+ * "conv_split_tile" 3): compared bit for bit in tests/test_conv_astat_gpu.py.  The launch is repeated `reps` times;
+ * *kernel_ms = HIP-event time of the last one.  Refuses (error) what the kernel cannot run. */
 int ymk_op_conv1x1_astat(const float* x_dev, int m, int c, const float* w_host_oc, int cout, const float* scale_host,
-                         const float* bias_host, const float* res_dev, int act, float* y_dev, int reps, float* kernel_ms, void* stream);
+                         const float* bias_host, const float* res_dev, int act, const float* ln_g_host, const float* ln_b_host,
+                         float ln_eps, float* y_dev, int reps, float* kernel_ms, void* stream);
 
 int ymk_op_layernorm(const float* x_dev, int rows, int d, const float* g_dev, const float* b_dev, float eps,
                      float* y_dev, void* stream);

@@ -54,9 +54,9 @@ def conv2d(x, weight, scale=None, bias=None, residual=None, stride=1, padding=0,
     return _nchw(y)
 
 
-def conv1x1_astat(x, weight, scale=None, bias=None, residual=None, act="none", reps=1):
-    """The candidate A-stationary kernel (ymk_op_conv1x1_astat): x [M, C] on the device, weight [Cout, C] -> (y [M, Cout], ms of
-    the last of `reps` launches)."""
+def conv1x1_astat(x, weight, scale=None, bias=None, residual=None, act="none", reps=1, ln=None):
+    """The A-stationary kernel at any row count (ymk_op_conv1x1_astat): x [M, C] on the device, weight [Cout, C] -> (y [M, Cout],
+    ms of the last of `reps` launches).  ln = (gamma [C], beta [C], eps): LayerNorm folded into the operand load."""
     import ctypes
 
     lib = _lib.load()
@@ -68,10 +68,13 @@ def conv1x1_astat(x, weight, scale=None, bias=None, residual=None, act="none", r
     sh = scale.detach().float().cpu().contiguous() if scale is not None else None
     bh = bias.detach().float().cpu().contiguous() if bias is not None else None
     rh = residual.float().contiguous() if residual is not None else None
+    gh = ln[0].detach().float().cpu().contiguous() if ln is not None else None
+    beh = ln[1].detach().float().cpu().contiguous() if ln is not None else None
     y = torch.empty((m, cout), dtype=torch.float32, device=x.device)
     ms = ctypes.c_float()
     with torch.cuda.device(x.device):
         _lib.check(lib.ymk_op_conv1x1_astat(xh.data_ptr(), m, c, wh.data_ptr(), cout, _lib.ptr(sh), _lib.ptr(bh), _lib.ptr(rh), ACT[act],
+                                            _lib.ptr(gh), _lib.ptr(beh), float(ln[2]) if ln is not None else 0.0,
                                             y.data_ptr(), reps, ctypes.byref(ms), _lib.current_stream_ptr()), "ymk_op_conv1x1_astat")
     return y, float(ms.value)
 

@@ -49,6 +49,7 @@ def test_dbnet_batch8_full_size(dev):
     assert torch.equal(net(x)["binary"], out)  # the same launch shapes: bit-identical on repeat
 
 
+@pytest.mark.slow(order=4)
 def test_text_recognizer_open_beta_batch128_branch(dev):
     from oracle import pipeline as op
     from oracle.parseq import PRESETS, make_cfg
@@ -91,6 +92,7 @@ def test_parseq_large_v4_1_geometry(dev, width, batch):
     assert (out - ref).abs().max().item() < 1e-3
 
 
+@pytest.mark.slow(order=2)
 def test_text_recognizer_2048_lines_every_mini_batch(dev):
     """configs[2] at its full size: ONE TextRecognizer("parseq") call on 2048 lines = 16 mini-batches of 128 through two
     grouped forwards.  The oracle chain (oracle.pipeline.recognize: crops, bucketing, batching, decode, un-permutation) runs
@@ -129,6 +131,7 @@ def test_text_recognizer_2048_lines_every_mini_batch(dev):
     print("2048 lines: distinct strings", len(set(contents)), "widest mini-batch", max(c[3] for c in calls), "px")
 
 
+@pytest.mark.slow(order=3)
 def test_wave_sized_grouped_forward(dev):
     """The shape the analyzer bench runs: ~650 lines in 30 mini-batches of one grouped forward, rows-per-block of the fused
     greedy step left on AUTO (more than 288 rows: two rows per block).  Six groups against the oracle, every group against
@@ -168,7 +171,8 @@ def test_wave_sized_grouped_forward(dev):
     print("wave-sized forward:", rows, "lines,", len(xs), "groups, steps", min(steps), "..", max(steps))
 
 
-@pytest.mark.parametrize("page_hw", [(1000, 1400), (1600, 1200)])
+@pytest.mark.slow(order=1)
+@pytest.mark.parametrize("page_hw", [(1600, 1200), (1000, 1400)])
 def test_whole_page_schema_vs_oracle_chain(dev, page_hw):
     from oracle import pipeline as op
     from oracle.dbnet import dbnet_forward

@@ -9,6 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.slow(order=5)
 def test_cell_detector_matches_oracle_chain(dev):
     from oracle.rtdetr import rtdetr_forward
     from tests.test_rtdetr_gpu import assert_same_detections

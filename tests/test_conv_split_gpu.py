@@ -103,7 +103,7 @@ def test_producer_records_bound_the_true_maximum_on_whole_pages(dev):
     pages = [synthetic_page_with_truth(100 + i, *((1600, 1200) if i % 2 else (1200, 1600)))[0] for i in range(8)]
     before = _lib.amax_check_counters()
     try:
-        _lib.debug_option("amax_check", 1)
+        _lib.debug_option("amax_check", int(__import__("os").environ.get("YMK_AMAX_CHECK_LEVEL", 1)))
         res = an.serve(pages, wave=8, in_flight=1)
     finally:
         _lib.debug_option("amax_check", 0)

@@ -1,0 +1,124 @@
+"""The round-5 routes of the fp16-split path, each against its round-4 form on the same inputs (same planes, same products,
+same accumulation order wherever the arithmetic is meant to be identical; fp32-grade agreement where a scale differs):
+
+  * "astat": chip-filling pointwise layers with K <= 256 on the A-stationary kernel (ymk_conv_astat.hip) - the same bits as
+    the register-staged kernel (tests/test_conv_astat_gpu.py checks the operator; here: whole nets, routing on / off);
+  * "parseq_no_ln_fusion": the ViT blocks' LayerNorms folded into the operand load of q|k|v and fc1
+    (models/layers/parseq_transformer.py:188-204) against LayerNorm as its own launch;
+  * "act_planes": the tensor between a bottleneck's 1 x 1 reduction and its 3 x 3 convolution stored as fp16 planes under a
+    bound (models/dbnet_plus.py:33-38, rtdetr_backbone.py) against fp32 activations.
+
+ymk_stat counters prove that the route under test was really taken."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class _Option:
+    def __init__(self, key, value, restore):
+        self.key, self.value, self.restore = key, value, restore
+
+    def __enter__(self):
+        from yomitoku_amd import _lib
+
+        _lib.debug_option(self.key, self.value)
+
+    def __exit__(self, *exc):
+        from yomitoku_amd import _lib
+
+        _lib.debug_option(self.key, self.restore)
+        return False
+
+
+def test_dbnet_with_and_without_fp16_planes_between_reduction_and_3x3(dev):
+    from oracle.dbnet import dbnet_forward
+    from yomitoku_amd import _lib
+    from yomitoku_amd.nets import DBNet
+    from yomitoku_amd.utils.synth import dbnet_state_dict
+
+    sd = dbnet_state_dict(1234)
+    net = DBNet().load_state_dict(sd).to(dev)
+    x = torch.randn(2, 3, 960, 1280, generator=torch.Generator().manual_seed(41))  # layer1 and layer2 fill the chip: 7 pairs
+    w0, r0 = _lib.stat("planes_written_launches"), _lib.stat("planes_read_launches")
+    with_planes = net(x.to(dev))["binary"].cpu()
+    written, read = _lib.stat("planes_written_launches") - w0, _lib.stat("planes_read_launches") - r0
+    assert written == read and written >= 7, (written, read)  # layer1 (3) + layer2 (4) at this size; all 16 at the bench's
+    assert torch.equal(net(x.to(dev))["binary"].cpu(), with_planes)  # bit-identical on repeat
+    with _Option("act_planes", 0, 1):
+        w1 = _lib.stat("planes_written_launches")
+        without = net(x.to(dev))["binary"].cpu()
+        assert _lib.stat("planes_written_launches") == w1
+    ref = dbnet_forward(sd, x)["binary"]
+    e_with, e_without = (with_planes - ref).abs().max().item(), (without - ref).abs().max().item()
+    print("planes", written, "max|dP| vs oracle with / without planes", e_with, e_without, "between them", (with_planes - without).abs().max().item())
+    assert e_with < 1e-3 and e_without < 1e-3
+    assert e_with < max(4.0 * e_without, 2e-5)  # the bound-derived scale costs no accuracy worth the name
+    assert (with_planes - without).abs().max().item() < 5e-5
+
+
+def test_rtdetr_with_and_without_fp16_planes(dev):
+    from tests.test_rtdetr_gpu import _net, assert_same_detections
+    from yomitoku_amd import _lib
+    from yomitoku_amd.utils.synth_rtdetr import rtdetr_state_dict
+
+    sd = rtdetr_state_dict(1242, num_classes=6)
+    net = _net(dev, sd, 6)
+    x = torch.rand(4, 3, 640, 640, generator=torch.Generator().manual_seed(9))
+    w0 = _lib.stat("planes_written_launches")
+    a = net(x.to(dev))
+    assert _lib.stat("planes_written_launches") - w0 >= 3
+    with _Option("act_planes", 0, 1):
+        b = net(x.to(dev))
+    assert_same_detections(a["pred_logits"].cpu().numpy(), a["pred_boxes"].cpu().numpy(), b["pred_logits"].cpu().numpy(),
+                           b["pred_boxes"].cpu().numpy())
+
+
+def test_parseq_layernorm_fusion_and_astat_routing_on_and_off(dev):
+    from tests.test_parseq_gpu import _net
+    from yomitoku_amd import _lib
+    from yomitoku_amd.utils.synth import parseq_state_dict, synthetic_line_batch
+
+    sd = parseq_state_dict(1235, eos_bias=5.5)
+    _, net = _net(dev, sd)
+    x = synthetic_line_batch(29, 128, 256).to(dev)  # 32 768 token rows: every encoder GEMM fills the chip
+    a0, f0 = _lib.stat("astat_launches"), _lib.stat("ln_fused_launches")
+    fused = net(x).cpu()
+    steps = net.last_ar_steps
+    n_astat, n_fused = _lib.stat("astat_launches") - a0, _lib.stat("ln_fused_launches") - f0
+    assert n_fused == 24 and n_astat >= 36, (n_astat, n_fused)  # 12 blocks x (qkv, fc1) fused; proj on the same kernel
+    with _Option("parseq_no_ln_fusion", 1, 0):
+        f1 = _lib.stat("ln_fused_launches")
+        unfused = net(x).cpu()
+        assert _lib.stat("ln_fused_launches") == f1 and net.last_ar_steps == steps
+    with _Option("astat", 0, 1), _Option("parseq_no_ln_fusion", 1, 0):
+        a1 = _lib.stat("astat_launches")
+        staged = net(x).cpu()
+        assert _lib.stat("astat_launches") == a1 and net.last_ar_steps == steps
+    # routing alone changes no bit (same planes, same products, same order per accumulator); the fusion changes the
+    # normalised rows by the rounding of one fp32 expression at most (same formula, same order: usually nothing)
+    assert torch.equal(unfused, staged), (unfused - staged).abs().max().item()
+    assert torch.equal(fused.argmax(-1), unfused.argmax(-1))
+    assert (fused - unfused).abs().max().item() < 1e-4
+
+
+def test_whole_pages_with_every_route_on_and_off(dev):
+    """Four pages through DocumentAnalyzer.serve with the three routes on (the default) and off: every discrete leaf equal,
+    scores to 1e-4 - the same bar `serve == __call__` is held to."""
+    from tests.test_pipeline_gpu import _assert_same_schema
+    from tests.test_serving_gpu import _analyzer
+    from yomitoku_amd import _lib
+    from yomitoku_amd.utils.synth import synthetic_page_with_truth
+
+    an = _analyzer()
+    pages = [synthetic_page_with_truth(70 + i, 1200, 1600)[0] for i in range(4)]
+    c0 = {k: _lib.stat(k) for k in ("astat_launches", "ln_fused_launches", "planes_read_launches")}
+    on = [r.model_dump() for r in an.serve(pages, wave=4, in_flight=1)]
+    assert all(_lib.stat(k) > v for k, v in c0.items()), c0
+    with _Option("astat", 0, 1), _Option("parseq_no_ln_fusion", 1, 0), _Option("act_planes", 0, 1):
+        off = [r.model_dump() for r in an.serve(pages, wave=4, in_flight=1)]
+    an.close()
+    assert sum(len(p["words"]) for p in on) > 0
+    for a, b in zip(on, off):
+        _assert_same_schema(a, b)

@@ -57,6 +57,7 @@ SIGNATURES = {
     ),
     "ymk_table_hole_rects": (c_int, [c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, POINTER(c_int)]),
     "ymk_debug_option": (c_int, [c_char_p, c_int]),
+    "ymk_stat": (c_int, [c_char_p, POINTER(c_int64)]),
     "ymk_amax_check_counters": (c_int, [POINTER(c_int64)]),
     "ymk_prof_begin": (c_int, []),
     "ymk_prof_end": (c_int, [POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
@@ -69,7 +70,8 @@ SIGNATURES = {
     ),
     "ymk_op_conv1x1_astat": (
         c_int,
-        [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, POINTER(c_float), c_void_p],
+        [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int,
+         POINTER(c_float), c_void_p],
     ),
     "ymk_op_layernorm": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "ymk_op_attention": (
@@ -126,6 +128,13 @@ def check(status: int, what: str = "ymk call"):
 
 
 CONV_FAST_DEFAULT = 27  # ymk_debug_option("conv_fast"): the library's default bits (include/ymk.h)
+
+
+def stat(key: str) -> int:
+    """A launch counter of the library (include/ymk.h: ymk_stat)."""
+    v = c_int64()
+    check(load().ymk_stat(key.encode(), ctypes.byref(v)), f"ymk_stat({key})")
+    return int(v.value)
 
 
 def debug_option(key: str, value: int):

@@ -18,12 +18,12 @@ void prof_begin();
 void prof_end(double* ms, double* flop, int64_t* launches);
 double prof_bytes();
 int64_t prof_launch_table(double* ms, double* flop, double* bytes, double* products, int64_t capacity);
-void conv1x1_f16_astat(hipStream_t s, const float* x, int M, int C, const ConvW& w, const float* res, int act, float* y, int reps,
-                       float* kernel_ms);  // ymk_conv_astat.hip
+bool gemm_takes_astat(int M, int K, const ConvW& w, bool with_res, int ld);
 bool conv_debug_option(const std::string& key, int value);
 bool parseq_debug_option(const std::string& key, int value);
 bool decstep_debug_option(const std::string& key, int value);
 bool conv_split_debug_option(const std::string& key, int value);
+bool conv_split_stat(const std::string& key, long long* value);
 void amax_check_counters(long long* out4);
 }  // namespace ymk
 
@@ -178,6 +178,15 @@ int ymk_debug_option(const char* key, int value) {
   YMK_API_END
 }
 
+int ymk_stat(const char* key, int64_t* value) {
+  YMK_API_BEGIN
+  YMK_CHECK(key != nullptr && value != nullptr, "null argument");
+  long long v = 0;
+  YMK_CHECK(ymk::conv_split_stat(std::string(key), &v), std::string("unknown counter: ") + key);
+  *value = v;
+  YMK_API_END
+}
+
 int ymk_amax_check_counters(int64_t* out4) {
   YMK_API_BEGIN
   YMK_CHECK(out4 != nullptr, "null argument");
@@ -250,20 +259,65 @@ int ymk_op_conv2d(const float* x_dev, int n, int h, int w, int c, const float* w
 }
 
 int ymk_op_conv1x1_astat(const float* x_dev, int m, int c, const float* w_host_oc, int cout, const float* scale_host,
-                         const float* bias_host, const float* res_dev, int act, float* y_dev, int reps, float* kernel_ms, void* stream) {
+                         const float* bias_host, const float* res_dev, int act, const float* ln_g_host, const float* ln_b_host, float ln_eps,
+                         float* y_dev, int reps, float* kernel_ms, void* stream) {
   YMK_API_BEGIN
   using namespace ymk;
   YMK_CHECK(x_dev && w_host_oc && y_dev && m > 0 && c > 0 && cout > 0, "bad argument");
+  YMK_CHECK((ln_g_host == nullptr) == (ln_b_host == nullptr), "LayerNorm: gamma and beta come together");
+  hipStream_t s = (hipStream_t)stream;
   DevicePool pool;
   ConvW cw;
   cw.cout = cout;
   cw.cin = c;
   std::vector<float> panel;
+  YMK_CHECK(c % 4 == 0, "astat: channels must be a multiple of 4");
   pack_conv_weight(w_host_oc, cout, c, 1, 1, false, panel, cw.kpad, cw.ctiles);
+  YMK_CHECK(cw.kpad <= 256, "astat: K <= 256");
   cw.w = pool.upload(panel);
   if (scale_host) cw.scale = pool.upload(scale_host, cout);
   if (bias_host) cw.bias = pool.upload(bias_host, cout);
-  conv1x1_f16_astat((hipStream_t)stream, x_dev, m, c, cw, res_dev, act, y_dev, reps, kernel_ms);
+  // the input's max|x| record: measured - or, in front of a fused LayerNorm, the static bound of its output, as the models do
+  unsigned* rec = nullptr;
+  const float *g_dev = nullptr, *b_dev = nullptr;
+  if (ln_g_host) {
+    const std::vector<float> g(ln_g_host, ln_g_host + c), b(ln_b_host, ln_b_host + c);
+    g_dev = pool.upload(g);
+    b_dev = pool.upload(b);
+    rec = make_layernorm_amax_record(pool, g, b);
+  } else {
+    rec = reinterpret_cast<unsigned*>(pool.alloc(AMAX_REC_WORDS));
+    YMK_HIP(hipMemsetAsync(rec, 0, AMAX_REC_WORDS * sizeof(unsigned), s));
+    absmax_record(s, x_dev, (size_t)m * c, rec);
+  }
+  struct Events {  // freed on every way out (a failing HIP call throws)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Events() {
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+      (void)conv_split_debug_option("conv_split_tile", 0);
+    }
+  } ev;
+  YMK_HIP(hipEventCreate(&ev.e0));
+  YMK_HIP(hipEventCreate(&ev.e1));
+  SplitCtxOwner split_ctx;  // the fp16 planes of this call's panel live and die with it
+  ConvSplitScope scope(SPLIT_F16X2, split_ctx.get(), 0);
+  YMK_CHECK(conv_split_debug_option("conv_split_tile", 30), "conv_split_tile");  // the A-stationary kernel for whatever it can run
+  for (int r = 0; r < std::max(1, reps); ++r) {
+    if (r == std::max(1, reps) - 1) YMK_HIP(hipEventRecord(ev.e0, s));
+    if (ln_g_host) {
+      YMK_CHECK(gemm_ln_fused(s, x_dev, m, c, c, g_dev, b_dev, ln_eps, cw, act, res_dev, cout, y_dev, cout, rec),
+                "astat: this launch cannot carry a fused LayerNorm (C must be 128 or 192)");
+    } else {
+      YMK_CHECK(gemm_takes_astat(m, c, cw, res_dev != nullptr, cout), "astat: not a launch the A-stationary kernel runs");
+      gemm(s, x_dev, m, c, c, cw, act, res_dev, cout, y_dev, cout, nullptr, nullptr, EPI_STORE, rec);
+    }
+    if (r == std::max(1, reps) - 1) YMK_HIP(hipEventRecord(ev.e1, s));
+  }
+  YMK_HIP(hipStreamSynchronize(s));
+  float ms = 0.f;
+  YMK_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+  if (kernel_ms) *kernel_ms = ms;
   YMK_API_END
 }
 

@@ -55,6 +55,11 @@ struct Tensor {
   int n = 0, h = 0, w = 0, c = 0;
   int ld = 0;  // floats between consecutive pixels (>= c)
   unsigned* amax = nullptr;  // record of max|x| over the tensor, filled by its producer (see above), or null
+  // true: the values are stored as the two scaled fp16 planes the fp16-split kernels multiply with, not as fp32 - per pixel and
+  // 32-channel slice 32 high halves then 32 low halves (128 bytes, where the fp32 form has its 32 floats: same size, same ld),
+  // scaled by the power of two that f16 scales derive from the record `amax` (which then holds the producer's BOUND, below).
+  // Only a k x k convolution on the LDS-DMA kernel reads such a tensor (conv_planes_pair_ok decides; ymk_conv_dma.hip).
+  bool planes = false;
   size_t pixels() const { return (size_t)n * h * w; }
   Tensor slice_c(int c0, int cn) const {
     Tensor t = *this;
@@ -111,6 +116,27 @@ __device__ __forceinline__ unsigned amax_read(const unsigned* rec, int lane) {
 // ---------------------------------------------------------------- activations
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_SIGMOID = 3, ACT_GELU = 4 };
 
+// GELU, exact (erf) form: 0.5 v (1 + erf(v / sqrt 2)) - timm's ViT blocks and the PARSeq decoder (nn.GELU(), parseq_transformer.py:
+// 57, 188-204).  erf through erfc(z) = t P(t) exp(-z^2), t = 1 / (1 + p z) (the Abramowitz-Stegun 7.1.26 form with one more
+// coefficient, refitted: 8e-9 in exact arithmetic, 4e-7 absolute as evaluated in fp32 - the rounding of a libm-grade erff times v
+// is the same size, and both sit at the 2^-21 of one fp16-plane product).  Branch-free: 13 VALU instructions and two
+// quarter-rate ones (v_rcp_f32, v_exp_f32) where the library erff costs ~40 with both of its ranges evaluated; the GELU epilogue
+// of the ViT fc1 layers was as long as their MFMA work.  Every kernel of the library uses this one function.
+__device__ __forceinline__ float gelu_f32(float v) {
+  const float z = fabsf(v) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.39032074649205456f, z, 1.f));
+  float q = -0.22690855651422961f;
+  q = fmaf(q, t, 0.8816638035254636f);
+  q = fmaf(q, t, -0.6277749224408846f);
+  q = fmaf(q, t, 0.6443424378640197f);
+  q = fmaf(q, t, 0.09342759526711675f);
+  q = fmaf(q, t, 0.23524963446014596f);
+  const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
+  const float r = fmaf(-(t * q), e, 1.f);  // erf(|v| / sqrt 2)
+  const float hv = 0.5f * v;
+  return fmaf(hv, copysignf(r, v), hv);
+}
+
 // ---------------------------------------------------------------- conv / linear
 // Packed weight panel for the implicit-GEMM kernel (ymk_conv.hip).
 //   mode 0 ("chunk"): K runs tap-major, each tap owns ctiles*32 slots (channels zero padded)
@@ -121,6 +147,10 @@ struct ConvW {
   float* bias = nullptr;   // [cout] or null
   int cout = 0, cin = 0, kh = 1, kw = 1;
   int kpad = 0, ctiles = 0, mode = 0;
+  // |y| <= pl_a max|x| + pl_b for every output of the layer before a residual (pl_a = max over output channels of |scale|
+  // times the L1 norm of the channel's weights, pl_b = max |bias|; ReLU / SiLU / GELU only shrink it): the bound a producer
+  // of fp16 PLANES scales its outputs by - the scale must be known before the first output exists
+  float pl_a = 0.f, pl_b = 0.f;
 };
 
 // EPI_ROWMAX: instead of the tile, every row's (largest value, its column) within the tile: out[m][tile_n] = {max as float,
@@ -143,6 +173,12 @@ struct ConvArgs {
   // max|x| records for callers without Tensor objects (gemm): of the input (filled by its producer) / to fill for the output
   const unsigned* amax_in = nullptr;
   unsigned* amax_out = nullptr;
+  // LayerNorm(gamma, beta, eps) over the input's channels fused into the operand load (gemm_ln_fused only; ConvK::ln_g)
+  const float* ln_g = nullptr;
+  const float* ln_b = nullptr;
+  float ln_eps = 0.f;
+  // the output is written as fp16 planes (Tensor::planes) under the bound pl_a max|x_in| + pl_b; the caller marks the tensor
+  bool out_planes = false;
 };
 
 // Split-operand convolutions (ymk_conv_split.hip).  "conv_split" codes: 0 = exact fp32 MFMA; 2 / 3 = operands cut into
@@ -183,11 +219,25 @@ void absmax_record(hipStream_t s, const float* x, size_t n, unsigned* rec);
 // out must be pre-shaped (n, oh, ow, cout[, ld]); for EPI_DECONV2X2 out is (n, 2h, 2w, cout/4).
 void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, const Tensor& out);
 
+// A 1 x 1 (or any) convolution `w1` whose ONLY consumer is the k x k convolution `w2`: may the tensor between them live as fp16
+// planes?  True when the process runs the fp16-split form with the "act_planes" option on, both launches fill the chip, the
+// producer lands on a kernel whose epilogue writes planes (not the A-stationary one) with an activation that cannot grow its
+// input (none / ReLU / SiLU / GELU), no residual, and the consumer lands on the LDS-DMA kernel.  The producer then gets
+// ConvArgs::out_planes, its output Tensor::planes = true.  `in`: the producer's input.
+bool conv_planes_pair_ok(const Tensor& in, const ConvW& w1, const ConvArgs& a1, const ConvW& w2, const ConvArgs& a2);
+
 // Row-major GEMM view of the same kernel: out[m][:] = act(A[m][:] . W^T * scale + bias + res[m][:]).
 // `res_ld == 0` broadcasts one residual row to every m.
 void gemm(hipStream_t s, const float* A, int M, int K, int lda, const ConvW& w, int act, const float* res, int res_ld,
           float* out, int out_ld, const int* row_group = nullptr, const int* group_open = nullptr, int epi = EPI_STORE,
           const unsigned* amax_in = nullptr, unsigned* amax_out = nullptr);
+
+// out[m][:] = act(LayerNorm(X[m][:]; gamma, beta, eps) . W^T * scale + bias + res[m][:]) in ONE launch, the normalised rows never
+// written (conv_f16_astat<.., LN>, ymk_conv_astat.hip: fp16-split mode, K = 128 / 192, a launch that fills the chip).
+// amax_in: the STATIC bound of the LayerNorm's output (make_layernorm_amax_record).  False = nothing was launched: the caller
+// runs layernorm() and gemm() (timm ViT blocks norm1 -> attn.qkv and norm2 -> mlp.fc1, parseq_transformer.py:188-204).
+bool gemm_ln_fused(hipStream_t s, const float* X, int M, int K, int ldx, const float* ln_g, const float* ln_b, float ln_eps, const ConvW& w,
+                   int act, const float* res, int res_ld, float* out, int out_ld, const unsigned* amax_in, unsigned* amax_out = nullptr);
 
 // Host-side packing: OIHW fp32 -> panel. `cin_pad4` packs for the tap4 mode (cin<=4).
 void pack_conv_weight(const float* oihw, int cout, int cin, int kh, int kw, bool tap4,

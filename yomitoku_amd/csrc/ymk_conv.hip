@@ -678,8 +678,21 @@ static void launch_n64(hipStream_t s, ConvK& k) {
   }
 }
 
-void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, const Tensor& out) {
+// conv2d proper.  With a LayerNorm to fuse (a.ln_g) only the fp16-split path is tried and the result says whether it took the
+// launch; without one every launch is taken by some kernel (true).
+static bool conv2d_impl(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, const Tensor& out) {
   ConvK k{};
+  k.ln_g = a.ln_g;
+  k.ln_b = a.ln_b;
+  k.ln_eps = a.ln_eps;
+  k.in_planes = in.planes ? 1 : 0;
+  k.out_planes = a.out_planes ? 1 : 0;
+  k.pl_a = w.pl_a;
+  k.pl_b = w.pl_b;
+  if (a.out_planes)
+    YMK_CHECK(a.epi == EPI_STORE && a.res == nullptr && out.ld == w.cout && w.cout % 32 == 0 && out.amax != nullptr,
+              "conv: fp16 planes are written by plain stores into a whole tensor of 32-channel slices that has a record");
+  if (in.planes) YMK_CHECK(in.ld == in.c && in.c % 32 == 0 && in.amax != nullptr, "conv: malformed tensor of fp16 planes");
   k.in = in.p;
   k.w = w.w;
   k.scale = w.scale;
@@ -732,9 +745,10 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
     YMK_CHECK(w.kh == 1 && w.kw == 1 && a.stride == 1 && a.pad == 0, "deconv epilogue wants a 1x1 panel");
     YMK_CHECK(out.n == in.n && out.h == 2 * in.h && out.w == 2 * in.w && out.c * 4 == w.cout, "deconv: bad output shape");
   }
-  if (k.M == 0) return;
+  if (k.M == 0) return true;
   {
     const size_t ib = ((in.pixels() - 1) * (size_t)in.ld + in.c) * sizeof(float);
+    if (a.ln_g != nullptr && ib >= (size_t)OOB_OFFSET) return false;
     YMK_CHECK(ib < (size_t)OOB_OFFSET, "conv input view must stay below 4 GiB (split the batch)");
     k.in_bytes = (unsigned)ib;
   }
@@ -751,7 +765,9 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
     int split = t_conv_split;
     if (split < 0) split = g_conv_split.load(std::memory_order_relaxed);
     if (split < 0) split = t_split_default;
-    if (split != 0 && t_split_ctx != nullptr && conv2d_split(s, k, w, split, t_split_ctx)) return;
+    if (split != 0 && t_split_ctx != nullptr && conv2d_split(s, k, w, split, t_split_ctx)) return true;
+    if (a.ln_g != nullptr) return false;
+    YMK_CHECK(!in.planes && !a.out_planes, "conv: fp16 planes outside the fp16-split path (conv_planes_pair_ok decides before the launch)");
   }
   if (a.epi == EPI_ROWMAX) {  // fixed 64-column tiles (the caller sized the partial table for them), never split-K
     k.vec = 0;
@@ -761,7 +777,7 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
     hipLaunchKernelGGL((conv_igemm<64, 64, 2, 2, 0, 1>), dim3(mt * nt), dim3(256), 0, s, k);
     if (e) YMK_HIP(hipEventRecord(e->second, s));
     YMK_HIP(hipGetLastError());
-    return;
+    return true;
   }
   // tile selection: wide tiles when there is enough work to fill 256 CUs x 2 blocks
   const long blocks128 = (long)((k.M + 127) / 128) * ((w.cout + 127) / 128);
@@ -794,6 +810,49 @@ void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, 
     else launch<64, 64, 2, 2>(s, k);
   }
   YMK_HIP(hipGetLastError());
+  return true;
+}
+
+int conv_split_route_with_planes(long M, int cout, int kpad, int taps, bool* auto_tile);  // ymk_conv_split.hip
+
+bool conv_planes_pair_ok(const Tensor& in, const ConvW& w1, const ConvArgs& a1, const ConvW& w2, const ConvArgs& a2) {
+  if (conv_effective_split() != SPLIT_F16X2 || t_split_ctx == nullptr) return false;
+  if (w1.mode != 0 || w2.mode != 0 || a1.epi != EPI_STORE || a2.epi != EPI_STORE || a1.res != nullptr) return false;
+  if (a1.row_group != nullptr || a2.row_group != nullptr || a1.ln_g != nullptr) return false;
+  if (a1.act != ACT_NONE && a1.act != ACT_RELU && a1.act != ACT_SILU && a1.act != ACT_GELU) return false;
+  if (w1.cout % 32 != 0 || w2.cin != w1.cout || w2.kh * w2.kw <= 1 || in.planes) return false;
+  const int sw1 = a1.stride_w > 0 ? a1.stride_w : a1.stride, sw2 = a2.stride_w > 0 ? a2.stride_w : a2.stride;
+  const int h1 = conv_out_dim(in.h, w1.kh, a1.stride, a1.pad, a1.dil), v1 = conv_out_dim(in.w, w1.kw, sw1, a1.pad, a1.dil);
+  const int h2 = conv_out_dim(h1, w2.kh, a2.stride, a2.pad, a2.dil), v2 = conv_out_dim(v1, w2.kw, sw2, a2.pad, a2.dil);
+  if (h1 <= 0 || v1 <= 0 || h2 <= 0 || v2 <= 0) return false;
+  if ((size_t)in.n * h1 * v1 * w1.cout * sizeof(float) >= (size_t)OOB_OFFSET) return false;  // the consumer's input view
+  bool auto1 = false, auto2 = false;
+  const int r1 = conv_split_route_with_planes((long)in.n * h1 * v1, w1.cout, w1.kpad, w1.kh * w1.kw, &auto1);
+  const int r2 = conv_split_route_with_planes((long)in.n * h2 * v2, w2.cout, w2.kpad, w2.kh * w2.kw, &auto2);
+  return auto1 && auto2 && (r1 == 2 || r1 == 3) && r2 == 2;  // producer: LDS-DMA or register-staged kernel; consumer: LDS-DMA
+}
+
+void conv2d(hipStream_t s, const Tensor& in, const ConvW& w, const ConvArgs& a, const Tensor& out) {
+  YMK_CHECK(a.ln_g == nullptr, "conv2d: a fused LayerNorm goes through gemm_ln_fused");
+  (void)conv2d_impl(s, in, w, a, out);
+}
+
+bool gemm_ln_fused(hipStream_t s, const float* X, int M, int K, int ldx, const float* ln_g, const float* ln_b, float ln_eps, const ConvW& w,
+                   int act, const float* res, int res_ld, float* out, int out_ld, const unsigned* amax_in, unsigned* amax_out) {
+  YMK_CHECK(K == w.cin && ln_g != nullptr && ln_b != nullptr, "gemm_ln_fused: K must equal the weight's in-features; gamma and beta are required");
+  if (w.kh != 1 || w.kw != 1 || w.mode != 0 || amax_in == nullptr) return false;
+  Tensor in{const_cast<float*>(X), 1, 1, M, K, ldx};
+  Tensor o{out, 1, 1, M, w.cout, out_ld};
+  Tensor r{const_cast<float*>(res), 1, 1, M, w.cout, res_ld};
+  ConvArgs a;
+  a.act = act;
+  a.res = res ? &r : nullptr;
+  a.amax_in = amax_in;
+  a.amax_out = amax_out;
+  a.ln_g = ln_g;
+  a.ln_b = ln_b;
+  a.ln_eps = ln_eps;
+  return conv2d_impl(s, in, w, a, o);
 }
 
 void gemm(hipStream_t s, const float* A, int M, int K, int lda, const ConvW& w, int act, const float* res, int res_ld,

@@ -1,11 +1,12 @@
-// A-stationary fp16-split 1 x 1 convolution for short K (K <= 256): CANDIDATE kernel - conv2d does not dispatch to it; it
-// is reachable only through ymk_op_conv1x1_astat (include/ymk.h), where tests/test_conv_astat_gpu.py compares it with the
-// kernels the models run (bit for bit) and tools/astat_timing.py times it (profiles/r04_conv_astat_candidate_timing.jsonl).  Why it exists: DESIGN.md section 9 item 1,
-// profiles/r04_conv_two_roof_by_layer.md (the K = 192 linear layers of the PARSeq encoder at 0.22-0.45 of their HBM roof, the
-// ResNet expands at 0.38-0.57) and profiles/r04_conv_f16_short_k_pmc_pass*.csv (their waves wait two thirds of their cycles,
-// 16 VALU + 12.6 SALU instructions per MFMA: every 128 x 128 tile pays the A fetch, the fp32 -> (h, l) conversion and the
-// prologue again for a K loop of 2-8 steps).  References for the layers: models/layers/parseq_transformer.py:188-204 (timm ViT
-// blocks), models/dbnet_plus.py:33-38 (ResNet-50 bottlenecks).
+// A-stationary fp16-split 1 x 1 convolution for short K (K <= 256).  Round 4 built and validated it behind a test operator;
+// round 5 routes the library's short-K pointwise layers to it (conv2d_split in ymk_conv_split.hip: the PARSeq encoder's qkv /
+// proj / fc1, the ResNet expands with their residual, the decoders' 256 -> 256 projections) and folds the LayerNorm in front of
+// a linear layer into its operand load.  Why it exists: profiles/r04_conv_two_roof_by_layer.md (the K = 192 linear layers of
+// the PARSeq encoder at 0.22-0.45 of their HBM roof, the ResNet expands at 0.38-0.57) and
+// profiles/r04_conv_f16_short_k_pmc_pass*.csv (their waves wait two thirds of their cycles, 16 VALU + 12.6 SALU instructions
+// per MFMA: every 128 x 128 tile pays the A fetch, the fp32 -> (h, l) conversion and the prologue again for a K loop of 2-8
+// steps).  References for the layers: models/layers/parseq_transformer.py:188-204 (timm ViT blocks: norm1 -> qkv, norm2 ->
+// fc1), models/dbnet_plus.py:33-38 (ResNet-50 bottlenecks).
 //
 // Same arithmetic as conv_f16_dma (ymk_conv_dma.hip): two scaled fp16 planes per fp32 operand, the three MFMAs of a product
 // tile in the same order, the same K order - the results must equal that kernel's bit for bit.  What changes is who waits:
@@ -97,7 +98,10 @@ __device__ __forceinline__ void astat_store(const ConvK& p, const f32x16 (&acc)[
 
 // 1 x 1, stride 1, no padding (the caller checks); KT = Kpad / 32 K tiles (compile time: the A planes live in registers);
 // BN columns per column block; grid = ceil(M / 128) x column groups (p.ntiles_n column blocks are dealt to gridDim.y groups)
-template <int BN, int KT>
+// LN: the rows are LayerNorm-ed on their way into the planes (p.ln_g / p.ln_b / p.ln_eps over the C = 32 KT channels of a row:
+// a row lives in the two lanes li and li + 32 of its wave, so mean and variance are one xor-shuffle away) - what
+// k_layernorm + this kernel computed through a [M][C] round trip; p.amax is then the LayerNorm's static output bound.
+template <int BN, int KT, bool LN = false>
 __global__ __launch_bounds__(256, 2) void conv_f16_astat(ConvK p, const uint4* __restrict__ wsplit, unsigned w_bytes) {
   constexpr int TN = BN / 32;
   constexpr int RG = KT * 16 + TN * 24 <= 160 ? 16 : 4;  // residual values in flight per lane: as many as the registers allow
@@ -139,10 +143,50 @@ __global__ __launch_bounds__(256, 2) void conv_f16_astat(ConvK p, const uint4* _
         u[kt][s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)o0, 0, 0));
         v[kt][s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)o1, 0, 0));
       }
+    if constexpr (LN) {
+      // torch.nn.LayerNorm as k_layernorm computes it: mean, then the biased variance of the centred values, then
+      // (x - mean) * rstd * gamma + beta; C == 32 KT here (the launcher checks), so no lane holds a padding channel
+      float sum = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+      for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) astat_split8(u[kt][s], v[kt][s], sa, ah[kt][s], al[kt][s]);
+        for (int s = 0; s < 2; ++s)
+          sum += ((u[kt][s].x + u[kt][s].y) + (u[kt][s].z + u[kt][s].w)) + ((v[kt][s].x + v[kt][s].y) + (v[kt][s].z + v[kt][s].w));
+      sum += __shfl_xor(sum, 32);
+      const float mean = sum / (float)(32 * KT);
+      float sq = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          u[kt][s] -= mean;
+          v[kt][s] -= mean;
+          sq += ((u[kt][s].x * u[kt][s].x + u[kt][s].y * u[kt][s].y) + (u[kt][s].z * u[kt][s].z + u[kt][s].w * u[kt][s].w)) +
+                ((v[kt][s].x * v[kt][s].x + v[kt][s].y * v[kt][s].y) + (v[kt][s].z * v[kt][s].z + v[kt][s].w * v[kt][s].w));
+        }
+      sq += __shfl_xor(sq, 32);
+      const float rstd = 1.f / sqrtf(sq / (float)(32 * KT) + p.ln_eps);
+      // scale / shift and cut one K tile at a time behind a scheduling fence: the staging registers of a tile die as its planes
+      // are born.  (At K = 192 the compiler still parks 44 registers in scratch across this prologue - 256 are not quite enough
+      // for a whole fp32 row next to its planes; visiting the row a second time instead, tile by tile, measured no fewer in the
+      // resource report and adds an L2 round trip per tile.)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int c = kt * 32 + s * 16 + lh * 8;
+          const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.ln_g + c), g1 = *reinterpret_cast<const f32x4*>(p.ln_g + c + 4);
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.ln_b + c), b1 = *reinterpret_cast<const f32x4*>(p.ln_b + c + 4);
+          astat_split8(u[kt][s] * rstd * g0 + b0, v[kt][s] * rstd * g1 + b1, sa, ah[kt][s], al[kt][s]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) astat_split8(u[kt][s], v[kt][s], sa, ah[kt][s], al[kt][s]);
+    }
   }
 
   // ---- B: slab q = (nb - nb0) KT + kt of this block's sequence -> stage q % 3, two slabs ahead
@@ -162,8 +206,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16_astat(ConvK p, const uint4* _
   };
 
   const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (unsigned)p.M * (unsigned)p.out_ld * 4u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.out), 0,
-                                                                          (unsigned)p.M * (unsigned)(p.res ? p.res_ld : p.out_ld) * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.res ? p.res : p.out), 0,
+      p.res ? (p.res_ld ? (unsigned)p.M * (unsigned)p.res_ld * 4u : (unsigned)p.Cout * 4u) : (unsigned)p.M * (unsigned)p.out_ld * 4u, 0x00020000);
   unsigned am = 0u;
   f32x16 acc[TN];
 #pragma unroll
@@ -242,111 +287,80 @@ __global__ __launch_bounds__(256, 2) void conv_f16_astat(ConvK p, const uint4* _
 __global__ void k_split_panel_f16(const float* __restrict__ w, unsigned short* __restrict__ out, int kpad, const float* __restrict__ scale,
                                   int cout, float* __restrict__ scale_out, int taps, int ctiles);
 
-template <int BN, int KT>
+template <int BN, int KT, bool LN>
 static void launch_astat(hipStream_t s, ConvK& k, const void* planes, size_t w_bytes, int groups) {
-  k.ntiles_n = (k.Cout + BN - 1) / BN;
-  hipLaunchKernelGGL((conv_f16_astat<BN, KT>), dim3((k.M + 127) / 128, groups), dim3(256), 0, s, k, reinterpret_cast<const uint4*>(planes), (unsigned)w_bytes);
+  hipLaunchKernelGGL((conv_f16_astat<BN, KT, LN>), dim3((k.M + 127) / 128, groups), dim3(256), 0, s, k, reinterpret_cast<const uint4*>(planes), (unsigned)w_bytes);
 }
 
-// y[M][Cout] = act(scale * (x[M][C] . W^T) + bias + res) through the A-stationary kernel; w: packed fp32 panel of a 1 x 1
-// layer (pack_conv_weight), planes and max|x| record built here per call (a test operator: nothing is cached).
-// kernel_ms: HIP-event time of the convolution launch alone (the last of `reps` launches).
-void conv1x1_f16_astat(hipStream_t s, const float* x, int M, int C, const ConvW& w, const float* res, int act, float* y, int reps,
-                       float* kernel_ms) {
-  YMK_CHECK(w.kh == 1 && w.kw == 1 && w.mode == 0 && w.cin == C && C % 4 == 0, "astat: a packed 1 x 1 layer with C % 4 == 0");
-  YMK_CHECK(w.kpad % 32 == 0 && w.kpad >= 32 && w.kpad <= 256, "astat: K <= 256");
-  YMK_CHECK(M > 0 && (size_t)M * (size_t)std::max(C, w.cout) * 4 < (size_t)OOB_OFFSET, "astat: views below 4 GiB");
-  const size_t rows = (size_t)((w.cout + 255) / 256 * 256), real = (size_t)((w.cout + 127) / 128 * 128);
-  const size_t w_bytes = rows * w.kpad * 2 * 2;
-  YMK_CHECK(w_bytes < (size_t)OOB_OFFSET, "astat: weight planes below 4 GiB");
-  struct Scratch {  // freed on every way out (a failing HIP call throws)
-    void* planes = nullptr;
-    float* wscale = nullptr;
-    unsigned* rec = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    ~Scratch() {
-      if (e0) (void)hipEventDestroy(e0);
-      if (e1) (void)hipEventDestroy(e1);
-      (void)hipFree(planes);
-      (void)hipFree(wscale);
-      (void)hipFree(rec);
-    }
-  } sc;
-  YMK_HIP(hipMalloc(&sc.planes, w_bytes));
-  YMK_HIP(hipMalloc(reinterpret_cast<void**>(&sc.wscale), real * sizeof(float)));
-  YMK_HIP(hipMalloc(reinterpret_cast<void**>(&sc.rec), AMAX_REC_WORDS * sizeof(unsigned)));
-  YMK_HIP(hipEventCreate(&sc.e0));
-  YMK_HIP(hipEventCreate(&sc.e1));
-  void* const planes = sc.planes;
-  float* const wscale = sc.wscale;
-  unsigned* const rec = sc.rec;
-  const hipEvent_t e0 = sc.e0, e1 = sc.e1;
-  YMK_HIP(hipMemsetAsync(planes, 0, w_bytes, s));
-  YMK_HIP(hipMemsetAsync(rec, 0, AMAX_REC_WORDS * sizeof(unsigned), s));
-  hipLaunchKernelGGL(k_split_panel_f16, dim3((unsigned)real), dim3(256), 0, s, w.w, reinterpret_cast<unsigned short*>(planes), w.kpad, w.scale,
-                     w.cout, wscale, 1, w.ctiles);
-  absmax_record(s, x, (size_t)M * C, rec);
+// column width of the launch: 64 where the registers are needed elsewhere - K > 192 (A planes of 7-8 K tiles), a residual at
+// K > 128 (sixteen residual values in flight per lane instead of four: what the K = 192 projection lost to in round 4), a
+// fused LayerNorm (the fp32 staging of a whole row next to its planes) - and for Cout <= 64
+static bool astat_narrow(const ConvK& k) { return k.Kpad > 192 || k.Cout <= 64 || (k.res != nullptr && k.Kpad > 128) || k.ln_g != nullptr; }
+
+int conv2d_f16_astat_columns(const ConvK& k) { return astat_narrow(k) ? 64 : 128; }
+
+// The launch (conv2d_split routes to it; the caller has set k.scale to the fp16 panels' epilogue scale and k.amax).  A 1 x 1,
+// stride-1, unpadded layer with Kpad <= 256, plain stores, views below 4 GiB; with k.ln_g: C == Kpad.  False = not taken.
+bool conv2d_f16_astat_can(const ConvK& k, size_t w_bytes) {
+  if (k.KH != 1 || k.KW != 1 || k.stride != 1 || k.stride_w != 1 || k.pad != 0 || k.epi != EPI_STORE || k.row_group != nullptr) return false;
+  if (k.Kpad % 32 != 0 || k.Kpad < 32 || k.Kpad > 256 || k.C % 4 != 0 || k.M <= 0) return false;
+  if ((size_t)k.M * (size_t)k.out_ld * 4 >= (size_t)OOB_OFFSET || (size_t)k.M * (size_t)k.res_ld * 4 >= (size_t)OOB_OFFSET) return false;
+  if (w_bytes >= (size_t)OOB_OFFSET) return false;
+  if (k.ln_g != nullptr && (k.C != k.Kpad || k.ln_b == nullptr || (k.Kpad != 128 && k.Kpad != 192))) return false;
+  return true;
+}
+
+// the same question for a row-major GEMM out[M][w.cout] = X[M][K] . W^T (leading dimension ld for output and residual)
+bool gemm_takes_astat(int M, int K, const ConvW& w, bool with_res, int ld) {
   ConvK k{};
-  k.in = x;
-  k.scale = wscale;
-  k.bias = w.bias;
-  k.res = res;
-  k.res_ld = res ? w.cout : 0;
-  k.out = y;
-  k.H = 1;
-  k.W = M;
-  k.C = C;
-  k.in_ld = C;
-  k.KH = k.KW = 1;
-  k.stride = k.stride_w = 1;
-  k.dil = 1;
-  k.OH = 1;
-  k.OW = M;
-  k.Cout = w.cout;
-  k.out_ld = w.cout;
-  k.Kpad = w.kpad;
-  k.ctiles = w.ctiles;
-  k.M = M;
-  k.act = act;
+  k.KH = k.KW = k.stride = k.stride_w = 1;
   k.epi = EPI_STORE;
-  k.in_bytes = (unsigned)((size_t)M * C * 4);
-  k.amax = rec;
+  k.Kpad = w.kpad;
+  k.C = K;
+  k.M = M;
+  k.out_ld = ld;
+  k.res_ld = with_res ? ld : 0;
+  return w.kh == 1 && w.kw == 1 && w.mode == 0 && conv2d_f16_astat_can(k, (size_t)((w.cout + 255) / 256 * 256) * w.kpad * 4);
+}
+
+bool conv2d_f16_astat(hipStream_t s, ConvK& k, const void* planes, size_t w_bytes) {
+  if (!conv2d_f16_astat_can(k, w_bytes)) return false;
+  const bool narrow = astat_narrow(k);
+  const int bn = narrow ? 64 : 128;
+  k.ntiles_n = (k.Cout + bn - 1) / bn;
   // few row blocks: deal the column blocks to groups so that the launch still covers the chip (A is then loaded per group)
-  const int mblocks = (M + 127) / 128;
-  const bool narrow = w.kpad > 192 || w.cout <= 64;
-  const int nt = (w.cout + (narrow ? 63 : 127)) / (narrow ? 64 : 128);
+  const int mblocks = (k.M + 127) / 128;
   int groups = 1;
-  while (mblocks * groups < 512 && groups * 2 <= nt) groups *= 2;
-  for (int r = 0; r < std::max(1, reps); ++r) {
-    YMK_HIP(hipEventRecord(e0, s));
-    if (narrow) {
-      switch (w.kpad / 32) {
-        case 1: launch_astat<64, 1>(s, k, planes, w_bytes, groups); break;
-        case 2: launch_astat<64, 2>(s, k, planes, w_bytes, groups); break;
-        case 3: launch_astat<64, 3>(s, k, planes, w_bytes, groups); break;
-        case 4: launch_astat<64, 4>(s, k, planes, w_bytes, groups); break;
-        case 5: launch_astat<64, 5>(s, k, planes, w_bytes, groups); break;
-        case 6: launch_astat<64, 6>(s, k, planes, w_bytes, groups); break;
-        case 7: launch_astat<64, 7>(s, k, planes, w_bytes, groups); break;
-        default: launch_astat<64, 8>(s, k, planes, w_bytes, groups); break;
-      }
-    } else {
-      switch (w.kpad / 32) {
-        case 1: launch_astat<128, 1>(s, k, planes, w_bytes, groups); break;
-        case 2: launch_astat<128, 2>(s, k, planes, w_bytes, groups); break;
-        case 3: launch_astat<128, 3>(s, k, planes, w_bytes, groups); break;
-        case 4: launch_astat<128, 4>(s, k, planes, w_bytes, groups); break;
-        case 5: launch_astat<128, 5>(s, k, planes, w_bytes, groups); break;
-        default: launch_astat<128, 6>(s, k, planes, w_bytes, groups); break;
-      }
+  while (mblocks * groups < 512 && groups * 2 <= k.ntiles_n) groups *= 2;
+  const int kt = k.Kpad / 32;
+  if (k.ln_g != nullptr) {  // the ViT widths that fit the registers
+    switch (kt) {
+      case 4: launch_astat<64, 4, true>(s, k, planes, w_bytes, groups); break;
+      case 6: launch_astat<64, 6, true>(s, k, planes, w_bytes, groups); break;
+      default: return false;
     }
-    YMK_HIP(hipEventRecord(e1, s));
+  } else if (narrow) {
+    switch (kt) {
+      case 1: launch_astat<64, 1, false>(s, k, planes, w_bytes, groups); break;
+      case 2: launch_astat<64, 2, false>(s, k, planes, w_bytes, groups); break;
+      case 3: launch_astat<64, 3, false>(s, k, planes, w_bytes, groups); break;
+      case 4: launch_astat<64, 4, false>(s, k, planes, w_bytes, groups); break;
+      case 5: launch_astat<64, 5, false>(s, k, planes, w_bytes, groups); break;
+      case 6: launch_astat<64, 6, false>(s, k, planes, w_bytes, groups); break;
+      case 7: launch_astat<64, 7, false>(s, k, planes, w_bytes, groups); break;
+      default: launch_astat<64, 8, false>(s, k, planes, w_bytes, groups); break;
+    }
+  } else {
+    switch (kt) {
+      case 1: launch_astat<128, 1, false>(s, k, planes, w_bytes, groups); break;
+      case 2: launch_astat<128, 2, false>(s, k, planes, w_bytes, groups); break;
+      case 3: launch_astat<128, 3, false>(s, k, planes, w_bytes, groups); break;
+      case 4: launch_astat<128, 4, false>(s, k, planes, w_bytes, groups); break;
+      case 5: launch_astat<128, 5, false>(s, k, planes, w_bytes, groups); break;
+      default: launch_astat<128, 6, false>(s, k, planes, w_bytes, groups); break;
+    }
   }
-  YMK_HIP(hipGetLastError());
-  YMK_HIP(hipStreamSynchronize(s));
-  float ms = 0.f;
-  YMK_HIP(hipEventElapsedTime(&ms, e0, e1));
-  if (kernel_ms) *kernel_ms = ms;
+  return true;
 }
 
 }  // namespace ymk

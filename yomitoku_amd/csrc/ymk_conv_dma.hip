@@ -56,7 +56,13 @@ __device__ __forceinline__ void split8(const f32x4 u, const f32x4 v, float sa, h
 // DMA_WAVES waves of 32 rows x BN columns (block tile 32 DMA_WAVES x BN), DMA_NST LDS stages of one 32-k tile, loads
 // DMA_NST - 1 tiles ahead.  <BN, 8, 3>: 256-row tiles, 144 KB, one block per CU.  <BN, 4, 2>: 128-row tiles, 68 KB, TWO blocks
 // per CU - another block's main loop covers a block's prologue and epilogue (what the short-K layers need).
-template <int BN, int DMA_WAVES, int DMA_NST>
+// APL: the ACTIVATIONS are fp16 planes in HBM already (Tensor::planes: the 128 bytes of a pixel's 32-channel slice are 32 high
+// halves then 32 low halves, written by the producing convolution's epilogue under the scale of the record p.amax): the
+// fragment read is two ds_read_b128 straight into the MFMA operands - no fp32 -> (h, l) conversion in the loop, where the fp32
+// form spends 12 VALU instructions per 16-k step and tap (6.8 VALU per MFMA on the 3 x 3 layers, the MFMA pipe 0.47 busy:
+// profiles/r04_conv_f16_short_k_pmc_pass*.csv).  Same DMA addressing, same swizzle, same products in the same order.
+// OPL: the epilogue writes planes (epilogue_tile<.., PL>).
+template <int BN, int DMA_WAVES, int DMA_NST, bool APL = false, bool OPL = false>
 __global__ __launch_bounds__(64 * DMA_WAVES, 2) void conv_f16_dma(ConvK p, const uint4* __restrict__ wsplit, unsigned w_bytes) {
   constexpr int DMA_BM = 32 * DMA_WAVES, DMA_NT = 64 * DMA_WAVES;
   constexpr int TN = BN / 32;                 // 32-column MFMA tiles of a wave
@@ -173,11 +179,16 @@ __global__ __launch_bounds__(64 * DMA_WAVES, 2) void conv_f16_dma(ConvK p, const
     const char* As = lds + st * STAGE_B + arow * 128;
     const char* Bs = lds + st * STAGE_B + A_STAGE + li * 128;
     {
-      const int ca = s * 4 + lh * 2;
-      const f32x4 u = *reinterpret_cast<const f32x4*>(As + ((ca ^ aswz) * 16));
-      const f32x4 v = *reinterpret_cast<const f32x4*>(As + (((ca + 1) ^ aswz) * 16));
       hf16x8_t ah, al;
-      split8(u, v, sa, ah, al);
+      if constexpr (APL) {  // k = 16 s + 8 lh .. + 7 of the slice: high halves in slots 0-3, low halves in slots 4-7
+        ah = *reinterpret_cast<const hf16x8_t*>(As + (((s * 2 + lh) ^ aswz) * 16));
+        al = *reinterpret_cast<const hf16x8_t*>(As + (((4 + s * 2 + lh) ^ aswz) * 16));
+      } else {
+        const int ca = s * 4 + lh * 2;
+        const f32x4 u = *reinterpret_cast<const f32x4*>(As + ((ca ^ aswz) * 16));
+        const f32x4 v = *reinterpret_cast<const f32x4*>(As + (((ca + 1) ^ aswz) * 16));
+        split8(u, v, sa, ah, al);
+      }
       hf16x8_t bh[TN], bl[TN];
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
@@ -222,14 +233,21 @@ __global__ __launch_bounds__(64 * DMA_WAVES, 2) void conv_f16_dma(ConvK p, const
       Cs[row * LDC + b * 32 + li] = acc[b][r] * inv_sa;
     }
   __syncthreads();
-  epilogue_tile<DMA_BM, BN, DMA_NT>(p, Cs, m0, n0, t);
+  epilogue_tile<DMA_BM, BN, DMA_NT, false, 4, OPL>(p, Cs, m0, n0, t);
 }
 
-template <int BN, int WAVES, int NST>
+template <int BN, int WAVES, int NST, bool APL = false, bool OPL = false>
 static void launch_dma(hipStream_t s, ConvK& k, const void* wsplit, size_t w_bytes) {
   const int mt = (k.M + 32 * WAVES - 1) / (32 * WAVES), nt = (k.Cout + BN - 1) / BN;
   k.ntiles_n = nt;
-  hipLaunchKernelGGL((conv_f16_dma<BN, WAVES, NST>), dim3(mt * nt), dim3(64 * WAVES), 0, s, k, reinterpret_cast<const uint4*>(wsplit), (unsigned)w_bytes);
+  hipLaunchKernelGGL((conv_f16_dma<BN, WAVES, NST, APL, OPL>), dim3(mt * nt), dim3(64 * WAVES), 0, s, k, reinterpret_cast<const uint4*>(wsplit), (unsigned)w_bytes);
+}
+
+template <int BN>
+static void launch_dma_planes(hipStream_t s, ConvK& k, const void* wsplit, size_t w_bytes) {
+  if (k.in_planes && k.out_planes) launch_dma<BN, 4, 2, true, true>(s, k, wsplit, w_bytes);
+  else if (k.in_planes) launch_dma<BN, 4, 2, true, false>(s, k, wsplit, w_bytes);
+  else launch_dma<BN, 4, 2, false, true>(s, k, wsplit, w_bytes);
 }
 
 // the caller (conv2d_split) has resolved the panel and the input's max|x| record.  rows: 128 (4 waves, two stages, two or three
@@ -238,6 +256,12 @@ static void launch_dma(hipStream_t s, ConvK& k, const void* wsplit, size_t w_byt
 // 128 x 64 form measured no better than the two-stage one and was dropped)
 bool conv2d_f16_dma(hipStream_t s, ConvK& k, const void* wsplit, size_t w_bytes, bool narrow, int rows) {
   if (w_bytes >= (size_t)OOB_OFFSET) return false;
+  if (k.in_planes || k.out_planes) {  // the plane forms exist for the dispatch's own tile (128 rows) only
+    if (rows != 128) return false;
+    if (narrow) launch_dma_planes<64>(s, k, wsplit, w_bytes);
+    else launch_dma_planes<128>(s, k, wsplit, w_bytes);
+    return true;
+  }
   if (rows == 128) {
     if (narrow) launch_dma<64, 4, 2>(s, k, wsplit, w_bytes);
     else launch_dma<128, 4, 2>(s, k, wsplit, w_bytes);

@@ -33,6 +33,16 @@ struct ConvK {
                 // launches that cannot store 16 bytes per lane (ragged Cout: the 7119-wide vocabulary head)
   const unsigned* amax;  // fp16-split kernels only: max|x| record of the input view (ymk_common.h; ymk_conv_split.hip)
   unsigned* amax_out;    // every kernel: record to fold max|y| of the stored outputs into, or null
+  // conv_f16_astat only (ymk_conv_astat.hip): LayerNorm(gamma, beta, eps) over the C channels of every input row, applied on
+  // the way into the operand planes - the launch then computes act(LayerNorm(x) . W^T ...) without the normalised tensor
+  // ever existing in memory; null = plain input.  No other kernel looks at these: conv2d_split refuses what it cannot fuse.
+  const float* ln_g;
+  const float* ln_b;
+  float ln_eps;
+  // fp16 PLANES in HBM (Tensor::planes): in_planes - the input view holds planes (conv_f16_dma<.., APL> only); out_planes - the
+  // epilogue writes planes scaled from the bound pl_a max|x_in| + pl_b and leaves THAT bound in amax_out (epilogue_tile<.., PL>)
+  int in_planes, out_planes;
+  float pl_a, pl_b;
 };
 
 // true when some row of the block's M tile [m0, m0 + BM) is still needed (or no row predicate was given); block-uniform
@@ -52,9 +62,20 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     case ACT_RELU: return fmaxf(v, 0.f);
     case ACT_SILU: return v / (1.f + expf(-v));
     case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
-    case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    case ACT_GELU: return gelu_f32(v);
     default: return v;
   }
+}
+
+// max|x| bits -> {sa, 1 / sa}, sa the power of two that puts max|x| into [2^14, 2^15); both kept normal whatever the input
+// (the one definition behind f16_scales / dma_f16_scales / astat_scales of the three fp16 kernels)
+__device__ __forceinline__ float2 f16_plane_scales(unsigned amax_bits) {
+  int e = (int)(amax_bits >> 23);  // biased exponent, 0 .. 255
+  e = e < 27 ? 27 : (e > 227 ? 227 : e);
+  float2 r;
+  r.x = __uint_as_float((unsigned)(268 - e) << 23);  // 2^(14 - (e - 127))
+  r.y = __uint_as_float((unsigned)(e - 14) << 23);
+  return r;
 }
 
 constexpr int LDK = 36;  // padded K-tile row (floats)
@@ -105,9 +126,48 @@ __device__ __forceinline__ void prefetch_residual(const ConvK& p, int m0, int n0
   }
 }
 
-template <int BM, int BN, int NT, bool PRE = false, int UNROLL = 4>
+// PL (fp16 kernels only): the outputs leave as the two fp16 planes of Tensor::planes instead of fp32 - 4 high halves and 4 low
+// halves per thread and row (two 8-byte stores where the fp32 form has one 16-byte store), scaled by the power of two of the
+// BOUND pl_a max|x_in| + pl_b, which is also what the output's record receives: the consumer derives the same scale from it.
+// Plain stores with 16-byte channel groups only (the launcher checks: EPI_STORE, vec, no residual, out_ld == Cout % 32 == 0).
+template <int BM, int BN, int NT, bool PRE = false, int UNROLL = 4, bool PL = false>
 __device__ __forceinline__ void epilogue_tile(const ConvK& p, const float* Cs, int m0, int n0, int t, const float4* pre = nullptr) {
   constexpr int LDC = BN + 4;
+  if constexpr (PL) {
+    typedef _Float16 ep_h2 __attribute__((ext_vector_type(2)));
+    typedef float ep_f2 __attribute__((ext_vector_type(2)));
+    constexpr int TPR = BN / 4, RPP = NT / TPR;
+    const int c4 = t % TPR, r0 = t / TPR;
+    const int co = n0 + c4 * 4;
+    const unsigned bound_bits = __float_as_uint(fmaf(__uint_as_float(amax_read(p.amax, t)), p.pl_a, p.pl_b));  // every lane: shuffles inside
+    const float so = f16_plane_scales(bound_bits).x;
+    if (co < p.Cout) {
+      const float4 sc = p.scale ? *reinterpret_cast<const float4*>(p.scale + co) : make_float4(1.f, 1.f, 1.f, 1.f);
+      const float4 bi = p.bias ? *reinterpret_cast<const float4*>(p.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+      char* const obase = reinterpret_cast<char*>(p.out) + (size_t)(co >> 5) * 128 + (size_t)(co & 31) * 2;
+#pragma unroll 4
+      for (int i = 0; i < EpiRows<BM, BN, NT>::NR; ++i) {
+        const int row = r0 + RPP * i;
+        const int m = m0 + row;
+        if (row >= BM || m >= p.M) break;
+        float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + c4 * 4);
+        v.x = apply_act(v.x * sc.x + bi.x, p.act);
+        v.y = apply_act(v.y * sc.y + bi.y, p.act);
+        v.z = apply_act(v.z * sc.z + bi.z, p.act);
+        v.w = apply_act(v.w * sc.w + bi.w, p.act);
+        ep_f2 a = {v.x * so, v.y * so}, b = {v.z * so, v.w * so};
+        const ep_h2 ha = __builtin_convertvector(a, ep_h2), hb = __builtin_convertvector(b, ep_h2);
+        a -= __builtin_convertvector(ha, ep_f2);  // exact
+        b -= __builtin_convertvector(hb, ep_f2);
+        const ep_h2 la = __builtin_convertvector(a, ep_h2), lb = __builtin_convertvector(b, ep_h2);
+        char* o = obase + (size_t)m * p.out_ld * 4;
+        *reinterpret_cast<uint2*>(o) = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
+        *reinterpret_cast<uint2*>(o + 64) = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
+      }
+    }
+    if (p.amax_out) amax_commit(p.amax_out, bound_bits, t);
+    return;
+  }
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   constexpr int TPR = BN / 4;        // threads per output row
   constexpr int RPP = NT / TPR;     // rows per pass
@@ -222,7 +282,7 @@ __device__ __forceinline__ void epilogue_tile(const ConvK& p, const float* Cs, i
 // ---- epilogue straight from the accumulators (EPI_STORE): lane (li, lh) of a wave holds, for MFMA tile (a, b), register
 // r = D[row 32a + (r & 3) + 8 (r >> 2) + 4 lh][column 32b + li]; a store instruction therefore writes two output rows,
 // 128 contiguous bytes each.  Same arithmetic per element as epilogue_tile.  One instantiation per activation (the
-// activation switch sits outside the unrolled element loops: the erff expansion appears once per element, not five
+// activation switch sits outside the unrolled element loops: the GELU expansion appears once per element, not five
 // functions per element).
 template <int ACT, int TM, int TN>
 __device__ __forceinline__ void epilogue_direct_act(const ConvK& p, const f32x16 (&acc)[TM][TN], int mw, int nw, int li, int lh) {
@@ -278,5 +338,9 @@ std::pair<hipEvent_t, hipEvent_t>* conv_prof_open(hipStream_t s, const ConvK& k,
 // split-operand path (ymk_conv_split.hip): true when the launch was taken.  code 2 / 3: bf16 planes (3 / 6 MFMAs per
 // product tile), SPLIT_F16X2: two scaled fp16 planes (3 MFMAs)
 bool conv2d_split(hipStream_t s, ConvK& k, const ConvW& w, int code, SplitCtx* ctx);
+// A-stationary short-K 1 x 1 kernel (ymk_conv_astat.hip): false = this launch is not one it runs
+bool conv2d_f16_astat_can(const ConvK& k, size_t w_bytes);
+bool conv2d_f16_astat(hipStream_t s, ConvK& k, const void* planes, size_t w_bytes);
+int conv2d_f16_astat_columns(const ConvK& k);
 
 }  // namespace ymk

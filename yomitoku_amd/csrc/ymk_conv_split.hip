@@ -70,15 +70,7 @@ __device__ __forceinline__ void split4(const f32x4 v, float sa, uint2* planes) {
   }
 }
 
-// max|x| bits -> {sa, 1 / sa}, sa the power of two that puts max|x| into [2^14, 2^15); both kept normal whatever the input
-__device__ __forceinline__ float2 f16_scales(unsigned amax_bits) {
-  int e = (int)(amax_bits >> 23);  // biased exponent, 0 .. 255
-  e = e < 27 ? 27 : (e > 227 ? 227 : e);
-  float2 r;
-  r.x = __uint_as_float((unsigned)(268 - e) << 23);  // 2^(14 - (e - 127))
-  r.y = __uint_as_float((unsigned)(e - 14) << 23);
-  return r;
-}
+__device__ __forceinline__ float2 f16_scales(unsigned amax_bits) { return f16_plane_scales(amax_bits); }  // ymk_conv_kernel.h
 
 // blocks of this shape a CU's 160 KB of LDS holds (at most 2 are asked for) -> minimum waves per SIMD for the register allocator
 template <int BM, int BN, int WM, int WN, int NS, int KS>
@@ -90,7 +82,8 @@ constexpr int bf16_waves_per_simd() {
 
 // KS: 32-k tiles per LDS stage (a stage = one barrier interval: KS = 2 halves the barriers per k and doubles the MFMAs a wave
 // issues between them); PF: stages the global loads run ahead of the MFMAs (2 = two register sets, as conv_igemm's PF).
-template <int BM, int BN, int WM, int WN, int NS, int KS, int PF, int FMT>
+// OPL (fp16 form): the epilogue writes fp16 planes (epilogue_tile<.., PL>, Tensor::planes).
+template <int BM, int BN, int WM, int WN, int NS, int KS, int PF, int FMT, bool OPL = false>
 __global__ __launch_bounds__(64 * WM * WN, (bf16_waves_per_simd<BM, BN, WM, WN, NS, KS>())) void conv_igemm_split(ConvK p, const uint4* __restrict__ wsplit) {
   typedef typename Half<FMT>::v8 h8;
   static_assert(PF >= 1 && PF <= 3, "prefetch: 1 = one stage ahead, 2 = two ahead, 3 = two ahead with the LDS stores threaded through the MFMAs");
@@ -396,7 +389,7 @@ __global__ __launch_bounds__(64 * WM * WN, (bf16_waves_per_simd<BM, BN, WM, WN, 
           }
     }
     __syncthreads();
-    epilogue_tile<EROWS, BN, NT>(p, Cs, m0 + e0, n0, t);
+    epilogue_tile<EROWS, BN, NT, false, 4, OPL>(p, Cs, m0 + e0, n0, t);
   }
 }
 
@@ -598,10 +591,39 @@ SplitCtx* SplitCtxOwner::get() {
 }
 SplitCtxOwner::~SplitCtxOwner() { delete p_; }
 
-template <int FMT, int BM, int BN, int WM, int WN, int NS, int KS = 1, int PF = 1>
+// amax_check mode: the launch's record against a pass over its input (counters above).  Level 2 also waits for the answer
+// and names the launch whose record lies below the truth on stderr (a debugging aid: it serialises the stream).
+static void amax_verify(hipStream_t s, const ConvK& k, SplitCtx* ctx) {
+  if (!g_amax_counters) {
+    YMK_HIP(hipMalloc((void**)&g_amax_counters, 4 * sizeof(unsigned long long)));
+    YMK_HIP(hipMemset(g_amax_counters, 0, 4 * sizeof(unsigned long long)));
+  }
+  const unsigned* truth = ctx->absmax(s, k);
+  hipLaunchKernelGGL(k_amax_verify, dim3(1), dim3(64), 0, s, k.amax, truth, g_amax_counters);
+  if (g_amax_check.load(std::memory_order_relaxed) >= 2) {
+    unsigned got[AMAX_REC_WORDS], want[AMAX_REC_WORDS];
+    YMK_HIP(hipStreamSynchronize(s));
+    YMK_HIP(hipMemcpy(got, k.amax, sizeof(got), hipMemcpyDeviceToHost));
+    YMK_HIP(hipMemcpy(want, truth, sizeof(want), hipMemcpyDeviceToHost));
+    unsigned g = 0, w = 0;
+    for (int i = 0; i < AMAX_LINES; ++i) {
+      g = std::max(g, got[i * AMAX_LINE_WORDS]);
+      w = std::max(w, want[i * AMAX_LINE_WORDS]);
+    }
+    if (g < w) {
+      float gf, wf;
+      std::memcpy(&gf, &g, 4);
+      std::memcpy(&wf, &w, 4);
+      std::fprintf(stderr, "amax_check: record BELOW the truth: %g < %g  M=%d C=%d ld=%d Cout=%d k=%dx%d stride=%d H=%d W=%d act=%d res=%d rec=%p in=%p\n", gf, wf,
+                   k.M, k.C, k.in_ld, k.Cout, k.KH, k.KW, k.stride, k.H, k.W, k.act, k.res ? 1 : 0, (const void*)k.amax, (const void*)k.in);
+    }
+  }
+}
+
+template <int FMT, int BM, int BN, int WM, int WN, int NS, int KS = 1, int PF = 1, bool OPL = false>
 static void launch_split(hipStream_t s, ConvK& k, const void* wsplit, SplitCtx* ctx = nullptr) {
   if (KS > 1 && (k.Kpad >> 5) % KS != 0) {  // a stage holds KS whole K tiles: odd tile counts take the one-tile form
-    launch_split<FMT, BM, BN, WM, WN, NS, 1, PF>(s, k, wsplit, ctx);
+    launch_split<FMT, BM, BN, WM, WN, NS, 1, PF, OPL>(s, k, wsplit, ctx);
     return;
   }
   const int mt = (k.M + BM - 1) / BM, nt = (k.Cout + BN - 1) / BN;
@@ -610,13 +632,9 @@ static void launch_split(hipStream_t s, ConvK& k, const void* wsplit, SplitCtx* 
   if (FMT == 1 && k.amax == nullptr) {
     k.amax = ctx->absmax(s, k);  // no record from the producer: a pass over the input (inside the timed span)
   } else if (FMT == 1 && g_amax_check.load(std::memory_order_relaxed)) {
-    if (!g_amax_counters) {
-      YMK_HIP(hipMalloc((void**)&g_amax_counters, 4 * sizeof(unsigned long long)));
-      YMK_HIP(hipMemset(g_amax_counters, 0, 4 * sizeof(unsigned long long)));
-    }
-    hipLaunchKernelGGL(k_amax_verify, dim3(1), dim3(64), 0, s, k.amax, ctx->absmax(s, k), g_amax_counters);
+    amax_verify(s, k, ctx);
   }
-  hipLaunchKernelGGL((conv_igemm_split<BM, BN, WM, WN, NS, KS, PF, FMT>), dim3(mt * nt), dim3(64 * WM * WN), 0, s, k,
+  hipLaunchKernelGGL((conv_igemm_split<BM, BN, WM, WN, NS, KS, PF, FMT, OPL>), dim3(mt * nt), dim3(64 * WM * WN), 0, s, k,
                      reinterpret_cast<const uint4*>(wsplit));
   if (e) YMK_HIP(hipEventRecord(e->second, s));
 }
@@ -631,9 +649,28 @@ static void launch_split(hipStream_t s, ConvK& k, const void* wsplit, SplitCtx* 
 //   12 / 13 / 14 = 128 x 128 x 16 waves / 256 x 128 x 16 waves / 128 x 128 x 8 waves with the stores threaded through the MFMAs
 // (bf16 only; the fp16 form keeps the shapes that won there: 0 / 3 = 128 x 128 x 16 waves, 1 = 128 x 64, 2 = 256 x 128, 11)
 static std::atomic<int> g_split_tile{0};
+// ymk_debug_option("astat", v): 1 (default) = the short-K pointwise layers the A-stationary kernel measured ahead on take it;
+// 0 = none does (the round-4 routing, for A/B runs); "conv_split_tile" 30 forces it for every launch it can run
+static std::atomic<int> g_astat{1};
+// ymk_debug_option("act_planes", v): 1 (default) = the tensor between a bottleneck's 1 x 1 reduction and its 3 x 3 convolution
+// lives in HBM as the two fp16 planes the 3 x 3 multiplies with (written by the reduction's epilogue under a bound, read by
+// LDS-DMA without any conversion: ymk_conv_dma.hip APL) wherever conv_planes_pair_ok allows; 0 = fp32 activations everywhere
+static std::atomic<int> g_act_planes{1};
+// launch counters since the process started (ymk_stat; tests assert that a route was really taken)
+static std::atomic<long long> g_n_astat{0}, g_n_ln_fused{0}, g_n_planes_read{0}, g_n_planes_written{0};
+bool conv_split_stat(const std::string& key, long long* value) {
+  if (key == "astat_launches") *value = g_n_astat.load();
+  else if (key == "ln_fused_launches") *value = g_n_ln_fused.load();
+  else if (key == "planes_read_launches") *value = g_n_planes_read.load();
+  else if (key == "planes_written_launches") *value = g_n_planes_written.load();
+  else return false;
+  return true;
+}
 bool conv_split_debug_option(const std::string& key, int value) {
   if (key == "conv_split_tile") g_split_tile = value;
   else if (key == "amax_check") g_amax_check = value;
+  else if (key == "astat") g_astat = value;
+  else if (key == "act_planes") g_act_planes = value;
   else return false;
   return true;
 }
@@ -666,6 +703,11 @@ static void dispatch_bf16(hipStream_t s, ConvK& k, const void* ws, int tile, boo
 }
 
 static void dispatch_f16(hipStream_t s, ConvK& k, const void* ws, int tile, bool narrow, SplitCtx* ctx) {
+  if (k.out_planes) {  // plane-writing epilogues exist for the two shapes the automatic choice uses
+    if (narrow) launch_split<1, 128, 64, 4, 2, 2, 1, 1, true>(s, k, ws, ctx);
+    else launch_split<1, 128, 128, 4, 4, 2, 1, 1, true>(s, k, ws, ctx);
+    return;
+  }
   if (narrow) {
     launch_split<1, 128, 64, 4, 2, 2>(s, k, ws, ctx);
     return;
@@ -683,46 +725,117 @@ static void dispatch_f16(hipStream_t s, ConvK& k, const void* ws, int tile, bool
 
 bool conv2d_f16_dma(hipStream_t s, ConvK& k, const void* wsplit, size_t w_bytes, bool narrow, int rows);  // ymk_conv_dma.hip
 
-bool conv2d_split(hipStream_t s, ConvK& k, const ConvW& w, int code, SplitCtx* ctx) {
-  if (w.mode != 0 || ctx == nullptr || (code != 2 && code != 3 && code != SPLIT_F16X2)) return false;  // 4-channel stems keep the fp32 kernel
-  // launches that fill the chip: >= 256 tiles of 128 x 128, or - Cout > 64 - of 128 x 64 (a batch-2 RT-DETRv2 stage, the
-  // greedy loop's vocabulary head at a few hundred rows); the rest keeps the fp32 paths (split-K / small tiles)
-  const bool rowmax = k.epi == EPI_ROWMAX;  // (max, column) per 64-column tile: the 128 x 64 tile
-  const long mt128 = (k.M + 127) / 128;
-  const long blocks128 = mt128 * ((w.cout + 127) / 128), blocks64 = mt128 * ((w.cout + 63) / 64);
+// ---- which kernel an fp16-split launch runs on: ONE rule, asked by conv2d_split for the launch itself and by
+// conv_planes_pair_ok (ymk_conv.hip) for a producer / consumer pair before either is launched
+//   none: not a launch that fills the chip (>= 256 tiles of 128 x 128, or - few - of 128 x 64): the exact fp32 paths keep it
+//   astat (ymk_conv_astat.hip): pointwise layers with K <= 256 and more than 64 output channels - the ViT blocks' qkv / proj /
+//     fc1 (K = 192), the ResNet expands 64 -> 256 / 128 -> 512 / 256 -> 1024 with their residual, the decoders' 256 -> 256
+//     projections: A rows are fetched and cut into planes once per 128 rows instead of once per tile
+//     (profiles/r04_conv_astat_candidate_timing.jsonl: qkv 379 us against 508, 64 -> 256 + residual 424 against 485).  A
+//     launch with a LayerNorm to fuse has no other kernel to go to: taken there or refused.  It neither reads nor writes planes.
+//   dma (ymk_conv_dma.hip; 128-row tiles, two or three blocks per CU) where it measured ahead of the register-staged kernel
+//     (profiles/r04_conv_sweep_f16_lds_dma.txt): every k x k layer (+2..17 %), long-K 1 x 1 reductions (+3..7 %) and the
+//     64-column 1 x 1 layers (+1..6 %)
+//   staged (conv_igemm_split): the rest - wide 1 x 1 layers with K > 256 (the ViT fc2, the 512 -> 128 reductions)
+enum SplitRoute : int { ROUTE_NONE = 0, ROUTE_ASTAT = 1, ROUTE_DMA = 2, ROUTE_STAGED = 3 };
+struct RouteQuery {
+  long M;
+  int cout, kpad, taps;
+  bool rowmax, row_group, astat_can, ln, planes_io;
+};
+static SplitRoute route_f16(const RouteQuery& q, int& tile, bool& narrow) {
+  const long mt128 = (q.M + 127) / 128;
+  const long blocks128 = mt128 * ((q.cout + 127) / 128), blocks64 = mt128 * ((q.cout + 63) / 64);
+  tile = g_split_tile.load(std::memory_order_relaxed);
+  const bool auto_tile = tile == 0;
+  const bool astat_forced = tile == 30;  // tests: the A-stationary kernel at any size it can run
   bool few = false;
-  if (blocks128 < 256) {
-    if (blocks64 < 256) return false;
+  if (blocks128 < 256 && !astat_forced) {
+    if (blocks64 < 256) return ROUTE_NONE;
     few = true;
   }
+  if (tile == 0) tile = 3;
+  narrow = q.cout <= 64 || tile == 1 || q.rowmax || few;
+  if (!q.rowmax && q.astat_can && !q.planes_io &&
+      (astat_forced || q.ln || (auto_tile && g_astat.load(std::memory_order_relaxed) != 0 && q.cout > 64 && !few)))
+    return ROUTE_ASTAT;
+  if (q.ln) return ROUTE_NONE;
+  if (tile == 30) {
+    if (blocks128 < 256) return ROUTE_NONE;  // forced, but not a launch the kernel runs: as without the option
+    tile = 3;
+  }
+  const bool dma_shape = q.taps > 1 || (q.kpad >= 1024 && q.cout <= 512) || q.cout <= 64;
+  const bool dma_fills = blocks128 >= 256 || (q.cout <= 64 && mt128 >= 256);
+  if (!q.rowmax && !q.row_group && (tile == 20 || tile == 21 || (auto_tile && dma_shape && dma_fills))) return ROUTE_DMA;
+  if (tile == 20 || tile == 21) tile = 3;
+  return ROUTE_STAGED;
+}
+
+// for conv_planes_pair_ok: the route of a plain-store fp16-split launch that reads or writes planes; `auto_tile`: no tile is forced
+int conv_split_route_with_planes(long M, int cout, int kpad, int taps, bool* auto_tile) {
+  int tile = 0;
+  bool narrow = false;
+  *auto_tile = g_split_tile.load(std::memory_order_relaxed) == 0 && g_act_planes.load(std::memory_order_relaxed) != 0;
+  return (int)route_f16(RouteQuery{M, cout, kpad, taps, false, false, false, false, true}, tile, narrow);
+}
+
+bool conv2d_split(hipStream_t s, ConvK& k, const ConvW& w, int code, SplitCtx* ctx) {
+  if (w.mode != 0 || ctx == nullptr || (code != 2 && code != 3 && code != SPLIT_F16X2)) return false;  // 4-channel stems keep the fp32 kernel
+  const bool planes_io = k.in_planes != 0 || k.out_planes != 0;
+  if ((k.ln_g != nullptr || planes_io) && code != SPLIT_F16X2) return false;  // fused LayerNorm / planes in HBM: fp16 form only
+  const bool rowmax = k.epi == EPI_ROWMAX;  // (max, column) per 64-column tile: the 128 x 64 tile
+  const size_t w_bytes_f16 = (size_t)((w.cout + 255) / 256 * 256) * w.kpad * 2 * 2;
+  int tile = 0;
+  bool narrow = false;
+  SplitRoute route = ROUTE_STAGED;
+  if (code == SPLIT_F16X2) {
+    route = route_f16(RouteQuery{k.M, w.cout, k.Kpad, k.KH * k.KW, rowmax, k.row_group != nullptr, conv2d_f16_astat_can(k, w_bytes_f16),
+                                 k.ln_g != nullptr, planes_io}, tile, narrow);
+  } else {  // bf16 evaluation forms: the register-staged kernel, for launches that fill the chip
+    const long mt128 = (k.M + 127) / 128;
+    const long blocks128 = mt128 * ((w.cout + 127) / 128), blocks64 = mt128 * ((w.cout + 63) / 64);
+    tile = g_split_tile.load(std::memory_order_relaxed);
+    if (tile == 0) tile = code == 3 ? 2 : 3;
+    if (tile == 20 || tile == 21 || tile == 30) tile = 3;
+    if (blocks128 < 256 && blocks64 < 256) return false;
+    narrow = w.cout <= 64 || tile == 1 || rowmax || blocks128 < 256;
+  }
+  if (route == ROUTE_NONE) return false;
+  YMK_CHECK(!k.in_planes || (route == ROUTE_DMA && tile != 20), "a tensor stored as fp16 planes reached a kernel that cannot read it");
+  YMK_CHECK(!k.out_planes || (route == ROUTE_DMA && tile != 20) || (route == ROUTE_STAGED && (narrow || tile == 3)),
+            "fp16 planes asked of a kernel that cannot write them");
   const SplitCtx::Panels& pn = ctx->panels(s, w, code);
-  int tile = g_split_tile.load(std::memory_order_relaxed);
-  const bool auto_tile = tile == 0;
-  if (tile == 0) tile = code == 3 ? 2 : 3;
-  const bool narrow = w.cout <= 64 || tile == 1 || rowmax || few;
-  // the LDS-DMA form (ymk_conv_dma.hip; 128-row tiles, two or three blocks per CU) where it measured ahead of the
-  // register-staged kernel (profiles/r04_conv_sweep_f16_lds_dma.txt): every k x k layer (+2..17 %: the 3 x 3 layers of all
-  // three backbones and the decoders), long-K 1 x 1 reductions (+3..7 %) and the 64-column 1 x 1 layers (+1..6 %).  Wide 1 x 1
-  // layers with short K - the expands with their residual reads, the ViT GEMMs - lose 10-35 % there (their time is the
-  // epilogue's memory traffic, which sixteen-wave blocks keep more of in flight) and stay on the register-staged kernel.
-  const int taps = k.KH * k.KW;
-  const bool dma_shape = taps > 1 || (k.Kpad >= 1024 && w.cout <= 512) || w.cout <= 64;
-  const bool dma_fills = mt128 * ((w.cout + 127) / 128) >= 256 || (w.cout <= 64 && mt128 >= 256);
-  if (code == SPLIT_F16X2 && !rowmax && k.row_group == nullptr && (tile == 20 || tile == 21 || (auto_tile && dma_shape && dma_fills))) {
+  if (k.in_planes) ++g_n_planes_read;
+  if (k.out_planes) ++g_n_planes_written;
+  if (route == ROUTE_ASTAT) {
+    k.scale = pn.scale;
+    const int bn = conv2d_f16_astat_columns(k);
+    auto* e = conv_prof_open(s, k, 128, bn, ((k.M + 127) / 128) * ((k.Cout + bn - 1) / bn), 162);
+    if (k.amax == nullptr) k.amax = ctx->absmax(s, k);
+    else if (g_amax_check.load(std::memory_order_relaxed) && k.ln_g == nullptr) amax_verify(s, k, ctx);
+    const bool taken = conv2d_f16_astat(s, k, pn.planes, w_bytes_f16);
+    if (e) YMK_HIP(hipEventRecord(e->second, s));
+    YMK_HIP(hipGetLastError());
+    YMK_CHECK(taken, "conv_f16_astat refused a launch it had accepted");
+    ++g_n_astat;
+    if (k.ln_g != nullptr) ++g_n_ln_fused;
+    return true;
+  }
+  if (route == ROUTE_DMA) {
     k.scale = pn.scale;
     const bool nar = w.cout <= 64;
     const int rows = tile == 20 ? 256 : 128;
     k.ntiles_n = (k.Cout + (nar ? 64 : 128) - 1) / (nar ? 64 : 128);
     auto* e = conv_prof_open(s, k, rows, nar ? 64 : 128, ((k.M + rows - 1) / rows) * k.ntiles_n, 161);
+    YMK_CHECK(!k.in_planes || k.amax != nullptr, "a tensor of fp16 planes without the record that holds its scale");
     if (k.amax == nullptr) k.amax = ctx->absmax(s, k);
-    const size_t w_bytes = (size_t)((w.cout + 255) / 256 * 256) * w.kpad * 2 * 2;
-    const bool taken = conv2d_f16_dma(s, k, pn.planes, w_bytes, nar, rows);
+    else if (g_amax_check.load(std::memory_order_relaxed) && !k.in_planes) amax_verify(s, k, ctx);
+    const bool taken = conv2d_f16_dma(s, k, pn.planes, w_bytes_f16, nar, rows);
     if (e) YMK_HIP(hipEventRecord(e->second, s));
     YMK_HIP(hipGetLastError());
     YMK_CHECK(taken, "conv_f16_dma refused a launch");
     return true;
   }
-  if (tile == 20 || tile == 21) tile = 3;
   if (code == SPLIT_F16X2) {
     k.scale = pn.scale;
     dispatch_f16(s, k, pn.planes, tile, narrow, ctx);

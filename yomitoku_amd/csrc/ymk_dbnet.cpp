@@ -141,7 +141,7 @@ class DBNetModel : public Model {
  private:
   // `rec`: the max|x| record the launch folds its outputs into (ymk_common.h); by default a fresh one for a fresh output
   Tensor conv(hipStream_t s, const Tensor& in, const ConvW& w, int stride, int pad, int dil, int act,
-              const Tensor* res = nullptr, const Tensor* into = nullptr, unsigned* rec = nullptr) {
+              const Tensor* res = nullptr, const Tensor* into = nullptr, unsigned* rec = nullptr, bool out_planes = false) {
     Tensor out;
     if (into) {
       out = *into;
@@ -151,6 +151,7 @@ class DBNetModel : public Model {
       out.amax = arena.amax_next();
     }
     if (rec) out.amax = rec;
+    out.planes = out_planes && out.amax != nullptr;
     if (arena.dry_run) return out;
     ConvArgs a;
     a.stride = stride;
@@ -158,12 +159,20 @@ class DBNetModel : public Model {
     a.dil = dil;
     a.act = act;
     a.res = res;
+    a.out_planes = out.planes;
     conv2d(s, in, w, a, out);
     return out;
   }
 
   Tensor bottleneck(hipStream_t s, const Tensor& x, const Bottleneck& b) {
-    Tensor t1 = conv(s, x, b.c1, 1, 0, 1, ACT_RELU);
+    // the tensor between the 1 x 1 reduction and the 3 x 3 has ONE reader: where both launches run fp16-split kernels that
+    // support it, it lives in HBM as the two fp16 planes the 3 x 3 multiplies with (Tensor::planes, conv_planes_pair_ok)
+    ConvArgs a1, a2;
+    a1.act = a2.act = ACT_RELU;
+    a2.stride = b.stride;
+    a2.pad = a2.dil = b.dil;
+    const bool planes = conv_planes_pair_ok(x, b.c1, a1, b.c2, a2);
+    Tensor t1 = conv(s, x, b.c1, 1, 0, 1, ACT_RELU, nullptr, nullptr, nullptr, planes);
     Tensor t2 = conv(s, t1, b.c2, b.stride, b.dil, b.dil, ACT_RELU);
     Tensor idn = x;
     if (b.has_down) idn = conv(s, x, b.down, b.stride, 0, 1, ACT_NONE);

@@ -103,7 +103,7 @@ __device__ void matvec(const float* __restrict__ Wt, const float* __restrict__ b
     float a = 0.f;
     for (int gg = 0; gg < G; ++gg) a += part[(size_t)gg * N + o];
     a += bias[o];
-    if (ACT == ACT_GELU) a = 0.5f * a * (1.f + erff(a * 0.70710678118654752440f));
+    if (ACT == ACT_GELU) a = gelu_f32(a);
     if (res) a += res[o];
     y[o] = a;
   }
@@ -288,7 +288,7 @@ __device__ void matvec_rows(const float* __restrict__ Wt, const float* __restric
     float a = 0.f;
     for (int gg = 0; gg < G; ++gg) a += pr[(size_t)gg * N + oo];
     a += bias[oo];
-    if (ACT == ACT_GELU) a = 0.5f * a * (1.f + erff(a * 0.70710678118654752440f));
+    if (ACT == ACT_GELU) a = gelu_f32(a);
     if (res) a += res[r * rs + oo];
     y[r * ys + oo] = a;
   }

@@ -28,9 +28,12 @@ static std::atomic<int> g_parseq_unfused{0};  // ymk_debug_option("parseq_unfuse
 static bool parseq_unfused() { return g_parseq_unfused.load(std::memory_order_relaxed) != 0; }
 static std::atomic<int> g_parseq_no_rowmax{0};  // ymk_debug_option("parseq_no_rowmax", 1): keep the AR logits (A/B, tests)
 static bool parseq_no_rowmax() { return g_parseq_no_rowmax.load(std::memory_order_relaxed) != 0; }
+static std::atomic<int> g_parseq_no_ln_fusion{0};  // ymk_debug_option("parseq_no_ln_fusion", 1): LayerNorm as its own launch (A/B, tests)
+static bool parseq_no_ln_fusion() { return g_parseq_no_ln_fusion.load(std::memory_order_relaxed) != 0; }
 bool parseq_debug_option(const std::string& key, int value) {
   if (key == "parseq_unfused") g_parseq_unfused = value;
   else if (key == "parseq_no_rowmax") g_parseq_no_rowmax = value;
+  else if (key == "parseq_no_ln_fusion") g_parseq_no_ln_fusion = value;
   else return false;
   return true;
 }
@@ -267,6 +270,16 @@ class ParseqModel : public Model {
     layernorm(s, x, D, 0, g, b, eps, y, D, M, D);
   }
 
+  // out = act(LayerNorm(x) . W^T + bias): one launch with the LayerNorm folded into the operand load where the A-stationary
+  // fp16-split kernel runs the layer (gemm_ln_fused: chip-filling launches at widths 128 / 192), else LayerNorm into
+  // `tmp` and the GEMM on it - the same values either way up to the order of the K sums
+  void ln_gemm(hipStream_t s, const float* x, const float* g, const float* b, float eps, float* tmp, int M, int D, const ConvW& w, int act,
+               float* out, int out_ld, const unsigned* ln_rec, unsigned* out_rec) {
+    if (!parseq_no_ln_fusion() && gemm_ln_fused(s, x, M, D, D, g, b, eps, w, act, nullptr, 0, out, out_ld, ln_rec, out_rec)) return;
+    ln(s, x, g, b, eps, tmp, M, D);
+    gemm(s, tmp, M, D, D, w, act, nullptr, 0, out, out_ld, nullptr, nullptr, EPI_STORE, ln_rec, out_rec);
+  }
+
   // query-stream tail shared by the AR step and the refinement pass:
   //   q (in/out, [M][Dd]) already holds query + self-attention; adds cross attention and the FFN,
   //   then decoder.norm + head -> out rows (ld_out floats apart)
@@ -406,13 +419,11 @@ class ParseqModel : public Model {
       // records of the GEMM inputs: static for the LayerNorm outputs; the q|k|v GEMM leaves one that also bounds the attention
       // output (a convex combination of V rows); fc1 leaves one for the hidden state
       unsigned *qkv_rec = arena.amax_next(), *h_rec = arena.amax_next();
-      ln(s, xs, b.ln1g, b.ln1b, 1e-6f, y, M, D);
-      gemm(s, y, M, D, D, b.qkv, ACT_NONE, nullptr, 0, qkv, 3 * D, nullptr, nullptr, EPI_STORE, b.ln1_rec, qkv_rec);
+      ln_gemm(s, xs, b.ln1g, b.ln1b, 1e-6f, y, M, D, b.qkv, ACT_NONE, qkv, 3 * D, b.ln1_rec, qkv_rec);
       flash_attention(s, qkv, qkv + D, qkv + 2 * D, att, B, eh_, L, L, hd, 3 * D, 3 * D, 3 * D, D, (long)L * 3 * D,
                       (long)L * 3 * D, (long)L * 3 * D, (long)L * D, scale, enc_t, qkv_rec, qkv_rec, qkv_rec);
       gemm(s, att, M, D, D, b.proj, ACT_NONE, xs, D, xs, D, nullptr, nullptr, EPI_STORE, qkv_rec);
-      ln(s, xs, b.ln2g, b.ln2b, 1e-6f, y, M, D);
-      gemm(s, y, M, D, D, b.fc1, ACT_GELU, nullptr, 0, hbuf, b.fc1.cout, nullptr, nullptr, EPI_STORE, b.ln2_rec, h_rec);
+      ln_gemm(s, xs, b.ln2g, b.ln2b, 1e-6f, y, M, D, b.fc1, ACT_GELU, hbuf, b.fc1.cout, b.ln2_rec, h_rec);
       gemm(s, hbuf, M, b.fc1.cout, b.fc1.cout, b.fc2, ACT_NONE, xs, D, xs, D, nullptr, nullptr, EPI_STORE, h_rec);
     }
     ln(s, xs, enc_ng_, enc_nb_, 1e-6f, mem, M, D);

@@ -230,11 +230,12 @@ class RtdetrModel : public Model {
   bool dry() const { return arena.dry_run; }
 
   Tensor conv(hipStream_t s, const Tensor& in, const ConvW& w, int stride, int pad, int act, const Tensor* res = nullptr,
-              const Tensor* into = nullptr, bool res_post = false) {
+              const Tensor* into = nullptr, bool res_post = false, bool out_planes = false) {
     Tensor out = into ? *into
                       : arena.tensor(in.n, conv_out_dim(in.h, w.kh, stride, pad, 1), conv_out_dim(in.w, w.kw, stride, pad, 1),
                                      w.cout);
     if (!into) out.amax = arena.amax_next();  // a fresh output gets a max|x| record (ymk_common.h); a slice keeps its buffer's
+    out.planes = out_planes && !into && out.amax != nullptr;
     if (dry()) return out;
     ConvArgs a;
     a.stride = stride;
@@ -242,6 +243,7 @@ class RtdetrModel : public Model {
     a.act = act;
     a.res = res;
     a.res_post = res_post;
+    a.out_planes = out.planes;
     conv2d(s, in, w, a, out);
     return out;
   }
@@ -285,7 +287,13 @@ class RtdetrModel : public Model {
     Tensor cur = p;
     for (int st = 0; st < 4; ++st) {
       for (const VdBlock& k : stages_[st]) {
-        Tensor t1 = conv(s, cur, k.a, 1, 0, ACT_RELU);
+        // branch2a's output has one reader, the 3 x 3 branch2b: fp16 planes in HBM where both launches allow (Tensor::planes)
+        ConvArgs pa, pb;
+        pa.act = pb.act = ACT_RELU;
+        pb.stride = k.stride;
+        pb.pad = 1;
+        const bool planes = conv_planes_pair_ok(cur, k.a, pa, k.b, pb);
+        Tensor t1 = conv(s, cur, k.a, 1, 0, ACT_RELU, nullptr, nullptr, false, planes);
         Tensor t2 = conv(s, t1, k.b, k.stride, 1, ACT_RELU);
         Tensor sh = cur;
         if (k.has_short) {

@@ -90,6 +90,20 @@ const HostTensor& WeightStore::get(const std::string& name) const {
 }
 
 // ---------------------------------------------------------------- packing helpers
+// ConvW::pl_a / pl_b from the OIHW weights and the folded scale / bias (1 / 0 where absent); a little head room for the
+// rounding of the fp32 sums and of the bound's own arithmetic
+static void plane_bound(ConvW& c, const float* oihw, size_t per_out, const std::vector<float>& scale, const std::vector<float>& bias) {
+  double a = 0.0, b = 0.0;
+  for (int o = 0; o < c.cout; ++o) {
+    double l1 = 0.0;
+    for (size_t i = 0; i < per_out; ++i) l1 += std::fabs((double)oihw[(size_t)o * per_out + i]);
+    a = std::max(a, l1 * (scale.empty() ? 1.0 : std::fabs((double)scale[o])));
+    if (!bias.empty()) b = std::max(b, std::fabs((double)bias[o]));
+  }
+  c.pl_a = (float)(a * 1.001);
+  c.pl_b = (float)(b * 1.001);
+}
+
 ConvW make_conv(DevicePool& pool, const WeightStore& ws, const std::string& conv_prefix, const std::string& bn_prefix,
                 bool tap4, float bn_eps) {
   const HostTensor& w = ws.get(conv_prefix + ".weight");
@@ -124,8 +138,10 @@ ConvW make_conv(DevicePool& pool, const WeightStore& ws, const std::string& conv
     c.scale = pool.upload(scale);
     c.bias = pool.upload(bias);
   } else if (has_cb) {
-    c.bias = pool.upload(ws.get(conv_prefix + ".bias").data);
+    bias = ws.get(conv_prefix + ".bias").data;
+    c.bias = pool.upload(bias);
   }
+  plane_bound(c, w.data.data(), w.numel() / (size_t)w.dims[0], scale, bias);
   return c;
 }
 
@@ -139,6 +155,7 @@ ConvW make_linear_raw(DevicePool& pool, const float* w_out_in, const float* bias
   pack_conv_weight(w_out_in, out, in, 1, 1, false, panel, c.kpad, c.ctiles);
   c.w = pool.upload(panel);
   if (bias) c.bias = pool.upload(bias, out);
+  plane_bound(c, w_out_in, (size_t)in, {}, bias ? std::vector<float>(bias, bias + out) : std::vector<float>());
   return c;
 }
 
