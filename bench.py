@@ -74,13 +74,11 @@ def split_mode():
 
 
 def kernel_source_sha():
-    """Hash of the convolution kernels' sources: stamps PMC-derived numbers kept under profiles/ (stale once a kernel changes).
-    ymk_conv_astat.hip is not in the list while no model dispatches to it (a candidate behind ymk_op_conv1x1_astat): it joins
-    the list in the commit that routes a layer to it."""
+    """Hash of the convolution kernels' sources: stamps PMC-derived numbers kept under profiles/ (stale once a kernel changes)."""
     import hashlib
 
     h = hashlib.sha256()
-    for name in ("ymk_conv.hip", "ymk_conv_split.hip", "ymk_conv_dma.hip", "ymk_conv_kernel.h"):
+    for name in ("ymk_conv.hip", "ymk_conv_split.hip", "ymk_conv_dma.hip", "ymk_conv_astat.hip", "ymk_conv_kernel.h"):
         with open(os.path.join(ROOT, "yomitoku_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -896,7 +894,7 @@ def main():
     roof = None
     leg("roofline: serial pass with per-launch events")
     if rank == 0 and not DRY and not args.no_roofline:
-        kern = ("conv_igemm_split (fp16-split MFMA implicit GEMM: the chip-filling conv / linear launches of the four nets) + conv_igemm / "
+        kern = ("conv_igemm_split / conv_f16_dma / conv_f16_astat (fp16-split MFMA implicit GEMM: the chip-filling conv / linear launches of the four nets) + conv_igemm / "
                 "conv_splitk (exact fp32 MFMA: the stems and the grid-starved launches), max|x| passes included" if split_mode() else
                 "conv_igemm / conv_splitk (fp32 MFMA implicit GEMM: every conv / linear layer of the four nets)")
         if args.workload == "analyzer":
@@ -914,7 +912,7 @@ def main():
         else:
             prof_step, units = step, args.pages
         roof = conv_roofline(lib, prof_step, units, "page", kern)
-        pmc = os.path.join(ROOT, "profiles", f"r04_{args.workload}_pmc_conv_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", f"r05_{args.workload}_pmc_conv_traffic.json")
         if roof is not None and os.path.exists(pmc):
             # HBM bytes per conv launch from the PMC passes of this same serial pass (rocprofv3 cannot run inside bench.py:
             # profiles/README.md has the commands); compare with algorithmic_bytes_per_launch.  The file carries the hash of the
@@ -967,6 +965,8 @@ def main():
                 secondary.update(fn())
             except Exception as exc:  # noqa: BLE001
                 secondary[name] = {"error": f"{type(exc).__name__}: {exc}"}
+            if name == "pages_per_s_exact_fp32":
+                an.close()  # the headline's analyzer is done (its nets rebuild on demand): ~100 GB of workspaces back before the next legs reserve theirs
             torch.cuda.empty_cache()  # a finished leg's page / crop tensors go back to the device before the next one reserves
 
     # ---- CPU baseline leg (rank 0, N=1): oracle chain on the host cores, bounded sample

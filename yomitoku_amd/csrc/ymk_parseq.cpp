@@ -541,6 +541,10 @@ class ParseqModel : public Model {
           S_in = NS;
         }
         refine_prep(s, prev_raw, NS, S_in, bos_, eos_, tok2, kpm, B, (it == 0 && ng > 1) ? gid : nullptr, gopen);
+        // rows >= S_in of the context buffer are never written: whatever the workspace held there before (another forward's
+        // activations - or, after the arena grew, any bit pattern, NaNs included) would set the fp16 scale of the K|V
+        // projection below, which takes max|x| over ALL its input rows: zero them (100 MB at wave scale: ~20 us)
+        if (S_in < NS) YMK_HIP(hipMemsetAsync(cn, 0, (size_t)MR * D * sizeof(float), s));
         ctx_embed_ln(s, tok2, NS, 0, S_in, emb_, posq_, ncg_, ncb_, 1e-5f, cn, NS, D, B);
         // project every row of the [B][NS] context buffer; rows >= S_in are stale but never attended (Lk = S_in)
         gemm(s, cn, MR, D, D, sa_kv_, ACT_NONE, nullptr, 0, skv, 2 * D);

@@ -564,12 +564,18 @@ class DocumentAnalyzer:
         pipe.defer_full_gc = bool(defer_full_gc)
         return pipe.serve(sources, with_source=with_source)
 
-    def close(self):
+    def close(self, release_models: bool = True):
+        """Stop the pipeline threads, release the extra recogniser handles and - `release_models` - the device memory of the
+        four nets (weights and the reserved workspaces: tens of GB per analyzer).  The analyzer stays usable: a net rebuilds
+        its handle from the state dict it holds the next time it is called."""
         pipe = getattr(self, "_pipeline", None)
         if pipe is not None:
             pipe.close()
             self._pipeline = None
         self.text_recognizer.close_replicas()
+        if release_models:
+            for module in (self.text_detector, self.text_recognizer, self.layout.layout_parser, self.layout.table_structure_recognizer):
+                module.model.close()
 
     def __call__(self, img):
         self.img = img
