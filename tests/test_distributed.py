@@ -257,3 +257,42 @@ def test_portable_entry_keeps_what_pickles():
     assert portable_entry(e) is e and portable_entry({"a": 1}) == {"a": 1}
     p = portable_entry(_PickyError(3, "page"))
     assert type(p) is RuntimeError and str(p) == "_PickyError: page (3)"
+
+
+def _forms_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import json
+
+    from yomitoku_amd import distributed as yd
+
+    ck = (lambda: {"net": {"w": torch.arange(6, dtype=torch.float32)}}) if rank == 0 else None
+    sources = [10, 11, -1, 13, 14]
+    server = yd.ShardedServer(_StubAnalyzer, ck, backend="gloo", device="cpu")
+    as_json = server.run(sources, gather="json", wave=2)
+    mine = server.run(sources, gather=None, wave=2)
+    server.close()
+    ok = True
+    if rank == 0:
+        decoded = [json.loads(t) for t in as_json]
+        ok = ok and [d[0] if isinstance(d, list) else d for d in decoded] == [10, 11, {"error": "ValueError: bad page -1"}, 13, 14]
+    else:
+        ok = ok and as_json is None
+    ok = ok and [(si, fi) for si, fi, _ in mine] == [(i, 0) for i in range(rank, 5, world)]
+    q.put((rank, bool(ok)))
+
+
+def test_gather_forms_world2():
+    """ShardedServer.run(gather="json"): rank 0 receives text it does not have to rebuild; gather=None: every rank keeps its own
+    triples and no result travels (the per-page path of an 8-GPU node without rank 0 in it)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_forms_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == {0: True, 1: True}

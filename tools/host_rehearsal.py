@@ -173,7 +173,7 @@ def rank_main(rank, world, port, args, q):
     t_serve = time.perf_counter() - t0
     cpu1 = resource.getrusage(resource.RUSAGE_SELF)
     t1 = time.perf_counter()
-    merged = server.gather(local)
+    merged = server.gather(local, form=args.gather) if args.gather != "none" else (server._agree("rehearsal", None) or list(e for _, _, e in local))
     t_gather = time.perf_counter() - t1
     n_local = len(local)
     failed = sum(isinstance(e, BaseException) for _, _, e in local)
@@ -183,11 +183,12 @@ def rank_main(rank, world, port, args, q):
     if rank == 0:
         import pickle
 
-        ok = [e for e in merged if not isinstance(e, BaseException)]
+        ok = [e for _, _, e in local if not isinstance(e, BaseException)]
         row["gathered"] = len(merged)
         row["words_per_page"] = round(float(np.mean([len(e.words) for e in ok])), 1) if ok else None
         row["cells_per_page"] = round(float(np.mean([sum(len(t.cells) for t in e.tables) for e in ok])), 1) if ok else None
         row["pickled_kb_per_page"] = round(len(pickle.dumps(ok[0])) / 1024, 1) if ok else None
+        row["json_kb_per_page"] = round(len(ok[0].model_dump_json()) / 1024, 1) if ok else None
         if failed:
             row["first_failure"] = repr(next(e for _, _, e in local if isinstance(e, BaseException)))
     q.put(row)
@@ -201,6 +202,7 @@ def main():
     ap.add_argument("--wave", type=int, default=16)
     ap.add_argument("--in-flight", type=int, default=4)
     ap.add_argument("--gpu-ms-per-wave", type=float, default=145.0, help="device time of a 16-page wave (110 pages/s)")
+    ap.add_argument("--gather", default="objects", choices=["objects", "json", "none"], help="what travels to rank 0 (ShardedServer.run)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     import socket
@@ -227,7 +229,7 @@ def main():
                 "job_pages_per_s": round(sum(r["pages"] for r in rows) / (max(r["serve_s"] for r in rows) + r0["gather_s"]), 1),
                 "gpu_bound_pages_per_s_per_rank": round(16e3 / args.gpu_ms_per_wave, 1),
                 "cpu_s_per_page": round(float(np.mean([r["cpu_s_per_page"] for r in rows])), 4),
-                "rank0_gather_s": r0["gather_s"], "pickled_kb_per_page": r0.get("pickled_kb_per_page"),
+                "gather": args.gather, "rank0_gather_s": r0["gather_s"], "pickled_kb_per_page": r0.get("pickled_kb_per_page"), "json_kb_per_page": r0.get("json_kb_per_page"),
                 "words_per_page": r0.get("words_per_page"), "cells_per_page": r0.get("cells_per_page"), "budget": r0["budget"],
                 "first_failure": r0.get("first_failure")}
         print(json.dumps(line), flush=True)

@@ -728,11 +728,14 @@ bool conv2d_f16_dma(hipStream_t s, ConvK& k, const void* wsplit, size_t w_bytes,
 // ---- which kernel an fp16-split launch runs on: ONE rule, asked by conv2d_split for the launch itself and by
 // conv_planes_pair_ok (ymk_conv.hip) for a producer / consumer pair before either is launched
 //   none: not a launch that fills the chip (>= 256 tiles of 128 x 128, or - few - of 128 x 64): the exact fp32 paths keep it
-//   astat (ymk_conv_astat.hip): pointwise layers with K <= 256 and more than 64 output channels - the ViT blocks' qkv / proj /
-//     fc1 (K = 192), the ResNet expands 64 -> 256 / 128 -> 512 / 256 -> 1024 with their residual, the decoders' 256 -> 256
-//     projections: A rows are fetched and cut into planes once per 128 rows instead of once per tile
-//     (profiles/r04_conv_astat_candidate_timing.jsonl: qkv 379 us against 508, 64 -> 256 + residual 424 against 485).  A
-//     launch with a LayerNorm to fuse has no other kernel to go to: taken there or refused.  It neither reads nor writes planes.
+//   astat (ymk_conv_astat.hip): pointwise layers with K <= 192 and more than 64 output channels - the ViT blocks' qkv / proj /
+//     fc1 and the final vocabulary head (K = 192), the ResNet expands 64 -> 256 / 128 -> 512 with their residual: A rows are
+//     fetched and cut into planes once per 128 rows instead of once per tile (profiles/r05_conv_astat_timing.jsonl: qkv 371 us
+//     against 514, 64 -> 256 + residual 403 against 475, the 124 634 x 7119 head 1.76 ms against 3.22).  At K = 256 the A
+//     planes leave registers for 64-column blocks only, and the per-layer table of the serial pass
+//     (profiles/r05_conv_two_roof_by_layer*.md) has that form BEHIND the register-staged kernel wherever a residual is read
+//     (256 -> 1024 + residual 2.67 ms against 2.27): K = 256 stays where it was.  A launch with a LayerNorm to fuse has no
+//     other kernel to go to: taken there or refused.  It neither reads nor writes planes.
 //   dma (ymk_conv_dma.hip; 128-row tiles, two or three blocks per CU) where it measured ahead of the register-staged kernel
 //     (profiles/r04_conv_sweep_f16_lds_dma.txt): every k x k layer (+2..17 %), long-K 1 x 1 reductions (+3..7 %) and the
 //     64-column 1 x 1 layers (+1..6 %)
@@ -757,7 +760,7 @@ static SplitRoute route_f16(const RouteQuery& q, int& tile, bool& narrow) {
   if (tile == 0) tile = 3;
   narrow = q.cout <= 64 || tile == 1 || q.rowmax || few;
   if (!q.rowmax && q.astat_can && !q.planes_io &&
-      (astat_forced || q.ln || (auto_tile && g_astat.load(std::memory_order_relaxed) != 0 && q.cout > 64 && !few)))
+      (astat_forced || q.ln || (auto_tile && g_astat.load(std::memory_order_relaxed) != 0 && q.cout > 64 && !few && q.kpad <= 192)))
     return ROUTE_ASTAT;
   if (q.ln) return ROUTE_NONE;
   if (tile == 30) {

@@ -220,6 +220,20 @@ def portable_entry(entry):
     return RuntimeError(_describe(entry))
 
 
+def _entry_json(entry) -> str:
+    """A page's entry as JSON text: the schema's own serialisation, or {"error": "Type: message"} for a failed page."""
+    if isinstance(entry, BaseException):
+        import json
+
+        return json.dumps({"error": _describe(entry)}, ensure_ascii=False)
+    dump = getattr(entry, "model_dump_json", None)
+    if dump is not None:
+        return dump()
+    import json
+
+    return json.dumps(entry, ensure_ascii=False, default=str)
+
+
 class ShardedServer:
     """The page loop of cli/main.py:116-120 over the GPUs of one node - what north_star calls "pages shard naturally (one page
     per GPU) ... with RCCL broadcast of weights": ONE process per GPU (torchrun, or any launcher that sets RANK / LOCAL_RANK /
@@ -297,30 +311,57 @@ class ShardedServer:
         local = self.analyzer.serve([sources[i] for i in mine], with_source=True, **serve_kwargs)
         return [(mine[si], fi, portable_entry(entry)) for si, fi, entry in local]
 
-    def gather(self, local) -> list | None:
+    def gather(self, local, form: str = "objects") -> list | None:
         """Every rank's (source, frame, entry) triples on rank 0, ordered by (source, frame): the entries alone are returned
-        there, None elsewhere.  A host-side gather of Python objects (schemas and exception objects pickle), not a data-path
-        collective.  `local` may also be {"error": text} - a rank whose share failed as a whole: the gather still runs on
-        every rank and then all of them raise ShardedJobError."""
+        there, None elsewhere.  A host-side gather of Python objects, not a data-path collective.  `local` may also be
+        {"error": text} - a rank whose share failed as a whole: the collectives still run on every rank and then all of them
+        raise ShardedJobError.
+
+        form "objects": the entries as they are (schemas and exception objects pickle).  Unpickling a page's schema costs
+        rank 0 ~2 ms (a few thousand pydantic objects), which at 8 GPUs x 110 pages/s is more than one core can do - so
+        "json": every schema travels as its `model_dump_json()` text (0.1 ms per page on the sender, NOTHING to rebuild on rank
+        0; a failed page as {"error": "Type: message"}) - the form for a caller that writes the pages out (cli/main.py:122-137
+        writes one JSON file per page).  Either way the cyclic garbage collector is held back while rank 0 unpickles: a
+        generation-2 pass per few thousand new containers made the 2-rank gather of 512 pages take 6.5 s (tools/host_rehearsal.py)."""
+        if form not in ("objects", "json"):
+            raise ValueError(f"gather form must be 'objects' or 'json', got {form!r}")
+        failed = local.get("error") if isinstance(local, dict) else None
+        if form == "json" and failed is None:
+            local = [(si, fi, _entry_json(entry)) for si, fi, entry in local]
         parts = [local if isinstance(local, dict) else list(local)]
         if self.world > 1:
             # all ranks learn about a failed rank (all_gather of one short string), rank 0 alone receives the results
-            self._agree("serving this rank's share", local.get("error") if isinstance(local, dict) else None)
+            self._agree("serving this rank's share", failed)
             parts = [None] * self.world if self.rank == 0 else None
-            dist.gather_object(list(local), parts, dst=0)
+            import gc
+
+            was_enabled = gc.isenabled()
+            gc.disable()
+            try:
+                dist.gather_object(list(local), parts, dst=0)
+            finally:
+                if was_enabled:
+                    gc.enable()
             if self.rank != 0:
                 return None
-        elif isinstance(local, dict):
-            self._agree("serving this rank's share", local.get("error"))
+        elif failed is not None:
+            self._agree("serving this rank's share", failed)
         merged = sorted((t for part in parts for t in part), key=lambda t: (t[0], t[1]))
         return [entry for _, _, entry in merged]
 
-    def run(self, sources: Sequence, **serve_kwargs) -> list | None:
+    def run(self, sources: Sequence, gather: str | None = "objects", **serve_kwargs) -> list | None:
+        """shard -> serve -> gather.  gather: "objects" (default: rank 0 gets every page's DocumentAnalyzerSchema / exception
+        object, the others None), "json" (rank 0 gets the schemas as JSON text: see `gather`), or None - no result travels at
+        all: EVERY rank returns its own [(global source index, frame index, entry)] and writes / forwards them itself, which is
+        how a node of 8 GPUs keeps rank 0 out of the per-page path; a failed rank still fails the job on every rank."""
         try:
             local = self.serve_local(sources, **serve_kwargs)
         except Exception as exc:  # noqa: BLE001 - the job failed on this rank: say so IN the collective the others will enter
             local = {"error": _describe(exc)}
-        return self.gather(local)
+        if gather is None:
+            self._agree("serving this rank's share", local.get("error") if isinstance(local, dict) else None)
+            return local
+        return self.gather(local, form=gather)
 
     def barrier(self):
         if self.world > 1:
