@@ -218,3 +218,35 @@ def test_reserve_once_falls_back_to_grow_on_demand(monkeypatch):
     net._h, net._reserve_tried_for = 5678, None  # what _build() does: a new handle has no reservation
     assert net.reserve_once(8, 1600, 1280) is True and net.reserve_once(8, 1600, 1280) is True and len(calls) == 2
     net._h = None  # nothing to destroy
+
+
+def test_two_jobs_at_once_restore_the_switch_interval_once_the_last_one_leaves():
+    """the switch interval is process-wide; two pipelines serving concurrently must not restore it out of order
+    (the first one out putting the long interval back under the second, or the short one staying behind for good)."""
+    import sys
+
+    from yomitoku_amd.serving import _switch_interval
+
+    before = sys.getswitchinterval()
+    inside = {}
+    a_in, b_in, a_out = threading.Event(), threading.Event(), threading.Event()
+
+    def job_a():
+        with _switch_interval(2e-4):
+            a_in.set()
+            b_in.wait(5)
+        inside["after_a_left"] = sys.getswitchinterval()  # B is still serving: the short interval must still be in force
+        a_out.set()
+
+    def job_b():
+        a_in.wait(5)
+        with _switch_interval(2e-4):
+            b_in.set()
+            a_out.wait(5)
+            inside["b_still_in"] = sys.getswitchinterval()
+
+    ta, tb = threading.Thread(target=job_a), threading.Thread(target=job_b)
+    ta.start(), tb.start()
+    ta.join(10), tb.join(10)
+    assert inside["after_a_left"] == pytest.approx(2e-4, rel=0.02) and inside["b_still_in"] == pytest.approx(2e-4, rel=0.02)  # (the interpreter stores microseconds)
+    assert sys.getswitchinterval() == before

@@ -39,10 +39,22 @@ def main():
     for m in nets:
         m.set_conv_split(code)
     split = [r.model_dump() for r in an.serve(pages)]
+    arms = []
+    if os.environ.get("ROUTES_CONTROL") == "1":
+        # the same split arithmetic on the round-4 routing: no A-stationary kernel, LayerNorm as its own launch, fp32
+        # activations everywhere - what the round-5 routes (one of which, the planes under a bound, changes a scale) add
+        from yomitoku_amd import _lib
+        for k, v in (("astat", 0), ("parseq_no_ln_fusion", 1), ("act_planes", 0)):
+            _lib.debug_option(k, v)
+        try:
+            arms.append(("split_round4_routing_vs_fp32", [r.model_dump() for r in an.serve(pages)]))
+        finally:
+            for k, v in (("astat", 1), ("parseq_no_ln_fusion", 0), ("act_planes", 1)):
+                _lib.debug_option(k, v)
     for m in nets:
         m.set_conv_split(0)
     again = [r.model_dump() for r in an.serve(pages)]
-    arms = [("split_det_layout_table_vs_fp32", split), ("fp32_repeat_vs_fp32", again)]
+    arms = [("split_det_layout_table_vs_fp32" if len(nets) == 3 else "split_all_four_nets_vs_fp32", split), ("fp32_repeat_vs_fp32", again)] + arms
     if os.environ.get("CONTROL") == "1":
         # the yardstick: EXACT fp32 products summed in another order (every convolution through the split-K kernel, which adds
         # the K tiles of a row in four interleaved chains) - what any second fp32 implementation differs by

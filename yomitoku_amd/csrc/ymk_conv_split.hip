@@ -540,6 +540,9 @@ class SplitCtx {
       else hipLaunchKernelGGL(k_split_panel<3>, dim3(blocks), dim3(256), 0, s, w.w, reinterpret_cast<unsigned short*>(pn.planes), n, w.kpad);
     }
     YMK_HIP(hipGetLastError());
+    // built once, on the stream of the forward that asked first: wait for it here, so that a later forward of this model on
+    // ANOTHER stream (a second lane, a caller that changed streams) can never read a panel that is still being written
+    YMK_HIP(hipStreamSynchronize(s));
     return cache_.emplace(key, pn).first->second;
   }
   // max|x| of the input view of launch k, on stream s; returns the device word the convolution kernel reads

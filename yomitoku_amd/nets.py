@@ -121,9 +121,10 @@ class HipNet:
         self._reserve_tried_for = None  # a new handle has no workspace reservation (reserve_once)
 
     def set_conv_split(self, planes):
-        """Operand precision of THIS model's convolutions / linear layers (include/ymk.h, "conv_split"): 0 = exact fp32 MFMA
-        (the default), 2 / 3 = fp32 operands cut into 2 / 3 bf16 planes with fp32 accumulation, None = follow the
-        process-wide switch.  Takes effect from the next forward."""
+        """Operand precision of THIS model's convolutions / linear layers (include/ymk.h, "conv_split"): 16 = fp32 operands as
+        two scaled fp16 planes, fp32 accumulation (what a model runs when nothing is set: the library's default since round 4),
+        0 = exact fp32 MFMA, 2 / 3 = 2 / 3 bf16 planes (evaluation), None = follow the process-wide switch if one is set,
+        else the default.  Takes effect from the next forward."""
         self._conv_split = None if planes is None else int(planes)
         if self._h is not None:
             _lib.check(_lib.load().ymk_model_set_param(self._h, b"conv_split", float(-1 if planes is None else int(planes))),

@@ -112,20 +112,35 @@ def _full_gc_deferred(on: bool):
         gc.set_threshold(t0, t1, t2)
 
 
+_switch_lock = threading.Lock()
+_switch_users = 0
+_switch_saved = None
+
+
 @contextlib.contextmanager
 def _switch_interval(seconds):
-    """CPython's thread switch interval shortened while the block runs, restored afterwards.  The stage threads are
-    launch-latency-bound: one returning from a 50 us library call must not wait 5 ms (the default interval) behind another
-    stage's Python loop before it can issue its next launch.  None / 0 leaves the interpreter alone."""
+    """CPython's thread switch interval shortened while the block runs.  The stage threads are launch-latency-bound: one
+    returning from a 50 us library call must not wait 5 ms (the default interval) behind another stage's Python loop before
+    it can issue its next launch.  None / 0 leaves the interpreter alone.  The setting is process-wide, so it is reference
+    counted: the first job in saves the interpreter's value, the LAST job out restores it - two pipelines serving at once
+    (two analyzers, two threads) cannot restore out of order and leave the short interval behind."""
+    global _switch_users, _switch_saved
     if not seconds:
         yield
         return
-    before = sys.getswitchinterval()
-    sys.setswitchinterval(float(seconds))
+    with _switch_lock:
+        if _switch_users == 0:
+            _switch_saved = sys.getswitchinterval()
+        _switch_users += 1
+        sys.setswitchinterval(min(float(seconds), sys.getswitchinterval()))
     try:
         yield
     finally:
-        sys.setswitchinterval(before)
+        with _switch_lock:
+            _switch_users -= 1
+            if _switch_users == 0 and _switch_saved is not None:
+                sys.setswitchinterval(_switch_saved)
+                _switch_saved = None
 
 
 class PagePipeline:
