@@ -189,6 +189,22 @@ def rank_main(rank, world, port, args, q):
         row["cells_per_page"] = round(float(np.mean([sum(len(t.cells) for t in e.tables) for e in ok])), 1) if ok else None
         row["pickled_kb_per_page"] = round(len(pickle.dumps(ok[0])) / 1024, 1) if ok else None
         row["json_kb_per_page"] = round(len(ok[0].model_dump_json()) / 1024, 1) if ok else None
+        if ok:  # what one page costs rank 0 to rebuild, collector on / held back (64 pages in one blob, as gather_object does)
+            import gc
+
+            blob = pickle.dumps(ok[:64])
+            t = time.perf_counter()
+            pickle.loads(blob)
+            row["unpickle_ms_per_page"] = round((time.perf_counter() - t) / len(ok[:64]) * 1e3, 2)
+            gc.disable()
+            t = time.perf_counter()
+            pickle.loads(blob)
+            row["unpickle_ms_per_page_gc_off"] = round((time.perf_counter() - t) / len(ok[:64]) * 1e3, 2)
+            gc.enable()
+            t = time.perf_counter()
+            for e in ok[:64]:
+                e.model_dump_json()
+            row["dump_json_ms_per_page"] = round((time.perf_counter() - t) / len(ok[:64]) * 1e3, 2)
         if failed:
             row["first_failure"] = repr(next(e for _, _, e in local if isinstance(e, BaseException)))
     q.put(row)
@@ -230,6 +246,8 @@ def main():
                 "gpu_bound_pages_per_s_per_rank": round(16e3 / args.gpu_ms_per_wave, 1),
                 "cpu_s_per_page": round(float(np.mean([r["cpu_s_per_page"] for r in rows])), 4),
                 "gather": args.gather, "rank0_gather_s": r0["gather_s"], "pickled_kb_per_page": r0.get("pickled_kb_per_page"), "json_kb_per_page": r0.get("json_kb_per_page"),
+                "unpickle_ms_per_page": r0.get("unpickle_ms_per_page"), "unpickle_ms_per_page_gc_off": r0.get("unpickle_ms_per_page_gc_off"),
+                "dump_json_ms_per_page": r0.get("dump_json_ms_per_page"),
                 "words_per_page": r0.get("words_per_page"), "cells_per_page": r0.get("cells_per_page"), "budget": r0["budget"],
                 "first_failure": r0.get("first_failure")}
         print(json.dumps(line), flush=True)

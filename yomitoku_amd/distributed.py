@@ -317,12 +317,13 @@ class ShardedServer:
         {"error": text} - a rank whose share failed as a whole: the collectives still run on every rank and then all of them
         raise ShardedJobError.
 
-        form "objects": the entries as they are (schemas and exception objects pickle).  Unpickling a page's schema costs
-        rank 0 ~2 ms (a few thousand pydantic objects), which at 8 GPUs x 110 pages/s is more than one core can do - so
-        "json": every schema travels as its `model_dump_json()` text (0.1 ms per page on the sender, NOTHING to rebuild on rank
-        0; a failed page as {"error": "Type: message"}) - the form for a caller that writes the pages out (cli/main.py:122-137
-        writes one JSON file per page).  Either way the cyclic garbage collector is held back while rank 0 unpickles: a
-        generation-2 pass per few thousand new containers made the 2-rank gather of 512 pages take 6.5 s (tools/host_rehearsal.py)."""
+        form "objects": the entries as they are (schemas and exception objects pickle).  Rank 0 then rebuilds every remote
+        page's schema - a few thousand pydantic objects, 0.4-0.6 ms per page on an idle core, and the whole gather of a
+        1024-page job with 8 ranks measured 6.7 s on an 8-core host (tools/host_rehearsal.py): at 8 GPUs x 110 pages/s that is
+        rank 0's whole budget - so "json": every schema travels as its `model_dump_json()` text (0.17 ms per page on the
+        sender, NOTHING to rebuild on rank 0: 1.1 s for the same job; a failed page as {"error": "Type: message"}) - the form
+        for a caller that writes the pages out (cli/main.py:122-137 writes one JSON file per page).  The cyclic garbage
+        collector is held back while rank 0 unpickles (a third of the rebuild time)."""
         if form not in ("objects", "json"):
             raise ValueError(f"gather form must be 'objects' or 'json', got {form!r}")
         failed = local.get("error") if isinstance(local, dict) else None
