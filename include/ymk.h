@@ -179,13 +179,16 @@ int ymk_prof_begin(void);
  *                        planes the 3 x 3 multiplies with (written by the reduction's epilogue under the bound
  *                        max|x_in| x max row L1 norm + max|bias|, read by LDS-DMA without conversion) wherever both launches
  *                        fill the chip; 0: fp32 activations everywhere (A/B runs)
+ *   "parseq_no_mlp_fusion" (0)  1: norm2 -> fc1 -> GELU -> fc2 of the ViT blocks as launches of their own through the [rows][4 D]
+ *                        buffer (A/B runs, tests); 0: one launch with the hidden state on chip where the fused kernel runs it
  *   "amax_check" (0)     1: every fp16-split launch whose input came with a max|x| record from its producer ALSO measures the
  *                        input and compares (ymk_amax_check_counters) - the self-check of the record plumbing; 2: also names every
  *                        launch whose record lies BELOW the measured maximum on stderr (serialises the stream) */
 int ymk_debug_option(const char* key, int value);
 /* Launch counters since the process started, for tests that must know a route was really taken: "astat_launches" (the
  * A-stationary short-K kernel), "ln_fused_launches" (those of them that carried a LayerNorm in their operand load),
- * "planes_written_launches" / "planes_read_launches" (convolutions whose output / input lives in HBM as fp16 planes). */
+ * "planes_written_launches" / "planes_read_launches" (convolutions whose output / input lives in HBM as fp16 planes),
+ * "mlp_fused_launches" (ViT MLP halves run as one launch). */
 int ymk_stat(const char* key, int64_t* value);
 /* out4 = {launches checked, records below the true max|x| (a bug), records more than 2^8 above it, largest record / truth
  * exponent distance} since the process started; synchronises the device. */
@@ -219,6 +222,14 @@ int ymk_op_conv2d(const float* x_dev, int n, int h, int w, int c, /* c % 4 == 0,
 int ymk_op_conv1x1_astat(const float* x_dev, int m, int c, const float* w_host_oc, int cout, const float* scale_host,
                          const float* bias_host, const float* res_dev, int act, const float* ln_g_host, const float* ln_b_host,
                          float ln_eps, float* y_dev, int reps, float* kernel_ms, void* stream);
+
+/* The MLP half of a ViT block in one launch (yomitoku_amd/csrc/ymk_vit_mlp.hip; what the PARSeq encoder runs per block when a
+ * forward fills the chip): y[m][d] = x + fc2(GELU(fc1(LayerNorm(x; gamma, beta, eps)))), fc1 [f][d] + bias [f], fc2 [d][f] + bias
+ * [d] (host, nn.Linear layout), x / y on the device.  d = 192, f = 768, m >= 32 641 (256 blocks of 128 rows) - refused (error)
+ * otherwise.  Repeated `reps` times IN PLACE on y (timing); *kernel_ms = HIP-event time of the last launch. */
+int ymk_op_vit_mlp(const float* x_dev, int m, int d, int f, const float* ln_g_host, const float* ln_b_host, float ln_eps,
+                   const float* w1_host_fd, const float* b1_host, const float* w2_host_df, const float* b2_host, float* y_dev, int reps,
+                   float* kernel_ms, void* stream);
 
 int ymk_op_layernorm(const float* x_dev, int rows, int d, const float* g_dev, const float* b_dev, float eps,
                      float* y_dev, void* stream);

@@ -79,6 +79,24 @@ def conv1x1_astat(x, weight, scale=None, bias=None, residual=None, act="none", r
     return y, float(ms.value)
 
 
+def vit_mlp(x, gamma, beta, eps, w1, b1, w2, b2, reps=1):
+    """ymk_op_vit_mlp: x [M, D] on the device -> (x + fc2(gelu(fc1(layer_norm(x)))) [M, D], ms of the last launch)."""
+    import ctypes
+
+    lib = _lib.load()
+    m, d = x.shape
+    f = w1.shape[0]
+    xh = x.float().contiguous()
+    host = [t.detach().float().cpu().contiguous() for t in (gamma, beta, w1, b1, w2, b2)]
+    y = torch.empty_like(xh)
+    ms = ctypes.c_float()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.ymk_op_vit_mlp(xh.data_ptr(), m, d, f, host[0].data_ptr(), host[1].data_ptr(), float(eps), host[2].data_ptr(),
+                                      host[3].data_ptr(), host[4].data_ptr(), host[5].data_ptr(), y.data_ptr(), reps, ctypes.byref(ms),
+                                      _lib.current_stream_ptr()), "ymk_op_vit_mlp")
+    return y, float(ms.value)
+
+
 def maxpool3x3s2(x):
     lib = _lib.load()
     n, c, h, w = x.shape

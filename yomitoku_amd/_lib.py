@@ -58,6 +58,10 @@ SIGNATURES = {
     "ymk_table_hole_rects": (c_int, [c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, POINTER(c_int)]),
     "ymk_debug_option": (c_int, [c_char_p, c_int]),
     "ymk_stat": (c_int, [c_char_p, POINTER(c_int64)]),
+    "ymk_op_vit_mlp": (
+        c_int,
+        [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, POINTER(c_float), c_void_p],
+    ),
     "ymk_amax_check_counters": (c_int, [POINTER(c_int64)]),
     "ymk_prof_begin": (c_int, []),
     "ymk_prof_end": (c_int, [POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),

@@ -321,6 +321,43 @@ int ymk_op_conv1x1_astat(const float* x_dev, int m, int c, const float* w_host_o
   YMK_API_END
 }
 
+int ymk_op_vit_mlp(const float* x_dev, int m, int d, int f, const float* ln_g_host, const float* ln_b_host, float ln_eps,
+                   const float* w1_host_fd, const float* b1_host, const float* w2_host_df, const float* b2_host, float* y_dev, int reps,
+                   float* kernel_ms, void* stream) {
+  YMK_API_BEGIN
+  using namespace ymk;
+  YMK_CHECK(x_dev && y_dev && ln_g_host && ln_b_host && w1_host_fd && b1_host && w2_host_df && b2_host && m > 0, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  DevicePool pool;
+  const std::vector<float> g(ln_g_host, ln_g_host + d), b(ln_b_host, ln_b_host + d);
+  const float* g_dev = pool.upload(g);
+  const float* b_dev = pool.upload(b);
+  ConvW fc1 = make_linear_raw(pool, w1_host_fd, b1_host, f, d), fc2 = make_linear_raw(pool, w2_host_df, b2_host, d, f);
+  struct Events {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Events() {
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+    }
+  } ev;
+  YMK_HIP(hipEventCreate(&ev.e0));
+  YMK_HIP(hipEventCreate(&ev.e1));
+  SplitCtxOwner split_ctx;
+  ConvSplitScope scope(SPLIT_F16X2, split_ctx.get(), 0);
+  YMK_HIP(hipMemcpyAsync(y_dev, x_dev, (size_t)m * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+  for (int r = 0; r < std::max(1, reps); ++r) {  // in place on y: repetitions (timing) keep transforming it
+    if (r == std::max(1, reps) - 1) YMK_HIP(hipEventRecord(ev.e0, s));
+    YMK_CHECK(vit_mlp_fused(s, y_dev, m, d, g_dev, b_dev, ln_eps, layernorm_output_bound(g, b), fc1, fc2),
+              "the fused ViT MLP runs D = 192, F = 768 and at least 256 blocks of 128 rows");
+    if (r == std::max(1, reps) - 1) YMK_HIP(hipEventRecord(ev.e1, s));
+  }
+  YMK_HIP(hipStreamSynchronize(s));
+  float ms = 0.f;
+  YMK_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+  if (kernel_ms) *kernel_ms = ms;
+  YMK_API_END
+}
+
 int ymk_op_layernorm(const float* x_dev, int rows, int d, const float* g_dev, const float* b_dev, float eps,
                      float* y_dev, void* stream) {
   YMK_API_BEGIN

@@ -239,6 +239,13 @@ void gemm(hipStream_t s, const float* A, int M, int K, int lda, const ConvW& w, 
 bool gemm_ln_fused(hipStream_t s, const float* X, int M, int K, int ldx, const float* ln_g, const float* ln_b, float ln_eps, const ConvW& w,
                    int act, const float* res, int res_ld, float* out, int out_ld, const unsigned* amax_in, unsigned* amax_out = nullptr);
 
+// x[m][:] <- x[m][:] + fc2(GELU(fc1(LayerNorm(x[m][:])))) in ONE launch, the hidden state never written (k_vit_mlp_f16,
+// ymk_vit_mlp.hip: fp16-split mode, D = 192, F = 768, a launch of >= 256 row blocks); ln_bound: the LayerNorm's static output
+// bound (the number make_layernorm_amax_record stores).  False = nothing was launched: the caller runs the three launches.
+bool vit_mlp_fused(hipStream_t s, float* x, int M, int ld, const float* ln_g, const float* ln_b, float ln_eps, float ln_bound, const ConvW& fc1,
+                   const ConvW& fc2);
+float layernorm_output_bound(const std::vector<float>& gamma, const std::vector<float>& beta);
+
 // Host-side packing: OIHW fp32 -> panel. `cin_pad4` packs for the tap4 mode (cin<=4).
 void pack_conv_weight(const float* oihw, int cout, int cin, int kh, int kw, bool tap4,
                       std::vector<float>& panel, int& kpad, int& ctiles);

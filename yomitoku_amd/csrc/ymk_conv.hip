@@ -580,6 +580,36 @@ std::pair<hipEvent_t, hipEvent_t>* conv_prof_open(hipStream_t s, const ConvK& k,
   return e;
 }
 
+// the same for a launch that is not one convolution (the fused ViT MLP): description, algorithmic FLOPs and bytes, and the
+// MFMA products behind one fp32-grade product, as given
+std::pair<hipEvent_t, hipEvent_t>* conv_prof_open_raw(hipStream_t s, const char* desc, double flops, double bytes, double products) {
+  if (!g_prof.on) return nullptr;
+  std::lock_guard<std::mutex> lock(g_prof.mu);
+  if (g_prof.used == g_prof.ev.size()) {
+    std::pair<hipEvent_t, hipEvent_t> n;
+    YMK_HIP(hipEventCreate(&n.first));
+    YMK_HIP(hipEventCreate(&n.second));
+    g_prof.ev.push_back(n);
+  }
+  auto* e = &g_prof.ev[g_prof.used++];
+  g_prof.flop += flops;
+  g_prof.bytes += bytes;
+  if (g_prof.desc.size() < g_prof.used) {
+    g_prof.desc.resize(g_prof.used);
+    g_prof.lflop.resize(g_prof.used);
+    g_prof.lbytes.resize(g_prof.used);
+    g_prof.lms.resize(g_prof.used);
+    g_prof.lprod.resize(g_prof.used);
+  }
+  g_prof.desc[g_prof.used - 1] = desc;
+  g_prof.lflop[g_prof.used - 1] = flops;
+  g_prof.lbytes[g_prof.used - 1] = bytes;
+  g_prof.lms[g_prof.used - 1] = 0.0;
+  g_prof.lprod[g_prof.used - 1] = products;
+  YMK_HIP(hipEventRecord(e->first, s));
+  return e;
+}
+
 template <int TM, int TN, int NW, int PF>
 static void launch_splitk(hipStream_t s, ConvK& k) {
   const int mt = (k.M + 32 * TM - 1) / (32 * TM), nt = (k.Cout + 32 * TN - 1) / (32 * TN);
@@ -853,6 +883,15 @@ bool gemm_ln_fused(hipStream_t s, const float* X, int M, int K, int ldx, const f
   a.ln_b = ln_b;
   a.ln_eps = ln_eps;
   return conv2d_impl(s, in, w, a, o);
+}
+
+bool vit_mlp_split_launch(hipStream_t s, SplitCtx* ctx, float* x, int M, int ld, const float* ln_g, const float* ln_b, float ln_eps,
+                          float ln_bound, const ConvW& fc1, const ConvW& fc2);  // ymk_conv_split.hip
+
+bool vit_mlp_fused(hipStream_t s, float* x, int M, int ld, const float* ln_g, const float* ln_b, float ln_eps, float ln_bound, const ConvW& fc1,
+                   const ConvW& fc2) {
+  if (conv_effective_split() != SPLIT_F16X2 || t_split_ctx == nullptr) return false;
+  return vit_mlp_split_launch(s, t_split_ctx, x, M, ld, ln_g, ln_b, ln_eps, ln_bound, fc1, fc2);
 }
 
 void gemm(hipStream_t s, const float* A, int M, int K, int lda, const ConvW& w, int act, const float* res, int res_ld,

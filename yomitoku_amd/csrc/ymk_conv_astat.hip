@@ -283,10 +283,6 @@ __global__ __launch_bounds__(256, 2) void conv_f16_astat(ConvK p, const uint4* _
 }
 
 
-// ymk_conv_split.hip: builds the two fp16 planes of a packed fp32 panel (channel-major K order) and the epilogue scale
-__global__ void k_split_panel_f16(const float* __restrict__ w, unsigned short* __restrict__ out, int kpad, const float* __restrict__ scale,
-                                  int cout, float* __restrict__ scale_out, int taps, int ctiles);
-
 template <int BN, int KT, bool LN>
 static void launch_astat(hipStream_t s, ConvK& k, const void* planes, size_t w_bytes, int groups) {
   hipLaunchKernelGGL((conv_f16_astat<BN, KT, LN>), dim3((k.M + 127) / 128, groups), dim3(256), 0, s, k, reinterpret_cast<const uint4*>(planes), (unsigned)w_bytes);

@@ -415,8 +415,11 @@ __global__ void k_split_panel(const float* __restrict__ w, unsigned short* __res
 // it at tap * ctiles + cc.  The kernels then walk the taps of one 32-channel slice back to back: the nine shifted windows of
 // a 3 x 3 layer overlap in all but one pixel column / row, and with only 128 bytes per pixel live they stay in L1 / L2, where
 // the tap-major order streams the whole Cin x 4 B of every pixel past between two visits (section 9 item 3 of round 3).
+// perm = 1 (1 x 1 panels only; the fused ViT MLP, ymk_vit_mlp.hip): inside every 32-wide K tile, source position k goes to the
+// slot whose MFMA k index reads it as "accumulator register order": slot 16 s + 8 lh + j holds k = 16 s + 8 (j >> 2) + 4 lh +
+// (j & 3) - the order in which a lane of the TRANSPOSED first product holds the hidden units of its row.
 __global__ void k_split_panel_f16(const float* __restrict__ w, unsigned short* __restrict__ out, int kpad, const float* __restrict__ scale,
-                                  int cout, float* __restrict__ scale_out, int taps, int ctiles) {
+                                  int cout, float* __restrict__ scale_out, int taps, int ctiles, int perm) {
   __shared__ unsigned red[4];
   const int row = blockIdx.x, t = threadIdx.x;
   const float* wr = w + (size_t)row * kpad;
@@ -429,9 +432,14 @@ __global__ void k_split_panel_f16(const float* __restrict__ w, unsigned short* _
   m = max(max(red[0], red[1]), max(red[2], red[3]));
   const float2 sc = f16_scales(m);
   for (int k = t; k < kpad; k += 256) {
-    const int kt_src = k >> 5, kk = k & 31;
+    const int kt_src = k >> 5;
+    int kk = k & 31;
     const int tap = kt_src / ctiles, cc = kt_src - tap * ctiles;
     const int kt = cc * taps + tap;
+    if (perm) {  // source k = 16 s + 8 q + 4 lh + e  ->  slot 16 s + 8 lh + 4 q + e
+      const int rem = kk & 15;
+      kk = (kk & 16) | (((rem >> 2) & 1) << 3) | ((rem >> 3) << 2) | (rem & 3);
+    }
     float r = wr[k] * sc.x;
     const _Float16 h = (_Float16)r;
     r -= (float)h;
@@ -510,6 +518,9 @@ void amax_check_counters(long long* out4) {
   YMK_HIP(hipMemcpy(out4, g_amax_counters, 4 * sizeof(long long), hipMemcpyDeviceToHost));
 }
 
+// cache key of the fc2 panel of the fused ViT MLP: fp16 planes with the accumulator-order K permutation (never a "conv_split" code)
+constexpr int SPLIT_F16X2_PERM = 17;
+
 // ---- per-model state
 class SplitCtx {
  public:
@@ -530,10 +541,10 @@ class SplitCtx {
     Panels pn;
     pn.planes = alloc(rows * w.kpad * ns * 2);  // rows padded to 256: the 256-wide tile reads whole tiles
     YMK_HIP(hipMemsetAsync(pn.planes, 0, rows * w.kpad * ns * 2, s));
-    if (code == SPLIT_F16X2) {
+    if (code == SPLIT_F16X2 || code == SPLIT_F16X2_PERM) {
       pn.scale = reinterpret_cast<float*>(alloc(real * sizeof(float)));
       hipLaunchKernelGGL(k_split_panel_f16, dim3((unsigned)real), dim3(256), 0, s, w.w, reinterpret_cast<unsigned short*>(pn.planes), w.kpad,
-                         w.scale, w.cout, pn.scale, w.kh * w.kw, w.ctiles);
+                         w.scale, w.cout, pn.scale, w.kh * w.kw, w.ctiles, code == SPLIT_F16X2_PERM ? 1 : 0);
     } else {
       const int blocks = (int)((n + 255) / 256);
       if (ns == 2) hipLaunchKernelGGL(k_split_panel<2>, dim3(blocks), dim3(256), 0, s, w.w, reinterpret_cast<unsigned short*>(pn.planes), n, w.kpad);
@@ -661,11 +672,13 @@ static std::atomic<int> g_astat{1};
 static std::atomic<int> g_act_planes{1};
 // launch counters since the process started (ymk_stat; tests assert that a route was really taken)
 static std::atomic<long long> g_n_astat{0}, g_n_ln_fused{0}, g_n_planes_read{0}, g_n_planes_written{0};
+long long vit_mlp_fused_launches();
 bool conv_split_stat(const std::string& key, long long* value) {
   if (key == "astat_launches") *value = g_n_astat.load();
   else if (key == "ln_fused_launches") *value = g_n_ln_fused.load();
   else if (key == "planes_read_launches") *value = g_n_planes_read.load();
   else if (key == "planes_written_launches") *value = g_n_planes_written.load();
+  else if (key == "mlp_fused_launches") *value = vit_mlp_fused_launches();
   else return false;
   return true;
 }
@@ -852,6 +865,65 @@ bool conv2d_split(hipStream_t s, ConvK& k, const ConvW& w, int code, SplitCtx* c
   }
   YMK_HIP(hipGetLastError());
   return true;
+}
+
+// ---- the fused ViT MLP (ymk_vit_mlp.hip): planes of fc1 (standard) and fc2 (permuted), the bounds, the launch
+struct MlpK {  // as in ymk_vit_mlp.hip
+  const float* x;
+  float* out;
+  int M, ld;
+  const float *ln_g, *ln_b;
+  float ln_eps, ln_bound;
+  const uint4* w1;
+  unsigned w1_bytes;
+  const float *s1, *b1;
+  const uint4* w2;
+  unsigned w2_bytes;
+  const float *s2, *b2;
+  float g_bound;
+};
+bool vit_mlp_f16_launch(hipStream_t s, const MlpK& k, int D, int F);
+std::pair<hipEvent_t, hipEvent_t>* conv_prof_open_raw(hipStream_t s, const char* desc, double flops, double bytes, double products);
+
+static std::atomic<long long> g_n_mlp_fused{0};
+long long vit_mlp_fused_launches() { return g_n_mlp_fused.load(); }
+
+bool vit_mlp_split_launch(hipStream_t s, SplitCtx* ctx, float* x, int M, int ld, const float* ln_g, const float* ln_b, float ln_eps,
+                          float ln_bound, const ConvW& fc1, const ConvW& fc2) {
+  const int D = fc1.cin, F = fc1.cout;
+  if (ctx == nullptr || fc1.mode != 0 || fc2.mode != 0 || fc1.kh * fc1.kw != 1 || fc2.kh * fc2.kw != 1) return false;
+  if (fc2.cin != F || fc2.cout != D || fc1.kpad != D || fc2.kpad != F || fc1.scale != nullptr || fc2.scale != nullptr) return false;
+  if (fc1.bias == nullptr || fc2.bias == nullptr || D != 192 || F != 768) return false;
+  if ((M + 127) / 128 < 256) return false;  // one block per CU: fewer blocks than CUs leave the layer to the GEMM kernels
+  const SplitCtx::Panels& p1 = ctx->panels(s, fc1, SPLIT_F16X2);
+  const SplitCtx::Panels& p2 = ctx->panels(s, fc2, SPLIT_F16X2_PERM);
+  MlpK k{};
+  k.x = x;
+  k.out = x;
+  k.M = M;
+  k.ld = ld;
+  k.ln_g = ln_g;
+  k.ln_b = ln_b;
+  k.ln_eps = ln_eps;
+  k.ln_bound = ln_bound;
+  k.w1 = reinterpret_cast<const uint4*>(p1.planes);
+  k.w1_bytes = (unsigned)((size_t)((F + 255) / 256 * 256) * fc1.kpad * 4);
+  k.s1 = p1.scale;
+  k.b1 = fc1.bias;
+  k.w2 = reinterpret_cast<const uint4*>(p2.planes);
+  k.w2_bytes = (unsigned)((size_t)((D + 255) / 256 * 256) * fc2.kpad * 4);
+  k.s2 = p2.scale;
+  k.b2 = fc2.bias;
+  k.g_bound = fc1.pl_a * ln_bound + fc1.pl_b;  // |GELU(v)| <= |v| <= pl_a max|LayerNorm output| + pl_b
+  char desc[160];
+  snprintf(desc, sizeof desc, "M=%7d Cin=%4d Cout=%4d k=1x1 s=1 d=1 res=1 tile=128x%d ksplit=163 grid=%d vit-mlp-fused(F=%d)", M, D, D, D, (M + 127) / 128, F);
+  // algorithmic work of the fused layer: both products; bytes: the rows in and out, the residual read, the two weight matrices
+  auto* e = conv_prof_open_raw(s, desc, 4.0 * (double)M * D * F, 4.0 * (3.0 * (double)M * D + 2.0 * (double)D * F), 3.0);
+  const bool taken = vit_mlp_f16_launch(s, k, D, F);
+  if (e) YMK_HIP(hipEventRecord(e->second, s));
+  YMK_HIP(hipGetLastError());
+  if (taken) ++g_n_mlp_fused;
+  return taken;
 }
 
 }  // namespace ymk

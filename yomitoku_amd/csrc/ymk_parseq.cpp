@@ -28,12 +28,15 @@ static std::atomic<int> g_parseq_unfused{0};  // ymk_debug_option("parseq_unfuse
 static bool parseq_unfused() { return g_parseq_unfused.load(std::memory_order_relaxed) != 0; }
 static std::atomic<int> g_parseq_no_rowmax{0};  // ymk_debug_option("parseq_no_rowmax", 1): keep the AR logits (A/B, tests)
 static bool parseq_no_rowmax() { return g_parseq_no_rowmax.load(std::memory_order_relaxed) != 0; }
+static std::atomic<int> g_parseq_no_mlp_fusion{0};  // ymk_debug_option("parseq_no_mlp_fusion", 1): fc1 / fc2 as GEMMs of their own (A/B, tests)
+static bool parseq_no_mlp_fusion() { return g_parseq_no_mlp_fusion.load(std::memory_order_relaxed) != 0; }
 static std::atomic<int> g_parseq_no_ln_fusion{0};  // ymk_debug_option("parseq_no_ln_fusion", 1): LayerNorm as its own launch (A/B, tests)
 static bool parseq_no_ln_fusion() { return g_parseq_no_ln_fusion.load(std::memory_order_relaxed) != 0; }
 bool parseq_debug_option(const std::string& key, int value) {
   if (key == "parseq_unfused") g_parseq_unfused = value;
   else if (key == "parseq_no_rowmax") g_parseq_no_rowmax = value;
   else if (key == "parseq_no_ln_fusion") g_parseq_no_ln_fusion = value;
+  else if (key == "parseq_no_mlp_fusion") g_parseq_no_mlp_fusion = value;
   else return false;
   return true;
 }
@@ -48,6 +51,7 @@ namespace {
 struct EncBlock {
   float *ln1g, *ln1b, *ln2g, *ln2b;
   unsigned *ln1_rec, *ln2_rec;  // static max|x| records of the two LayerNorm outputs (make_layernorm_amax_record)
+  float ln2_bound = 0.f;        // the number ln2_rec holds (layernorm_output_bound): scale of the fused MLP's row planes
   ConvW qkv, proj, fc1, fc2;
 };
 
@@ -101,6 +105,7 @@ class ParseqModel : public Model {
       b.ln2b = pool.upload(ws.get(p + "norm2.bias").data);
       b.ln1_rec = make_layernorm_amax_record(pool, ws.get(p + "norm1.weight").data, ws.get(p + "norm1.bias").data);
       b.ln2_rec = make_layernorm_amax_record(pool, ws.get(p + "norm2.weight").data, ws.get(p + "norm2.bias").data);
+      b.ln2_bound = layernorm_output_bound(ws.get(p + "norm2.weight").data, ws.get(p + "norm2.bias").data);
       b.qkv = make_linear(pool, ws, p + "attn.qkv");
       b.proj = make_linear(pool, ws, p + "attn.proj");
       b.fc1 = make_linear(pool, ws, p + "mlp.fc1");
@@ -423,8 +428,12 @@ class ParseqModel : public Model {
       flash_attention(s, qkv, qkv + D, qkv + 2 * D, att, B, eh_, L, L, hd, 3 * D, 3 * D, 3 * D, D, (long)L * 3 * D,
                       (long)L * 3 * D, (long)L * 3 * D, (long)L * D, scale, enc_t, qkv_rec, qkv_rec, qkv_rec);
       gemm(s, att, M, D, D, b.proj, ACT_NONE, xs, D, xs, D, nullptr, nullptr, EPI_STORE, qkv_rec);
-      ln_gemm(s, xs, b.ln2g, b.ln2b, 1e-6f, y, M, D, b.fc1, ACT_GELU, hbuf, b.fc1.cout, b.ln2_rec, h_rec);
-      gemm(s, hbuf, M, b.fc1.cout, b.fc1.cout, b.fc2, ACT_NONE, xs, D, xs, D, nullptr, nullptr, EPI_STORE, h_rec);
+      // norm2 -> fc1 -> GELU -> fc2 -> + residual: one launch with the hidden state on chip where the fused kernel runs the
+      // layer (ymk_vit_mlp.hip), else LayerNorm (folded or not) + the two GEMMs through the [M][4 D] buffer
+      if (parseq_no_mlp_fusion() || !vit_mlp_fused(s, xs, M, D, b.ln2g, b.ln2b, 1e-6f, b.ln2_bound, b.fc1, b.fc2)) {
+        ln_gemm(s, xs, b.ln2g, b.ln2b, 1e-6f, y, M, D, b.fc1, ACT_GELU, hbuf, b.fc1.cout, b.ln2_rec, h_rec);
+        gemm(s, hbuf, M, b.fc1.cout, b.fc1.cout, b.fc2, ACT_NONE, xs, D, xs, D, nullptr, nullptr, EPI_STORE, h_rec);
+      }
     }
     ln(s, xs, enc_ng_, enc_nb_, 1e-6f, mem, M, D);
     enc_scope.reset();

@@ -159,11 +159,15 @@ ConvW make_linear_raw(DevicePool& pool, const float* w_out_in, const float* bias
   return c;
 }
 
-unsigned* make_layernorm_amax_record(DevicePool& pool, const std::vector<float>& gamma, const std::vector<float>& beta) {
+float layernorm_output_bound(const std::vector<float>& gamma, const std::vector<float>& beta) {
   float g = 0.f, b = 0.f;
   for (float v : gamma) g = std::max(g, std::fabs(v));
   for (float v : beta) b = std::max(b, std::fabs(v));
-  const float bound = std::sqrt((float)gamma.size()) * g + b;
+  return std::sqrt((float)gamma.size()) * g + b;
+}
+
+unsigned* make_layernorm_amax_record(DevicePool& pool, const std::vector<float>& gamma, const std::vector<float>& beta) {
+  const float bound = layernorm_output_bound(gamma, beta);
   std::vector<float> rec(AMAX_REC_WORDS, 0.f);  // all-zero bit patterns but word 0
   rec[0] = bound;                                // the record holds fp32 bit patterns: upload the float as it is
   return reinterpret_cast<unsigned*>(pool.upload(rec));
