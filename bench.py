@@ -78,7 +78,7 @@ def kernel_source_sha():
     import hashlib
 
     h = hashlib.sha256()
-    for name in ("ymk_conv.hip", "ymk_conv_split.hip", "ymk_conv_dma.hip", "ymk_conv_astat.hip", "ymk_conv_kernel.h"):
+    for name in ("ymk_conv.hip", "ymk_conv_split.hip", "ymk_conv_dma.hip", "ymk_conv_astat.hip", "ymk_vit_mlp.hip", "ymk_conv_kernel.h"):
         with open(os.path.join(ROOT, "yomitoku_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -894,7 +894,7 @@ def main():
     roof = None
     leg("roofline: serial pass with per-launch events")
     if rank == 0 and not DRY and not args.no_roofline:
-        kern = ("conv_igemm_split / conv_f16_dma / conv_f16_astat (fp16-split MFMA implicit GEMM: the chip-filling conv / linear launches of the four nets) + conv_igemm / "
+        kern = ("conv_igemm_split / conv_f16_dma / conv_f16_astat / k_vit_mlp_f16 (fp16-split MFMA implicit GEMM: the chip-filling conv / linear launches of the four nets, the ViT MLP halves as one launch each) + conv_igemm / "
                 "conv_splitk (exact fp32 MFMA: the stems and the grid-starved launches), max|x| passes included" if split_mode() else
                 "conv_igemm / conv_splitk (fp32 MFMA implicit GEMM: every conv / linear layer of the four nets)")
         if args.workload == "analyzer":

@@ -25,7 +25,7 @@ from collections import defaultdict
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from _rocprof_io import counter_rows  # noqa: E402
 
-CONV = ("ymk::conv_igemm<", "ymk::conv_splitk<", "ymk::conv_igemm_split<", "ymk::conv_f16_dma<", "ymk::conv_f16_astat<")
+CONV = ("ymk::conv_igemm<", "ymk::conv_splitk<", "ymk::conv_igemm_split<", "ymk::conv_f16_dma<", "ymk::conv_f16_astat<", "ymk::k_vit_mlp_f16<")
 
 
 def _sum(out_dir, dst):
@@ -76,7 +76,7 @@ def _traffic(fetch_csv, write_csv, dst, command):
     write = write_kb * 1024.0 / n_w
     out = {
         "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- {command}",
-        "kernels": "conv_igemm_split<*> + conv_f16_dma<*> + conv_f16_astat<*> + conv_igemm<*> + conv_splitk<*>",
+        "kernels": "conv_igemm_split<*> + conv_f16_dma<*> + conv_f16_astat<*> + k_vit_mlp_f16<*> + conv_igemm<*> + conv_splitk<*>",
         "launches": n_f,
         "launches_write_pass": n_w,
         "fetch_bytes_per_launch_as_reported": round(fetch),

@@ -20,7 +20,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from _rocprof_io import counter_rows, kernel_rows  # noqa: E402
 
-CONV = ("ymk::conv_igemm<", "ymk::conv_splitk<", "ymk::conv_igemm_split<", "ymk::conv_f16_dma<", "ymk::conv_f16_astat<")
+CONV = ("ymk::conv_igemm<", "ymk::conv_splitk<", "ymk::conv_igemm_split<", "ymk::conv_f16_dma<", "ymk::conv_f16_astat<", "ymk::k_vit_mlp_f16<")
 
 
 def _is_conv(name):
@@ -75,7 +75,7 @@ def traffic_report(roof, launches, tail, fetch_dir, write_dir, out_path):
         **_bench_stamp(),
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --roofline-only "
                   "--no-cpu-baseline; conv dispatches of the timed serial pass only",
-        "kernels": "conv_igemm_split<*> + conv_f16_dma<*> + conv_f16_astat<*> + conv_igemm<*> + conv_splitk<*>", "launches": launches,
+        "kernels": "conv_igemm_split<*> + conv_f16_dma<*> + conv_f16_astat<*> + k_vit_mlp_f16<*> + conv_igemm<*> + conv_splitk<*>", "launches": launches,
         "conv_dispatches_in_fetch_pass": n_f, "conv_dispatches_in_write_pass": n_w,
         "fetch_bytes_per_launch_as_reported": round(fetch), "write_bytes_per_launch": round(write),
         "hbm_bytes_per_launch": round(2.0 * fetch + write),

@@ -916,7 +916,8 @@ bool vit_mlp_split_launch(hipStream_t s, SplitCtx* ctx, float* x, int M, int ld,
   k.b2 = fc2.bias;
   k.g_bound = fc1.pl_a * ln_bound + fc1.pl_b;  // |GELU(v)| <= |v| <= pl_a max|LayerNorm output| + pl_b
   char desc[160];
-  snprintf(desc, sizeof desc, "M=%7d Cin=%4d Cout=%4d k=1x1 s=1 d=1 res=1 tile=128x%d ksplit=163 grid=%d vit-mlp-fused(F=%d)", M, D, D, D, (M + 127) / 128, F);
+  // (the by-layer tools parse this line: the fused layer shows as M x D -> D with a residual on a 128 x D tile, ksplit 163)
+  snprintf(desc, sizeof desc, "M=%7d Cin=%4d Cout=%4d k=1x1 s=1 d=1 res=1 tile=128x%d ksplit=163 grid=%d", M, D, D, D, (M + 127) / 128);
   // algorithmic work of the fused layer: both products; bytes: the rows in and out, the residual read, the two weight matrices
   auto* e = conv_prof_open_raw(s, desc, 4.0 * (double)M * D * F, 4.0 * (3.0 * (double)M * D + 2.0 * (double)D * F), 3.0);
   const bool taken = vit_mlp_f16_launch(s, k, D, F);

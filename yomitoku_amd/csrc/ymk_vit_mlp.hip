@@ -60,20 +60,64 @@ __device__ __forceinline__ void mlp_split8(const f32x4 u, const f32x4 v, float s
   lo = mlp_h8{l[0].x, l[0].y, l[1].x, l[1].y, l[2].x, l[2].y, l[3].x, l[3].y};
 }
 
+// gelu_f32 (ymk_common.h) on four values at once, written on vectors so that the multiplies and fused multiply-adds become
+// packed instructions (v_pk_mul_f32 / v_pk_fma_f32: two values per issue slot); the same arithmetic per value.
+__device__ __forceinline__ f32x4 gelu_f32x4(const f32x4 v) {
+  f32x4 z, t, e;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) z[i] = fabsf(v[i]);
+  z = z * 0.70710678118654752440f;
+  const f32x4 d = z * 0.39032074649205456f + 1.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t[i] = __builtin_amdgcn_rcpf(d[i]);
+  f32x4 q = t * -0.22690855651422961f + 0.8816638035254636f;
+  q = q * t + -0.6277749224408846f;
+  q = q * t + 0.6443424378640197f;
+  q = q * t + 0.09342759526711675f;
+  q = q * t + 0.23524963446014596f;
+  const f32x4 w = z * z * -1.4426950408889634f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(w[i]);
+  const f32x4 r = 1.f - (t * q) * e;  // erf(|v| / sqrt 2)
+  const f32x4 hv = v * 0.5f;
+  f32x4 out;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[i] = fmaf(hv[i], copysignf(r[i], v[i]), hv[i]);
+  return out;
+}
+
+__device__ __forceinline__ mlp_f2 gelu_f32x2(const mlp_f2 v) {  // the same on a pair
+  mlp_f2 z = {fabsf(v.x), fabsf(v.y)};
+  z = z * 0.70710678118654752440f;
+  const mlp_f2 d = z * 0.39032074649205456f + 1.f;
+  const mlp_f2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  mlp_f2 q = t * -0.22690855651422961f + 0.8816638035254636f;
+  q = q * t + -0.6277749224408846f;
+  q = q * t + 0.6443424378640197f;
+  q = q * t + 0.09342759526711675f;
+  q = q * t + 0.23524963446014596f;
+  const mlp_f2 w = z * z * -1.4426950408889634f;
+  const mlp_f2 e = {__builtin_amdgcn_exp2f(w.x), __builtin_amdgcn_exp2f(w.y)};
+  const mlp_f2 r = 1.f - (t * q) * e;  // erf(|v| / sqrt 2)
+  const mlp_f2 hv = v * 0.5f;
+  return mlp_f2{fmaf(hv.x, copysignf(r.x, v.x), hv.x), fmaf(hv.y, copysignf(r.y, v.y), hv.y)};
+}
+
 // KT = D / 32 (the model width in 32-channel tiles), NCH = F / 32 (hidden chunks)
 template <int KT, int NCH>
 __global__ __launch_bounds__(256, 1) void k_vit_mlp_f16(MlpK p) {
   constexpr int D = 32 * KT, F = 32 * NCH;
   constexpr int W1_B = KT * 4096;  // a chunk of fc1 in LDS: KT K-tiles x [32 hidden rows][128 B]
   constexpr int W2_B = D * 128;    // a chunk of fc2 in LDS: [D output rows][128 B] (one 32-hidden tile)
-  constexpr int STAGE = W1_B + W2_B;
-  constexpr int NST = 3;
+  constexpr int N1 = 2, N2 = 3;    // ring depths: fc1's slab of chunk k is read ONE iteration before chunk k's turn, fc2's one AFTER
+  constexpr int RING2 = N1 * W1_B;  // byte offset of the fc2 ring
+  constexpr int TAB = RING2 + N2 * W2_B;
   constexpr int TAB_B = 2 * F * 4;  // fc1's scale and bias vectors, read per chunk by every lane
-  constexpr int NDMA = (KT * 4 + D / 8) / 4;  // LDS-DMA instructions per wave per chunk (each moves 1 KB)
-  static_assert((KT * 4) % 4 == 0 && (D / 8) % 4 == 0, "the chunk's DMA instructions divide among four waves");
-  static_assert(NST * STAGE + TAB_B <= 160 * 1024, "LDS");
-  __shared__ __attribute__((aligned(16))) char lds[NST * STAGE + TAB_B];
-  float* const tab = reinterpret_cast<float*>(lds + NST * STAGE);  // [F] scale | [F] bias
+  constexpr int NDMA = (KT * 4 + D / 8) / 4;  // LDS-DMA instructions per wave per iteration (each moves 1 KB)
+  static_assert((KT * 4) % 4 == 0 && (D / 8) % 4 == 0, "the slabs' DMA instructions divide among four waves");
+  static_assert(TAB + TAB_B <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(16))) char lds[TAB + TAB_B];
+  float* const tab = reinterpret_cast<float*>(lds + TAB);  // [F] scale | [F] bias
 
   const int t = threadIdx.x, wv = t >> 6, lane = t & 63, li = lane & 31, lh = lane >> 5;
   const float2 sx = f16_plane_scales(__float_as_uint(p.ln_bound));
@@ -86,23 +130,27 @@ __global__ __launch_bounds__(256, 1) void k_vit_mlp_f16(MlpK p) {
   const __amdgpu_buffer_rsrc_t rsrc_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.w1), 0, p.w1_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.w2), 0, p.w2_bytes, 0x00020000);
   const int jr = lane >> 3, js = lane & 7;
-  auto issue = [&](int c, int st) {
-    char* base = lds + st * STAGE;
+  auto issue1 = [&](int c, int slot) {  // fc1's slab of chunk c: instruction i = wv + 4 q of KT * 4 - K tile i >> 2, rows 8 (i & 3) .. + 7
+    char* base = lds + slot * W1_B;
 #pragma unroll
-    for (int q = 0; q < KT; ++q) {  // fc1: instruction i = wv + 4 q of KT * 4: K tile i >> 2, rows 8 (i & 3) .. + 7 of the chunk
+    for (int q = 0; q < KT; ++q) {
       const int i = wv + 4 * q, kt = i >> 2, row = 8 * (i & 3) + jr;
       const unsigned off = (unsigned)(32 * c + row) * (unsigned)(KT * 128) + (unsigned)(kt * 128) + (unsigned)((js ^ ((row >> 1) & 7)) * 16);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w1, (mlp_lds_void*)(base + kt * 4096 + (8 * (i & 3)) * 128), 16, (int)off, 0, 0, 0);
     }
+  };
+  auto issue2 = [&](int c, int slot) {  // fc2's slab of chunk c: instruction i = wv + 4 q of D / 8 - output rows 8 i .. + 7, K tile c
+    char* base = lds + RING2 + slot * W2_B;
 #pragma unroll
-    for (int q = 0; q < D / 32; ++q) {  // fc2: instruction i = wv + 4 q of D / 8: output rows 8 i .. + 7, K tile c
+    for (int q = 0; q < D / 32; ++q) {
       const int i = wv + 4 * q, row = 8 * i + jr;
       const unsigned off = (unsigned)row * (unsigned)(NCH * 128) + (unsigned)(c * 128) + (unsigned)((js ^ ((row >> 1) & 7)) * 16);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w2, (mlp_lds_void*)(base + W1_B + (8 * i) * 128), 16, (int)off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w2, (mlp_lds_void*)(base + (8 * i) * 128), 16, (int)off, 0, 0, 0);
     }
   };
-  issue(0, 0);
-  issue(1, 1);
+  issue1(0, 0);
+  issue1(1, 1);
+  issue2(0, 0);
 
   // fc1's scale | bias into LDS (published by the first chunk's barrier)
   for (int i = t; i < F; i += 256) {
@@ -166,67 +214,141 @@ __global__ __launch_bounds__(256, 1) void k_vit_mlp_f16(MlpK p) {
     for (int r = 0; r < 16; ++r) acc2[ct][r] = 0.f;
   const int swz = (li >> 1) & 7;  // rows li, 32 + li, .. of a slab: (row >> 1) & 7 is the same for all of them
 
-  int st = 0, stp = 2;
+  // ---- the chunk's work as EIGHT slots of nine MFMAs and six fragment reads each.  Slots 0-3: the first product of chunk c + 1
+  // (H^T = W1 . X^T: steps 3 j .. 3 j + 2 of its 2 KT k-steps, three MFMAs each - one per product term, into three
+  // accumulators so that consecutive MFMAs are independent); slots 4-7: the second product of chunk c - 1 (three column tiles
+  // of one k-step each).  The fragments of slot j + 1 are read at the START of slot j into the other half of a double buffer:
+  // one wave per SIMD has nobody to cover an LDS round trip (~130 cycles), and a fragment read issued right before its MFMA
+  // (what the compiler does left to itself: the first forms of this kernel, 1015-1048 us) stalls every MFMA for one.
+  static_assert(KT % 3 == 0, "slots of three k-steps / three column tiles");
+  constexpr int S1 = 2 * KT / 3, S2 = 2 * KT / 3, NSLOT = S1 + S2;  // 4 + 4 at KT = 6
+  auto load_slot = [&](int j, int slot1, int slot2, mlp_h8 (&f)[6]) {
+    if (j < S1) {
+      const char* W1s = lds + slot1 * W1_B + li * 128;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int step = 3 * j + u, kt = step >> 1, s = step & 1;
+        f[2 * u] = *reinterpret_cast<const mlp_h8*>(W1s + kt * 4096 + (((s * 2 + lh) ^ swz) * 16));
+        f[2 * u + 1] = *reinterpret_cast<const mlp_h8*>(W1s + kt * 4096 + (((4 + s * 2 + lh) ^ swz) * 16));
+      }
+    } else {
+      const char* W2s = lds + RING2 + slot2 * W2_B + li * 128;
+      const int jj = j - S1, s = jj / (KT / 3), ct0 = 3 * (jj % (KT / 3));
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        f[2 * u] = *reinterpret_cast<const mlp_h8*>(W2s + (ct0 + u) * 4096 + (((s * 2 + lh) ^ swz) * 16));
+        f[2 * u + 1] = *reinterpret_cast<const mlp_h8*>(W2s + (ct0 + u) * 4096 + (((4 + s * 2 + lh) ^ swz) * 16));
+      }
+    }
+  };
+  auto mfma_slot = [&](int j, const mlp_h8 (&f)[6], f32x16& h0, f32x16& h1, f32x16& h2, const mlp_h8 (&gh)[2], const mlp_h8 (&gl)[2]) {
+    if (j < S1) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int step = 3 * j + u, kt = step >> 1, s = step & 1;
+        h0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[2 * u + 1], xh[kt][s], h0, 0, 0, 0);
+        h1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[2 * u], xl[kt][s], h1, 0, 0, 0);
+        h2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[2 * u], xh[kt][s], h2, 0, 0, 0);
+      }
+    } else {
+      const int jj = j - S1, s = jj / (KT / 3), ct0 = 3 * (jj % (KT / 3));
+#pragma unroll
+      for (int u = 0; u < 3; ++u) acc2[ct0 + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl[s], f[2 * u], acc2[ct0 + u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 3; ++u) acc2[ct0 + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[s], f[2 * u + 1], acc2[ct0 + u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 3; ++u) acc2[ct0 + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[s], f[2 * u], acc2[ct0 + u], 0, 0, 0);
+    }
+  };
+
+  // Software pipeline, one wave per SIMD: iteration c issues the first product of chunk c + 1, the scale / bias / GELU / plane
+  // cut of chunk c (a sixteenth of it per MFMA pair: ~360 VALU instructions spread under 12 KT MFMAs) and the second product of
+  // chunk c - 1.
+  //   fc1 ring (2 slots): slab k is read at iteration k - 1, DMA-ed at iteration k - 2 into the slot slab k - 2 left at k - 3
+  //   fc2 ring (3 slots): slab k is read at iteration k + 1, DMA-ed at iteration k - 1 into the slot slab k - 3 left at k - 2
+  f32x16 c0, c1, c2;    // the three accumulators of the CURRENT chunk's first product
+  mlp_h8 ph[2], pl[2];  // planes of the PREVIOUS chunk's hidden values (zero before the first chunk: its product adds nothing)
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ph[s][e] = pl[s][e] = (_Float16)0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // fc1 slabs 0 and 1, fc2 slab 0
+  __builtin_amdgcn_s_barrier();
+  {  // the first chunk's first product (nothing to hide it under)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c0[r] = c1[r] = c2[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < S1; ++j) {
+      mlp_h8 f[6];
+      load_slot(j, 0, 0, f);
+      mfma_slot(j, f, c0, c1, c2, ph, pl);
+    }
+  }
+  int s1n = 1, s2p = 0, s2n = 1;  // ring slots: fc1 slab c + 1; fc2 slab c - 1 (slab 0 while c == 0: times zero planes); fc2 slab c + 1
 #pragma unroll 1
   for (int c = 0; c < NCH; ++c) {
-    // chunk c has landed once this wave's own DMAs of it have (the next chunk's may stay in flight) and every wave says so;
-    // the same barrier tells that every wave is done with the stage chunk c + 2 is about to overwrite
-    if (c + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // everything DMA-ed during the last iteration has landed once every wave's own share has; the same barrier tells that every
+    // wave is done with the slots this iteration's DMAs overwrite
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (c + 2 < NCH) issue(c + 2, stp);
-    const char* W1s = lds + st * STAGE + li * 128;
-    const char* W2s = lds + st * STAGE + W1_B + li * 128;
-
-    // ---- H^T chunk = W1[chunk] . X^T: three accumulators (one per product term) keep consecutive MFMAs independent
-    f32x16 h0, h1, h2;
+    if (c + 2 < NCH) issue1(c + 2, s1n ^ 1);
+    if (c + 1 < NCH) issue2(c + 1, s2n);
+    mlp_h8 fa[2][6];
+    load_slot(0, s1n, s2p, fa[0]);
+    // pre-activations of chunk c: register r of lane (li, lh) is hidden unit (r & 3) + 8 (r >> 2) + 4 lh
+    f32x4 v[4], a[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) h0[r] = h1[r] = h2[r] = 0.f;
+    for (int g = 0; g < 4; ++g) {  // registers 4 g .. 4 g + 3: four consecutive hidden units
+      const int hid = 32 * c + 8 * g + 4 * lh;
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(tab + hid), bi = *reinterpret_cast<const f32x4*>(tab + F + hid);
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+      for (int e = 0; e < 4; ++e) v[g][e] = (c0[4 * g + e] + c1[4 * g + e]) + c2[4 * g + e];
+      v[g] = v[g] * sc + bi;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 n0, n1, n2;
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const mlp_h8 wh = *reinterpret_cast<const mlp_h8*>(W1s + kt * 4096 + (((s * 2 + lh) ^ swz) * 16));
-        const mlp_h8 wl = *reinterpret_cast<const mlp_h8*>(W1s + kt * 4096 + (((4 + s * 2 + lh) ^ swz) * 16));
-        h0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[kt][s], h0, 0, 0, 0);
-        h1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[kt][s], h1, 0, 0, 0);
-        h2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[kt][s], h2, 0, 0, 0);
-      }
-    // ---- scale, bias, GELU, planes: register r of lane (li, lh) is hidden unit (r & 3) + 8 (r >> 2) + 4 lh of the chunk
+    for (int r = 0; r < 16; ++r) n0[r] = n1[r] = n2[r] = 0.f;
     mlp_h8 gh[2], gl[2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      f32x4 a[2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {  // registers 8 s + 4 q .. + 3: four consecutive hidden units
-        const int hid = 32 * c + 8 * (2 * s + q) + 4 * lh;
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(tab + hid), bi = *reinterpret_cast<const f32x4*>(tab + F + hid);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 8 * s + 4 * q + e;
-          a[q][e] = gelu_f32(((h0[r] + h1[r]) + h2[r]) * sc[e] + bi[e]);
-        }
-      }
-      mlp_split8(a[0], a[1], sg.x, gh[s], gl[s]);
-    }
-    // ---- out += G[chunk] . W2[chunk]^T over the D / 32 column tiles
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      mlp_h8 bh[KT], bl[KT];
-#pragma unroll
-      for (int ct = 0; ct < KT; ++ct) {
-        bh[ct] = *reinterpret_cast<const mlp_h8*>(W2s + ct * 4096 + (((s * 2 + lh) ^ swz) * 16));
-        bl[ct] = *reinterpret_cast<const mlp_h8*>(W2s + ct * 4096 + (((4 + s * 2 + lh) ^ swz) * 16));
+    for (int j = 0; j < NSLOT; ++j) {
+      if (j + 1 < NSLOT) load_slot(j + 1, s1n, s2p, fa[(j + 1) & 1]);  // (the last iteration multiplies a stale fc1 slab: no branch)
+      mfma_slot(j, fa[j & 1], n0, n1, n2, ph, pl);
+      {  // GELU of two of the sixteen values per slot (packed pairs); the plane cut once eight are through
+        const int g = j >> 1, e0 = 2 * (j & 1);
+        const mlp_f2 pair = gelu_f32x2(mlp_f2{v[g][e0], v[g][e0 + 1]});
+        a[g][e0] = pair.x;
+        a[g][e0 + 1] = pair.y;
+        if (j == NSLOT / 2 - 1) mlp_split8(a[0], a[1], sg.x, gh[0], gl[0]);
+        if (j == NSLOT - 1) mlp_split8(a[2], a[3], sg.x, gh[1], gl[1]);
       }
 #pragma unroll
-      for (int ct = 0; ct < KT; ++ct) acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl[s], bh[ct], acc2[ct], 0, 0, 0);
-#pragma unroll
-      for (int ct = 0; ct < KT; ++ct) acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[s], bl[ct], acc2[ct], 0, 0, 0);
-#pragma unroll
-      for (int ct = 0; ct < KT; ++ct) acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[s], bh[ct], acc2[ct], 0, 0, 0);
+      for (int i = 0; i < 9; ++i) {  // inside a slot: an MFMA, then its share of the slot's VALU work
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    st = st == NST - 1 ? 0 : st + 1;
-    stp = stp == NST - 1 ? 0 : stp + 1;
+    c0 = n0;
+    c1 = n1;
+    c2 = n2;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      ph[s] = gh[s];
+      pl[s] = gl[s];
+    }
+    s1n ^= 1;
+    s2p = c == 0 ? 0 : (s2p == N2 - 1 ? 0 : s2p + 1);
+    s2n = s2n == N2 - 1 ? 0 : s2n + 1;
+  }
+  {  // the last chunk's second product
+    f32x16 d0, d1, d2;
+#pragma unroll
+    for (int j = S1; j < NSLOT; ++j) {
+      mlp_h8 f[6];
+      load_slot(j, 0, s2p, f);
+      mfma_slot(j, f, d0, d1, d2, ph, pl);
+    }
   }
 
   // ---- epilogue: out[row][col] = x[row][col] + acc * (1 / scale of the hidden planes) * s2[col] + b2[col]; accumulator
