@@ -3,8 +3,9 @@ same accumulation order wherever the arithmetic is meant to be identical; fp32-g
 
   * "astat": chip-filling pointwise layers with K <= 256 on the A-stationary kernel (ymk_conv_astat.hip) - the same bits as
     the register-staged kernel (tests/test_conv_astat_gpu.py checks the operator; here: whole nets, routing on / off);
-  * "parseq_no_ln_fusion": the ViT blocks' LayerNorms folded into the operand load of q|k|v and fc1
-    (models/layers/parseq_transformer.py:188-204) against LayerNorm as its own launch;
+  * "parseq_no_ln_fusion" / "parseq_no_mlp_fusion": the ViT blocks' LayerNorms folded into the operand load of q|k|v and fc1,
+    and the whole MLP half (norm2 -> fc1 -> GELU -> fc2 -> + residual) as one launch (models/layers/parseq_transformer.py:
+    188-204) against LayerNorm and the two GEMMs as launches of their own;
   * "act_planes": the tensor between a bottleneck's 1 x 1 reduction and its 3 x 3 convolution stored as fp16 planes under a
     bound (models/dbnet_plus.py:33-38, rtdetr_backbone.py) against fp32 activations.
 
@@ -83,24 +84,31 @@ def test_parseq_layernorm_fusion_and_astat_routing_on_and_off(dev):
     sd = parseq_state_dict(1235, eos_bias=5.5)
     _, net = _net(dev, sd)
     x = synthetic_line_batch(29, 128, 256).to(dev)  # 32 768 token rows: every encoder GEMM fills the chip
-    a0, f0 = _lib.stat("astat_launches"), _lib.stat("ln_fused_launches")
+    keys = ("astat_launches", "ln_fused_launches", "mlp_fused_launches")
+    before = {k: _lib.stat(k) for k in keys}
     fused = net(x).cpu()
     steps = net.last_ar_steps
-    n_astat, n_fused = _lib.stat("astat_launches") - a0, _lib.stat("ln_fused_launches") - f0
-    assert n_fused == 24 and n_astat >= 36, (n_astat, n_fused)  # 12 blocks x (qkv, fc1) fused; proj on the same kernel
-    with _Option("parseq_no_ln_fusion", 1, 0):
+    n = {k: _lib.stat(k) - before[k] for k in keys}
+    # twelve blocks: norm1 inside qkv's operand load, the MLP half as one launch, proj (and K|V, the head) on the A-stationary kernel
+    assert n["ln_fused_launches"] == 12 and n["mlp_fused_launches"] == 12 and n["astat_launches"] >= 24, n
+    with _Option("parseq_no_mlp_fusion", 1, 0):
         f1 = _lib.stat("ln_fused_launches")
+        three_launches = net(x).cpu()
+        assert _lib.stat("ln_fused_launches") - f1 == 24 and net.last_ar_steps == steps  # norm2 now inside fc1's operand load
+    with _Option("parseq_no_mlp_fusion", 1, 0), _Option("parseq_no_ln_fusion", 1, 0):
+        f2, m2 = _lib.stat("ln_fused_launches"), _lib.stat("mlp_fused_launches")
         unfused = net(x).cpu()
-        assert _lib.stat("ln_fused_launches") == f1 and net.last_ar_steps == steps
-    with _Option("astat", 0, 1), _Option("parseq_no_ln_fusion", 1, 0):
-        a1 = _lib.stat("astat_launches")
-        staged = net(x).cpu()
-        assert _lib.stat("astat_launches") == a1 and net.last_ar_steps == steps
-    # routing alone changes no bit (same planes, same products, same order per accumulator); the fusion changes the
-    # normalised rows by the rounding of one fp32 expression at most (same formula, same order: usually nothing)
+        assert _lib.stat("ln_fused_launches") == f2 and _lib.stat("mlp_fused_launches") == m2 and net.last_ar_steps == steps
+        with _Option("astat", 0, 1):
+            a1 = _lib.stat("astat_launches")
+            staged = net(x).cpu()
+            assert _lib.stat("astat_launches") == a1 and net.last_ar_steps == steps
+    # routing alone changes no bit (same planes, same products, same order per accumulator); the fusions change the
+    # normalised rows by the rounding of one fp32 expression and the hidden planes' scale (a bound instead of the maximum)
     assert torch.equal(unfused, staged), (unfused - staged).abs().max().item()
-    assert torch.equal(fused.argmax(-1), unfused.argmax(-1))
-    assert (fused - unfused).abs().max().item() < 1e-4
+    for other in (three_launches, unfused):
+        assert torch.equal(fused.argmax(-1), other.argmax(-1))
+        assert (fused - other).abs().max().item() < 1e-4
 
 
 def test_whole_pages_with_every_route_on_and_off(dev):
@@ -113,10 +121,10 @@ def test_whole_pages_with_every_route_on_and_off(dev):
 
     an = _analyzer()
     pages = [synthetic_page_with_truth(70 + i, 1200, 1600)[0] for i in range(4)]
-    c0 = {k: _lib.stat(k) for k in ("astat_launches", "ln_fused_launches", "planes_read_launches")}
+    c0 = {k: _lib.stat(k) for k in ("astat_launches", "ln_fused_launches", "planes_read_launches")}  # (four pages: below the fused MLP's 256 row blocks)
     on = [r.model_dump() for r in an.serve(pages, wave=4, in_flight=1)]
     assert all(_lib.stat(k) > v for k, v in c0.items()), c0
-    with _Option("astat", 0, 1), _Option("parseq_no_ln_fusion", 1, 0), _Option("act_planes", 0, 1):
+    with _Option("astat", 0, 1), _Option("parseq_no_ln_fusion", 1, 0), _Option("parseq_no_mlp_fusion", 1, 0), _Option("act_planes", 0, 1):
         off = [r.model_dump() for r in an.serve(pages, wave=4, in_flight=1)]
     an.close()
     assert sum(len(p["words"]) for p in on) > 0

@@ -65,7 +65,7 @@ def test_parseq_with_a_layernorm_gain_outlier_and_a_loud_qkv_row(dev):
     net.close()
     print("records checked", chk.checked, "below", chk.below, "loose", chk.loose, "max|logit|", float(ref.abs().max()),
           "split vs oracle", float((out - ref).abs().max()), "exact vs oracle", float((exact - ref).abs().max()))
-    assert chk.checked >= 25 and chk.below == 0  # (launches that carry their LayerNorm have no tensor to re-measure)
+    assert chk.checked >= 10 and chk.below == 0  # (a launch that carries its LayerNorm, or the whole MLP, has no input tensor to re-measure)
     assert got_steps == exact_steps == steps and out.shape == ref.shape
     assert torch.equal(out.argmax(-1), exact.argmax(-1)), "the fp16 planes moved a token the exact-fp32 kernels decode"
     assert torch.equal(out.argmax(-1), ref.argmax(-1))
