@@ -11,6 +11,8 @@ import torch
 from yomitoku_amd import _lib
 
 dev = torch.device("cuda:0")
+if os.environ.get("YMK_LIB"):  # another build of the library (tools/jobs: the ablation builds of one kernel)
+    _lib.LIB_PATH = os.path.abspath(os.environ["YMK_LIB"])
 lib = _lib.load()
 # (name, n, h, w, cin, cout, k, stride, pad, dil, act, residual)
 SHAPES = [
