@@ -185,6 +185,7 @@ def test_file_reads_back_with_image_and_searchable_strings(tmp_path):
     assert b"/Subtype /Type0" in font and b"/Encoding /Identity-H" in font
     cmap = pages[0]["objs"][_ref(font, "ToUnicode")][1].decode("ascii")
     assert "<3000> <30FF> <3000>" in cmap and cmap.count("beginbfrange") == 3 and "<0000> <FFFF>" in cmap
+    assert "<D800>" not in cmap and "beginbfchar" not in cmap  # no character beyond the BMP in these pages: the block stays unmapped
     cid = pages[0]["objs"][int(re.search(rb"/DescendantFonts \[(\d+) 0 R\]", font).group(1))][0]
     assert b"/DW 1000" in cid and b"/W [0 4351 500 65377 65500 500 65512 65518 500]" in cid
 
@@ -211,3 +212,53 @@ def test_empty_job_and_page_without_words():
     doc = DocumentAnalyzerSchema(paragraphs=[], tables=[], words=[], figures=[])
     page, = _pages(searchable_pdf_bytes([np.zeros((40, 60, 3), np.uint8)], [doc]))
     assert page["box"] == [0, 0, 60, 40] and _strings(page["content"]) == []
+
+
+def _to_unicode_map(cmap: str) -> dict:
+    """code -> string, from the bfrange (<lo> <hi> <first>) and bfchar (<code> <utf-16-be>) sections of a ToUnicode CMap."""
+    table = {}
+    for body in re.findall(r"beginbfrange\n(.*?)\nendbfrange", cmap, re.S):
+        for lo, hi, first in re.findall(r"<([0-9A-F]{4})> <([0-9A-F]{4})> <([0-9A-F]{4})>", body):
+            for k in range(int(hi, 16) - int(lo, 16) + 1):
+                table[int(lo, 16) + k] = chr(int(first, 16) + k)
+    for body in re.findall(r"beginbfchar\n(.*?)\nendbfchar", cmap, re.S):
+        for code, dst in re.findall(r"<([0-9A-F]{4})> <([0-9A-F]+)>", body):
+            table[int(code, 16)] = bytes.fromhex(dst).decode("utf-16-be")
+    return table
+
+
+def test_characters_beyond_the_bmp_copy_back_whole():
+    """A CJK Extension B kanji (U+20BB7, the "tsuchiyoshi" of Yoshinoya), U+2000B and an emoji among BMP text, on two pages
+    of one file: each gets ONE 2-byte code of the surrogate block, the same code wherever it appears, and the ToUnicode map
+    gives the character back whole - where UTF-16 code units as codes would map to two lone surrogates."""
+    quad = [[100, 100], [700, 100], [700, 160], [100, 160]]
+
+    def doc(text):
+        return DocumentAnalyzerSchema(paragraphs=[ParagraphSchema(box=[50, 50, 900, 400], contents="", direction="horizontal", order=0, role=None)],
+                                      tables=[], figures=[],
+                                      words=[WordPrediction(points=quad, content=text, direction="horizontal", rec_score=1.0, det_score=1.0)])
+
+    texts = ["\U00020BB7野家で\U0002000B", "丼\U0001F35A と \U00020BB7"]
+    image = Image.fromarray(np.full((500, 1000, 3), 255, np.uint8))
+    pages = _pages(searchable_pdf_bytes([image, image], [doc(t) for t in texts], "high"))
+    font = pages[0]["font"]
+    assert pages[1]["font"] == font
+    cmap = pages[0]["objs"][_ref(font, "ToUnicode")][1].decode("ascii")
+    table = _to_unicode_map(cmap)
+    assert cmap.count("beginbfchar") == 1 and "3 beginbfchar" in cmap
+    assert table[0xD800] == "\U00020BB7" and table[0xD801] == "\U0002000B" and table[0xD802] == "\U0001F35A"
+    assert 0xD803 not in table and table[0x91CE] == "野"
+    for page, text in zip(pages, texts):
+        hexes = re.findall(r"Tm <([0-9A-F]*)> Tj", page["content"])
+        assert len(hexes) == 1 and len(hexes[0]) == 4 * len(text)  # one 2-byte code per CHARACTER
+        codes = [int(hexes[0][i : i + 4], 16) for i in range(0, len(hexes[0]), 4)]
+        assert "".join(table[c] for c in codes) == text
+    # the width model counts such a character as wide (one em), as the /DW of the font does
+    assert string_width("\U00020BB7", 10) == 10
+
+
+def test_a_lone_surrogate_in_the_input_becomes_the_replacement_character():
+    from yomitoku_amd.utils.searchable_pdf import _hex_codes
+
+    sup = {}
+    assert _hex_codes("a\ud800b", sup) == "0061FFFD0062" and sup == {}

@@ -11,8 +11,12 @@ a dependency here: this module writes the PDF itself.
 
   * the image: a JPEG (the reference's three quality presets) as a DCTDecode XObject filling the page, one pixel = one point;
   * the text: rendering mode 3 (neither filled nor stroked - the reference fills with alpha 0), a composite font that is not
-    embedded (no glyph is ever drawn), Identity-H codes = UTF-16 code units, and a ToUnicode CMap that maps every code to
-    itself - so search / copy give back exactly the recognised strings in any viewer, whichever face it substitutes;
+    embedded (no glyph is ever drawn), Identity-H codes = the characters' BMP code points, and a ToUnicode CMap that maps
+    every code to itself - so search / copy give back exactly the recognised strings in any viewer, whichever face it
+    substitutes.  A character beyond the BMP (a CJK Extension B kanji, say) has no 2-byte code point: it gets a code from the
+    surrogate block U+D800..DFFF - which no text uses - in order of first appearance in the document, and a `bfchar` entry
+    that maps that one code to the character's UTF-16 pair (two codes that each map to a lone surrogate, which is what
+    writing the UTF-16 code units would produce, copy as garbage);
   * widths: one em for everything from U+1100 up except the half-width forms, half an em below - the model `string_width`
     uses to choose the font size and the /W array the viewer uses to place the selection, so the two agree (the reference
     asks the TrueType face for its advance widths; with an invisible layer only the selection rectangle depends on them).
@@ -181,16 +185,36 @@ def _num(v: float) -> str:
     return "0" if s in ("", "-0") else s
 
 
-def _hex_utf16(text: str) -> str:
-    return text.encode("utf-16-be").hex().upper()
+SUPPLEMENTARY_BASE, SUPPLEMENTARY_SLOTS = 0xD800, 0x800  # the codes handed to characters beyond the BMP
 
 
-def _to_unicode_cmap() -> bytes:
-    rows = [f"<{hi:02X}00> <{hi:02X}FF> <{hi:02X}00>" for hi in range(256)]
+def _hex_codes(text: str, supplementary: dict) -> str:
+    """The 2-byte codes of `text` as a hex string; `supplementary` (character -> code) grows as new ones appear."""
+    out = []
+    for ch in text:
+        cp = ord(ch)
+        if 0xD800 <= cp <= 0xDFFF:  # a lone surrogate in the input: not a character
+            cp = 0xFFFD
+        elif cp > 0xFFFF:
+            if ch not in supplementary:
+                if len(supplementary) >= SUPPLEMENTARY_SLOTS:
+                    raise ValueError(f"more than {SUPPLEMENTARY_SLOTS} distinct characters beyond the BMP in one PDF")
+                supplementary[ch] = SUPPLEMENTARY_BASE + len(supplementary)
+            cp = supplementary[ch]
+        out.append(f"{cp:04X}")
+    return "".join(out)
+
+
+def _to_unicode_cmap(supplementary: dict) -> bytes:
+    rows = [f"<{hi:02X}00> <{hi:02X}FF> <{hi:02X}00>" for hi in range(256) if not 0xD8 <= hi <= 0xDF]
     blocks = []
-    for k in range(0, 256, 100):
+    for k in range(0, len(rows), 100):
         part = rows[k : k + 100]
         blocks.append(f"{len(part)} beginbfrange\n" + "\n".join(part) + "\nendbfrange")
+    chars = [f"<{code:04X}> <{ch.encode('utf-16-be').hex().upper()}>" for ch, code in sorted(supplementary.items(), key=lambda kv: kv[1])]
+    for k in range(0, len(chars), 100):
+        part = chars[k : k + 100]
+        blocks.append(f"{len(part)} beginbfchar\n" + "\n".join(part) + "\nendbfchar")
     return ("/CIDInit /ProcSet findresource begin\n12 dict begin\nbegincmap\n"
             "/CIDSystemInfo << /Registry (Adobe) /Ordering (UCS) /Supplement 0 >> def\n"
             "/CMapName /Adobe-Identity-UCS def\n/CMapType 2 def\n"
@@ -240,25 +264,28 @@ class _PdfFile:
         return out.getvalue()
 
 
-def _font_objects(pdf: _PdfFile) -> int:
+def _font_objects(pdf: _PdfFile, font: int, supplementary: dict):
+    """The composite font into the reserved object `font` - written after the pages, when every character beyond the BMP has
+    its code."""
     descriptor = pdf.add((f"<< /Type /FontDescriptor /FontName /{FONT_NAME} /Flags 4 /FontBBox [0 -120 1000 880] /ItalicAngle 0 "
                           "/Ascent 880 /Descent -120 /CapHeight 880 /StemV 80 >>").encode("ascii"))
-    # /DW 1000: one em; the narrow ranges of _is_narrow at half an em (codes are UTF-16 code units = BMP code points)
+    # /DW 1000: one em (the codes of the surrogate block included: characters beyond the BMP are wide); the narrow ranges of
+    # _is_narrow at half an em
     cid = pdf.add((f"<< /Type /Font /Subtype /CIDFontType2 /BaseFont /{FONT_NAME} "
                    "/CIDSystemInfo << /Registry (Adobe) /Ordering (Identity) /Supplement 0 >> "
                    f"/FontDescriptor {descriptor} 0 R /DW 1000 /W [0 4351 500 65377 65500 500 65512 65518 500] >>").encode("ascii"))
-    to_unicode = pdf.add_stream("", _to_unicode_cmap(), compress=True)
-    return pdf.add((f"<< /Type /Font /Subtype /Type0 /BaseFont /{FONT_NAME} /Encoding /Identity-H "
-                    f"/DescendantFonts [{cid} 0 R] /ToUnicode {to_unicode} 0 R >>").encode("ascii"))
+    to_unicode = pdf.add_stream("", _to_unicode_cmap(supplementary), compress=True)
+    pdf.put(font, (f"<< /Type /Font /Subtype /Type0 /BaseFont /{FONT_NAME} /Encoding /Identity-H "
+                   f"/DescendantFonts [{cid} 0 R] /ToUnicode {to_unicode} 0 R >>").encode("ascii"))
 
 
-def _content_stream(width: int, height: int, ops: Sequence) -> bytes:
+def _content_stream(width: int, height: int, ops: Sequence, supplementary: dict) -> bytes:
     lines = [f"q {width} 0 0 {height} 0 0 cm /Im0 Do Q", "BT", "3 Tr"]
     for op in ops:
         if op[0] == "font":
             lines.append(f"/F1 {_num(op[1])} Tf")
         elif op[7]:
-            lines.append(" ".join(_num(v) for v in op[1:7]) + f" Tm <{_hex_utf16(op[7])}> Tj")
+            lines.append(" ".join(_num(v) for v in op[1:7]) + f" Tm <{_hex_codes(op[7], supplementary)}> Tj")
     lines.append("ET")
     return ("\n".join(lines) + "\n").encode("ascii")
 
@@ -287,8 +314,8 @@ def _scaled_document(doc, scale: float):
 
 def searchable_pdf_bytes(images: Sequence, docs: Sequence, image_quality: str = "high") -> bytes:
     pdf = _PdfFile()
-    root, pages = pdf.reserve(), pdf.reserve()
-    font = _font_objects(pdf)
+    root, pages, font = pdf.reserve(), pdf.reserve(), pdf.reserve()
+    supplementary: dict = {}
     kids = []
     preset = IMAGE_QUALITY_PRESETS.get(image_quality, IMAGE_QUALITY_PRESETS["high"])
     for image, doc in zip(images, docs):
@@ -306,9 +333,10 @@ def searchable_pdf_bytes(images: Sequence, docs: Sequence, image_quality: str = 
         w, h = image.size
         xobject = pdf.add_stream(f"/Type /XObject /Subtype /Image /Width {w} /Height {h} /ColorSpace /Device{'Gray' if grey else 'RGB'} "
                                  "/BitsPerComponent 8 /Filter /DCTDecode", jpeg.getvalue(), compress=False)
-        contents = pdf.add_stream("", _content_stream(w, h, text_layer(_scaled_document(doc, scale), h)), compress=True)
+        contents = pdf.add_stream("", _content_stream(w, h, text_layer(_scaled_document(doc, scale), h), supplementary), compress=True)
         kids.append(pdf.add((f"<< /Type /Page /Parent {pages} 0 R /MediaBox [0 0 {w} {h}] /Contents {contents} 0 R "
                              f"/Resources << /XObject << /Im0 {xobject} 0 R >> /Font << /F1 {font} 0 R >> >> >>").encode("ascii")))
+    _font_objects(pdf, font, supplementary)
     pdf.put(pages, (f"<< /Type /Pages /Count {len(kids)} /Kids [" + " ".join(f"{k} 0 R" for k in kids) + "] >>").encode("ascii"))
     pdf.put(root, f"<< /Type /Catalog /Pages {pages} 0 R >>".encode("ascii"))
     return pdf.tobytes(root)
