@@ -49,6 +49,10 @@ import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / f16 MFMA (v_mfma_f32_32x32x16_f16)
+# what the chip holds under back-to-back 16-bit MFMAs and nothing else: 32 cycles per v_mfma_f32_32x32x16_f16 at the 1.74 GHz
+# it clocks down to (tools/diag/mfma_valu_overlap.hip, profiles/r05_conv_dma_ablation.md): 256 CUs x 4 x 1024 FLOP/clock.
+# Reported NEXT to the guide's peak, never instead of it.
+F16_MFMA_SUSTAINED_TFLOPS = 1820.0
 HBM_PEAK_GBS, HBM_ACHIEVABLE_GBS = 8000.0, 6290.0  # MI355X_MICROARCH.md: HBM3E spec / measured float4 copy
 # "conv_split" code (include/ymk.h) -> (16-bit MFMA products per fp32-grade product, dtype string of the bench line)
 SPLIT_MODES = {
@@ -401,6 +405,10 @@ def conv_roofline(lib, run_once, units, unit_name, kernel_desc, reps=3, split=No
             "peak_note": ("dense fp32 MFMA (v_mfma_f32_32x32x2_f32)" if products == 0 else
                           f"dense 16-bit MFMA {F16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {products} MFMA products per fp32-grade product = fp32-equivalent "
                           f"TFLOP/s; the same `achieved` is {ach / FP32_MFMA_PEAK_TFLOPS:.3f} of the exact-fp32 MFMA roof (157.3) of the round-3 line")}
+    if products:
+        mfma["frac_of_sustained"] = round(ach / (F16_MFMA_SUSTAINED_TFLOPS / products), 4)
+        mfma["sustained_note"] = (f"{F16_MFMA_SUSTAINED_TFLOPS:.0f} TFLOP/s: the 16-bit MFMA rate measured with nothing but MFMAs in flight (the clock drops to "
+                                  "1.74 GHz under them; profiles/r05_conv_dma_ablation.md) - context for `frac`, which stays against the guide's peak")
     hbm = {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
            "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 4),
            "peak_note": f"HBM3E {HBM_PEAK_GBS:.0f} GB/s spec; {HBM_ACHIEVABLE_GBS:.0f} GB/s measured achievable (MI355X_MICROARCH.md); algorithmic bytes, not PMC traffic"}
