@@ -983,10 +983,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not DRY and not args.roofline_only:
         if args.workload == "analyzer":
             charset = an.text_recognizer.charset
-            times = cpu_timed(lambda i: cpu_analyzer_page(sds, pages[i % len(pages)], charset, args.model_set), 2, 3, 90.0)
+            # one page through the CPU chain costs 13 s on an idle 128-core host and 46 s on a loaded one (both seen on the
+            # gpurun boxes): one warm-up page, then timed pages until 40 s are spent - at least one, at most three
+            times = cpu_timed(lambda i: cpu_analyzer_page(sds, pages[i % len(pages)], charset, args.model_set), 1, 3, 40.0)
             sample = (f"the same synthetic pages through the oracle restatement (PyTorch-CPU fp32) of the `-d cpu` chain with the "
                       f"{args.model_set} model set: detector + recogniser + layout + table nets with their pre/post-processing (PyTorch "
-                      f"path for the detector too: onnxruntime is not installed); 2 warm-up pages, {len(times)} timed, median")
+                      f"path for the detector too: onnxruntime is not installed); 1 warm-up page, {len(times)} timed, median")
         else:
             from oracle.dbnet import dbnet_forward
 
