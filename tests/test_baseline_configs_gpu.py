@@ -241,7 +241,15 @@ def test_whole_page_schema_vs_oracle_chain(dev, page_hw):
     an.img = img
     want = DocumentAnalyzerSchema(**an.aggregate(OCRSchema(words=ocr_aggregate(det_s, rec_s)),
                                                LayoutAnalyzerSchema(paragraphs=lay.paragraphs, tables=tables, figures=lay.figures)))
-    _assert_same_schema(want.model_dump(), got.model_dump(), score_rtol=1e-3)
+    try:
+        _assert_same_schema(want.model_dump(), got.model_dump(), score_rtol=1e-3)
+    except AssertionError:  # say which elements differ before failing (the first differing leaf alone rarely tells)
+        for name, d in (("oracle side", want), ("product", got)):
+            print(name, "paragraphs", [(p.box, p.order, p.direction, p.contents[:12]) for p in d.paragraphs])
+            print(name, "tables", [(t.box, t.n_row, t.n_col, t.order, len(t.cells)) for t in d.tables])
+            print(name, "figures", [(f.box, f.order, len(f.paragraphs)) for f in d.figures])
+            print(name, "words", len(d.words), [(w.content[:8], w.direction, round(w.rec_score, 4)) for w in d.words][:40])
+        raise
     assert len(got.words) == len(quads) and sum(len(w.content) for w in got.words) > 0
     if page_hw == (1000, 1400):  # the layout net finds table boxes on this page and at least one keeps rows AND columns
         assert len(lay.tables) >= 1 and len(got.tables) >= 1 and sum(len(t.cells) for t in got.tables) >= 1

@@ -205,25 +205,25 @@ def test_document_analyzer_end_to_end(dev, page):
     assert orders == list(range(len(orders)))
 
 
-def _assert_same_schema(a, b, score_rtol=1e-4, box_tol=0):
+def _assert_same_schema(a, b, score_rtol=1e-4, box_tol=0, path="$"):
     """Two model_dump() trees: same structure, strings and integers; floats within score_rtol; integer box / point
-    coordinates within box_tol pixels."""
-    assert type(a) is type(b), (a, b)
+    coordinates within box_tol pixels.  A failure names the path of the leaf."""
+    assert type(a) is type(b), (path, a, b)
     if isinstance(a, dict):
-        assert a.keys() == b.keys()
+        assert a.keys() == b.keys(), path
         for k in a:
             if k in ("box", "points") and box_tol:
-                assert np.abs(np.asarray(a[k]) - np.asarray(b[k])).max() <= box_tol, (k, a[k], b[k])
+                assert np.abs(np.asarray(a[k]) - np.asarray(b[k])).max() <= box_tol, (f"{path}.{k}", a[k], b[k])
             else:
-                _assert_same_schema(a[k], b[k], score_rtol, box_tol)
+                _assert_same_schema(a[k], b[k], score_rtol, box_tol, f"{path}.{k}")
     elif isinstance(a, (list, tuple)):
-        assert len(a) == len(b), (len(a), len(b))
-        for x, y in zip(a, b):
-            _assert_same_schema(x, y, score_rtol, box_tol)
+        assert len(a) == len(b), (path, len(a), len(b))
+        for i, (x, y) in enumerate(zip(a, b)):
+            _assert_same_schema(x, y, score_rtol, box_tol, f"{path}[{i}]")
     elif isinstance(a, float):
-        assert abs(a - b) <= score_rtol * max(abs(a), abs(b)) + 1e-9, (a, b)
+        assert abs(a - b) <= score_rtol * max(abs(a), abs(b)) + 1e-9, (path, a, b)
     else:
-        assert a == b, (a, b)
+        assert a == b, (path, a, b)
 
 
 def test_analyze_pages_equals_per_page_calls(dev, page):

@@ -446,16 +446,16 @@ class ParseqModel : public Model {
     init_decode(s, tok, NS, state, bos_, pad_, B);  // tok[:, 0] = bos, rest pad; state = {0, 0, -1, 0}
     const int dhd = D / dh_;
     const float dscale = 1.f / std::sqrt((float)dhd);
-    // Early stop without stalling the queue: step i notes in not_done[i] whether any row still lacks an <eos> (0 / 1: rows
-    // store, they do not count - ymk_seq.hip) and publishes it to mapped pinned host memory; the host reads the flag of step
+    // Early stop without stalling the queue: step i counts the rows still lacking an <eos> into
+    // not_done[i] and publishes it to mapped pinned host memory; the host reads the flag of step
     // i - LAG, so up to LAG speculative steps are in flight.  A speculative step's greedy kernel sees
     // not_done[i-1] == 0 and leaves tokens / repetition state untouched, hence `steps` and every
     // result are exactly those of the reference's step-by-step test (models/parseq.py:245-250).
     constexpr int LAG = 2;
     YMK_HIP(hipMemsetAsync(not_done, 0, (size_t)2 * NS * sizeof(int), s));  // not_done[NS] | arrived[NS]
     int* arrived = not_done + NS;
-    // host_flags_ is mapped pinned memory a one-thread launch behind step i's greedy kernel writes
-    // (that word + 1, so 0 = "not reported yet"): no copy-engine hop, no event per step.  Only
+    // host_flags_ is mapped pinned memory the last-arriving block of step i's greedy kernel writes
+    // (count + 1, so 0 = "not reported yet"): no copy-engine hop, no event per step.  Only
     // non-speculative steps write, and all of those have completed before a forward returns.
     for (int i = 0; i < NS; ++i) host_flags_[i] = 0;
     auto wait_flag = [&](int i) -> int {
@@ -498,11 +498,12 @@ class ParseqModel : public Model {
       }
       if (ar_rowmax)
         greedy_step(s, armax, (long)2 * head_tiles, head_tiles, i, NS, tok, raw, NS, state, eos_, rep_on_, rep_pmax_, rep_p1_, rep_min_,
-                    not_done + i, i > 0 ? not_done + i - 1 : nullptr, arrived + i, nullptr, B, gid, gop, ng, 1);
+                    not_done + i, i > 0 ? not_done + i - 1 : nullptr, arrived + i, i + 1 < NS ? host_flags_dev_ + i : nullptr, B, gid,
+                    gop, ng, 1);
       else
         greedy_step(s, arlog + (size_t)i * C, (long)NS * C, C, i, NS, tok, raw, NS, state, eos_, rep_on_, rep_pmax_, rep_p1_,
-                    rep_min_, not_done + i, i > 0 ? not_done + i - 1 : nullptr, arrived + i, nullptr, B, gid, gop, ng);
-      if (i + 1 < NS) publish_open(s, not_done + i, i > 0 ? not_done + i - 1 : nullptr, host_flags_dev_ + i);  // (the last step's word is never read)
+                    rep_min_, not_done + i, i > 0 ? not_done + i - 1 : nullptr, arrived + i,
+                    i + 1 < NS ? host_flags_dev_ + i : nullptr /* the last step's count is never read */, B, gid, gop, ng);
       if (i + 1 < NS && i >= LAG && wait_flag(i - LAG) == 0) {  // every row held an <eos> after step i - LAG
         steps = i - LAG + 1;
         break;
