@@ -560,7 +560,10 @@ class SplitCtx {
   const unsigned* absmax(hipStream_t s, const ConvK& k) {
     if (!slots_) {
       slots_ = reinterpret_cast<unsigned*>(alloc(2 * AMAX_REC_WORDS * sizeof(unsigned)));
-      YMK_HIP(hipMemset(slots_, 0, 2 * AMAX_REC_WORDS * sizeof(unsigned)));
+      // ON stream s, ahead of the first k_absmax: a plain hipMemset goes to the null stream, which the callers' (non-blocking)
+      // streams do not order with - if the runtime returns before the fill has run, it can land after k_absmax has written the
+      // word, and the model's first launch then scales its operands for max|x| = 0
+      YMK_HIP(hipMemsetAsync(slots_, 0, 2 * AMAX_REC_WORDS * sizeof(unsigned), s));
     }
     // the two words alternate along ONE stream (each launch clears the other word for its successor); a context that
     // moves to another stream waits for the old one first
