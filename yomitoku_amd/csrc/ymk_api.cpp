@@ -104,6 +104,10 @@ int ymk_model_finalize(ymk_model* m) {
   YMK_CHECK(m, "null model");
   YMK_HIP(hipSetDevice(m->device));
   m->impl->finalize();
+  // finalize() uploads the weights with synchronous copies from pageable host memory and fills a few words with hipMemset: all
+  // work of the null stream, which the forwards' non-blocking streams do not order with.  Whatever the runtime's guarantee at
+  // the return of such a call (staged vs. landed), after this line every byte is in place before a first forward can start
+  YMK_HIP(hipDeviceSynchronize());
   YMK_API_END
 }
 
