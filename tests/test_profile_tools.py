@@ -197,3 +197,21 @@ def test_hbm_table_divides_bytes_by_kernel_time(tmp_path):
     cells = [c.strip() for c in rows[0].strip("|").split("|")]
     # (2 x 1e6 KB + 0.5e6 KB) x 1024 B over 1 ms = 2.56 TB/s; 256 MB per call
     assert cells[1] == "10" and cells[4] == "256.0" and cells[5] == "2.56" and cells[6] == "0.41"
+
+
+def test_stress_call_parent_names_the_runs_that_differ(tmp_path):
+    """tools/stress_call.py on stand-in children (no device): reports are larger than a pipe's buffer, two of twelve
+    'lose their tables' in their cold call - the parent must finish, name them and the stage whose cold output differed."""
+    out = str(tmp_path / "stress.json")
+    env = dict(os.environ, YMK_FAKE_BAD="3,7")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_call.py"), "--fake", "--runs", "12", "--parallel", "4", "--label", "t",
+                        "--out", out], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1, r.stderr[-500:]
+    d = json.load(open(out))
+    assert d["completed"] == 12 and d["distinct_schemas"] == 2 and d["reference_counts"]["tables"] == 1
+    assert [x["run"] for x in d["runs_with_a_different_schema"]] == [3, 7]
+    assert d["runs_with_a_different_schema"][0]["first_difference"] == ".tables: 1 != 0 entries"
+    assert d["cold_output_differs_from_warm_output_by_stage"] == {"det": 0, "lay": 0, "tab": 2, "rec": 0}
+    clean = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_call.py"), "--fake", "--runs", "5", "--parallel", "2"],
+                           capture_output=True, text=True, timeout=120)
+    assert clean.returncode == 0 and json.loads(clean.stdout)["failures"] == 0

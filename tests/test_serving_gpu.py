@@ -121,3 +121,50 @@ def test_buffers_stay_put_across_jobs(dev, imgs):
     assert [n.workspace_bytes for n in nets] == ws
     assert sum(t.numel() for t in an.text_detector.post_processor._pinned.values()) == pinned
     an.close()
+
+
+COUNTERS = ("allocs_in_forward", "arena_grows_in_forward", "lazy_panel_builds", "syncs_in_forward")
+
+
+def test_no_forward_allocates_builds_or_waits(dev, imgs):
+    """Round-5 review item 1: everything a forward needs beyond its workspace exists when ymk_model_finalize returns (split
+    weight copies, max|x| words), and the workspace is sized before the forward is entered (`ensure_workspace` /
+    `reserve_once`) - so from the first call on no forward reaches hipMalloc / hipFree / hipHostMalloc, builds a weight
+    copy or waits for a stream (include/ymk.h: ymk_stat).  Both entry points, first calls included; two lanes; a precision
+    switched per model between forwards."""
+    from yomitoku_amd import _lib
+
+    before = {k: _lib.stat(k) for k in COUNTERS}
+    an = _analyzer()
+    first = an(imgs[0])[0].model_dump()  # the two chains' first forwards, concurrently
+    again = an(imgs[0])[0].model_dump()
+    _assert_same_schema(first, again, score_rtol=0.0)
+    an(imgs[3])  # another page size
+    out = an.serve(imgs + imgs[::-1], wave=4, in_flight=2)
+    assert not any(isinstance(o, Exception) for o in out)
+    an.text_detector.model.set_conv_split(0)  # exact fp32 and back: the copies exist (finalize / set_param), nothing is rebuilt
+    an(imgs[1])
+    an.text_detector.model.set_conv_split(None)
+    an(imgs[1])
+    after = {k: _lib.stat(k) for k in COUNTERS}
+    assert after == before, {k: after[k] - before[k] for k in COUNTERS}
+    an.close()
+
+
+def test_a_bare_abi_caller_may_let_the_library_grow_the_workspace(dev):
+    """The fallback stays: a caller that never reserves (here: ensure_workspace bypassed) gets its workspace grown inside
+    the forward - counted, and the result is the same."""
+    from yomitoku_amd import _lib
+    from yomitoku_amd.nets import DBNet
+    from yomitoku_amd.utils.synth import dbnet_state_dict
+
+    net = DBNet().load_state_dict(dbnet_state_dict(1234)).to(dev)
+    x = torch.randn(1, 3, 96, 128, generator=torch.Generator().manual_seed(0)).to(dev)
+    want = net(x)["binary"].cpu()
+    grows = _lib.stat("arena_grows_in_forward")
+    net.ensure_workspace = lambda *a: None
+    y = torch.randn(2, 3, 160, 128, generator=torch.Generator().manual_seed(1)).to(dev)
+    net(y)
+    assert _lib.stat("arena_grows_in_forward") == grows + 1
+    assert torch.equal(net(x)["binary"].cpu(), want)
+    net.close()

@@ -88,6 +88,11 @@ int ymk_model_set_param(ymk_model* m, const char* key, double value) {
   YMK_API_BEGIN
   YMK_CHECK(m && key, "null argument");
   m->impl->params[key] = value;
+  const std::string k(key);
+  if (m->impl->finalized && (k == "conv_split" || k == "conv_split_encoder")) {  // a precision switched between forwards: its copies now
+    YMK_HIP(hipSetDevice(m->device));
+    m->impl->prebuild_split();
+  }
   YMK_API_END
 }
 
@@ -104,10 +109,13 @@ int ymk_model_finalize(ymk_model* m) {
   YMK_CHECK(m, "null model");
   YMK_HIP(hipSetDevice(m->device));
   m->impl->finalize();
+  // the split copies of the weight panels for the precision the model runs, and its max|x| words: built here, so that no
+  // forward ever allocates, builds or waits for them (ymk_common.h: "device allocations and the forwards")
+  m->impl->prebuild_split();
   // finalize() uploads the weights with synchronous copies from pageable host memory and fills a few words with hipMemset: all
   // work of the null stream, which the forwards' non-blocking streams do not order with.  Whatever the runtime's guarantee at
   // the return of such a call (staged vs. landed), after this line every byte is in place before a first forward can start
-  YMK_HIP(hipDeviceSynchronize());
+  if (!ymk::debug_hazard_no_finalize_sync()) YMK_HIP(hipDeviceSynchronize());
   YMK_API_END
 }
 
@@ -186,7 +194,7 @@ int ymk_stat(const char* key, int64_t* value) {
   YMK_API_BEGIN
   YMK_CHECK(key != nullptr && value != nullptr, "null argument");
   long long v = 0;
-  YMK_CHECK(ymk::conv_split_stat(std::string(key), &v), std::string("unknown counter: ") + key);
+  YMK_CHECK(ymk::conv_split_stat(std::string(key), &v) || ymk::runtime_stat(std::string(key), &v), std::string("unknown counter: ") + key);
   *value = v;
   YMK_API_END
 }
@@ -299,14 +307,13 @@ int ymk_op_conv1x1_astat(const float* x_dev, int m, int c, const float* w_host_o
     ~Events() {
       if (e0) (void)hipEventDestroy(e0);
       if (e1) (void)hipEventDestroy(e1);
-      (void)conv_split_debug_option("conv_split_tile", 0);
     }
   } ev;
   YMK_HIP(hipEventCreate(&ev.e0));
   YMK_HIP(hipEventCreate(&ev.e1));
   SplitCtxOwner split_ctx;  // the fp16 planes of this call's panel live and die with it
   ConvSplitScope scope(SPLIT_F16X2, split_ctx.get(), 0);
-  YMK_CHECK(conv_split_debug_option("conv_split_tile", 30), "conv_split_tile");  // the A-stationary kernel for whatever it can run
+  ConvSplitTileScope tile_scope(30);  // the A-stationary kernel for whatever it can run - this thread's launches only
   for (int r = 0; r < std::max(1, reps); ++r) {
     if (r == std::max(1, reps) - 1) YMK_HIP(hipEventRecord(ev.e0, s));
     if (ln_g_host) {
@@ -379,8 +386,7 @@ int ymk_op_attention(const float* q_dev, const float* k_dev, const float* v_dev,
                          (long)lk * D, (long)lk * D, (long)lq * D, scale, mask_qk_dev, lk, kpm_dev, lk);
   else if (ymk::conv_effective_split() == ymk::SPLIT_F16X2) {
     // ymk_debug_option("conv_split", 16): the fp16-split form, its three max|x| records measured here (tests)
-    unsigned* rec = nullptr;
-    YMK_HIP(hipMalloc((void**)&rec, 3 * ymk::AMAX_REC_WORDS * sizeof(unsigned)));
+    unsigned* rec = (unsigned*)ymk::dev_malloc(3 * ymk::AMAX_REC_WORDS * sizeof(unsigned));
     YMK_HIP(hipMemsetAsync(rec, 0, 3 * ymk::AMAX_REC_WORDS * sizeof(unsigned), (hipStream_t)stream));
     ymk::absmax_record((hipStream_t)stream, q_dev, (size_t)b * lq * D, rec);
     ymk::absmax_record((hipStream_t)stream, k_dev, (size_t)b * lk * D, rec + ymk::AMAX_REC_WORDS);
@@ -388,7 +394,7 @@ int ymk_op_attention(const float* q_dev, const float* k_dev, const float* v_dev,
     ymk::flash_attention((hipStream_t)stream, q_dev, k_dev, v_dev, o_dev, b, heads, lq, lk, hd, D, D, D, D, (long)lq * D,
                          (long)lk * D, (long)lk * D, (long)lq * D, scale, nullptr, rec, rec + ymk::AMAX_REC_WORDS, rec + 2 * ymk::AMAX_REC_WORDS);
     YMK_HIP(hipStreamSynchronize((hipStream_t)stream));
-    YMK_HIP(hipFree(rec));
+    ymk::dev_free(rec);
   } else
     ymk::flash_attention((hipStream_t)stream, q_dev, k_dev, v_dev, o_dev, b, heads, lq, lk, hd, D, D, D, D, (long)lq * D,
                          (long)lk * D, (long)lk * D, (long)lq * D, scale);

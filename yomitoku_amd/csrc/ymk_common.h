@@ -39,6 +39,40 @@ struct Error : public std::runtime_error {
     if (!(cond)) throw ::ymk::Error(std::string("check failed: ") + #cond + ": " + (msg)); \
   } while (0)
 
+// ---------------------------------------------------------------- device allocations and the forwards
+// Contract since round 6: a forward (ymk_*_forward) neither allocates nor frees device / pinned memory, builds no weight copy
+// and waits for no stream when the caller sized the workspace first (ymk_model_reserve) - everything a forward needs beyond
+// its workspace exists when ymk_model_finalize returns.  The fallbacks remain (a caller that never reserves, a precision
+// switched through the process-wide option after finalize) and are COUNTED: every hipMalloc / hipFree / hipHostMalloc /
+// hipHostFree of the library goes through these wrappers, a forward opens a ForwardScope, and ymk_stat reports
+//   "allocs_in_forward"      allocations + frees made while the calling thread was inside a forward
+//   "arena_grows_in_forward" of those, workspace growth (the forward's shape was not covered by a reservation)
+//   "lazy_panel_builds"      split weight copies built on first use inside a forward instead of at finalize
+//   "syncs_in_forward"       hipStreamSynchronize calls those fallbacks made
+// (tests/test_serving_gpu.py asserts zeros over a job; tools/stress_call.py records them per run)
+void* dev_malloc(size_t bytes);
+void dev_free(void* p);
+void* host_malloc_pinned(size_t bytes, unsigned flags);
+void host_free_pinned(void* p);
+void forward_sync(hipStream_t s);  // hipStreamSynchronize, counted when inside a forward
+void note_lazy_panel_build();
+void note_arena_grow();
+bool in_forward();
+struct ForwardScope {
+  ForwardScope();
+  ~ForwardScope();
+};
+bool runtime_stat(const std::string& key, long long* value);
+// diagnostics of tools/stress_call.py, read once from the environment: YMK_DEBUG_LAZY_SPLIT=1 skips the finalize-time build
+// of the split weight copies and the max|x| words (the round-5 behaviour: built inside the first forward that asks);
+// YMK_DEBUG_HAZARD_NULL_MEMSET=1 re-opens the ordering hazard closed at the end of round 5 (the max|x| words zeroed by a
+// null-stream hipMemset that the forward's non-blocking stream does not order with) - to show what it does, never for use
+// YMK_DEBUG_HAZARD_NO_FINALIZE_SYNC=1 likewise drops the device synchronisation at the end of ymk_model_finalize (the weights'
+// null-stream uploads then order with nothing a first forward does on its non-blocking stream).
+bool debug_lazy_split();
+bool debug_hazard_null_memset();
+bool debug_hazard_no_finalize_sync();
+
 // ---------------------------------------------------------------- max|x| records
 // The fp16-split convolutions scale their input by a power of two taken from max|x| over the whole input view
 // (ymk_conv_split.hip).  A producer that writes a tensor can leave that maximum behind for free: an "amax record" is 32
@@ -211,6 +245,15 @@ class ConvSplitScope {
   SplitCtx* prev_ctx_;
 };
 
+// "conv_split_tile" (ymk_conv_split.hip) for the calling thread's launches while the scope lives; 0 = no force
+class ConvSplitTileScope {
+ public:
+  explicit ConvSplitTileScope(int tile);
+  ~ConvSplitTileScope();
+ private:
+  int prev_;
+};
+
 // the "conv_split" code conv2d / gemm launches of the calling thread resolve to right now (scope, process-wide option, default)
 int conv_effective_split();
 // max|x| over n floats (n % 4 == 0, 16-byte aligned) into word 0 of the zeroed record rec (ymk_conv_split.hip; tests / tools)
@@ -297,7 +340,6 @@ class WeightStore {
   std::map<std::string, HostTensor> t_;
 };
 
-struct ConvW;
 // Device buffer pool owned by a model (weights). Freed with the model.
 class DevicePool {
  public:
@@ -306,9 +348,16 @@ class DevicePool {
   float* upload(const float* p, size_t n);
   float* alloc(size_t n);
   size_t bytes() const { return bytes_; }
+  // every packed panel of the model, as make_conv / make_linear_raw built it (a caller that patches scale / bias afterwards
+  // notes the panel again): what Model::prebuild_split builds the split copies from at finalize.  `perm`: the fc2 panels of
+  // the ViT blocks the fused MLP kernel runs, which also need the accumulator-order copy.
+  void note(const ConvW& c, bool perm = false);
+  const std::vector<ConvW>& convs() const { return convs_; }
+  const std::vector<ConvW>& perm_convs() const { return perm_; }
  private:
   std::vector<void*> ptrs_;
   size_t bytes_ = 0;
+  std::vector<ConvW> convs_, perm_;
 };
 
 // conv (+ optional BatchNorm folded to scale/bias) from a state-dict
@@ -342,6 +391,9 @@ class Model {
   // "conv_split" parameter (ymk_model_set_param; may be changed between forwards): operand precision of this model's convs
   int conv_split() const { return (int)param("conv_split", -1); }
   SplitCtxOwner split_ctx;
+  // the split copies of every noted panel for the precision(s) this model's forwards resolve to right now, and the context's
+  // max|x| words: called by ymk_model_finalize and again when "conv_split" / "conv_split_encoder" change (ymk_conv_split.hip)
+  void prebuild_split();
 };
 
 Model* create_dbnet();

@@ -529,45 +529,44 @@ class SplitCtx {
     float* scale = nullptr;  // fp16 form only: the epilogue's per-channel scale with the row's power of two taken back out
   };
   ~SplitCtx() {
-    for (void* q : allocs_) (void)hipFree(q);
+    for (void* q : allocs_) dev_free(q);
+    if (moved_) (void)hipEventDestroy(moved_);
   }
-  // split copy of panel w for `code`, built on stream s the first time it is asked for
+  // split copy of panel w for `code`.  Built at ymk_model_finalize for the precision the model runs (prebuild below); a pair
+  // that is first asked for inside a forward - the process-wide precision switched after finalize, a single-operator call -
+  // is built here on stream s, counted ("lazy_panel_builds"), and waited for
   const Panels& panels(hipStream_t s, const ConvW& w, int code) {
     const Key key{w.w, code};
     auto it = cache_.find(key);
     if (it != cache_.end()) return it->second;
-    const int ns = code == 3 ? 3 : 2;
-    const size_t rows = (size_t)((w.cout + 255) / 256 * 256), real = (size_t)((w.cout + 127) / 128 * 128), n = real * w.kpad;
-    Panels pn;
-    pn.planes = alloc(rows * w.kpad * ns * 2);  // rows padded to 256: the 256-wide tile reads whole tiles
-    YMK_HIP(hipMemsetAsync(pn.planes, 0, rows * w.kpad * ns * 2, s));
-    if (code == SPLIT_F16X2 || code == SPLIT_F16X2_PERM) {
-      pn.scale = reinterpret_cast<float*>(alloc(real * sizeof(float)));
-      hipLaunchKernelGGL(k_split_panel_f16, dim3((unsigned)real), dim3(256), 0, s, w.w, reinterpret_cast<unsigned short*>(pn.planes), w.kpad,
-                         w.scale, w.cout, pn.scale, w.kh * w.kw, w.ctiles, code == SPLIT_F16X2_PERM ? 1 : 0);
-    } else {
-      const int blocks = (int)((n + 255) / 256);
-      if (ns == 2) hipLaunchKernelGGL(k_split_panel<2>, dim3(blocks), dim3(256), 0, s, w.w, reinterpret_cast<unsigned short*>(pn.planes), n, w.kpad);
-      else hipLaunchKernelGGL(k_split_panel<3>, dim3(blocks), dim3(256), 0, s, w.w, reinterpret_cast<unsigned short*>(pn.planes), n, w.kpad);
-    }
-    YMK_HIP(hipGetLastError());
-    // built once, on the stream of the forward that asked first: wait for it here, so that a later forward of this model on
-    // ANOTHER stream (a second lane, a caller that changed streams) can never read a panel that is still being written
-    YMK_HIP(hipStreamSynchronize(s));
+    note_lazy_panel_build();
+    const Panels pn = build(s, w, code);
+    // on the stream of the forward that asked first: wait for it here, so that a later forward of this model on ANOTHER
+    // stream (a second lane, a caller that changed streams) can never read a panel that is still being written
+    forward_sync(s);
     return cache_.emplace(key, pn).first->second;
+  }
+  // every (panel, code) pair a forward of the owning model can ask for, and the max|x| words, on stream s (ymk_model_finalize:
+  // the null stream, followed by a device synchronisation) - so that a forward never allocates, never builds, never waits
+  void prebuild(hipStream_t s, const std::vector<ConvW>& convs, const std::vector<ConvW>& perm, int code) {
+    if (code != 2 && code != 3 && code != SPLIT_F16X2) return;
+    for (const ConvW& w : convs)
+      if (w.mode == 0 && cache_.find(Key{w.w, code}) == cache_.end()) cache_.emplace(Key{w.w, code}, build(s, w, code));
+    if (code == SPLIT_F16X2)
+      for (const ConvW& w : perm)
+        if (w.mode == 0 && cache_.find(Key{w.w, SPLIT_F16X2_PERM}) == cache_.end())
+          cache_.emplace(Key{w.w, SPLIT_F16X2_PERM}, build(s, w, SPLIT_F16X2_PERM));
+    ensure_slots(s);
   }
   // max|x| of the input view of launch k, on stream s; returns the device word the convolution kernel reads
   const unsigned* absmax(hipStream_t s, const ConvK& k) {
-    if (!slots_) {
-      slots_ = reinterpret_cast<unsigned*>(alloc(2 * AMAX_REC_WORDS * sizeof(unsigned)));
-      // ON stream s, ahead of the first k_absmax: a plain hipMemset goes to the null stream, which the callers' (non-blocking)
-      // streams do not order with - if the runtime returns before the fill has run, it can land after k_absmax has written the
-      // word, and the model's first launch then scales its operands for max|x| = 0
-      YMK_HIP(hipMemsetAsync(slots_, 0, 2 * AMAX_REC_WORDS * sizeof(unsigned), s));
+    ensure_slots(s);
+    // the two words alternate along ONE stream (each launch clears the other word for its successor); when the context
+    // moves to another stream, that stream waits for the old one first
+    if (have_stream_ && s != stream_) {  // an event in the old stream's order, the new stream behind it: the host does not wait
+      YMK_HIP(hipEventRecord(moved_, stream_));
+      YMK_HIP(hipStreamWaitEvent(s, moved_, 0));
     }
-    // the two words alternate along ONE stream (each launch clears the other word for its successor); a context that
-    // moves to another stream waits for the old one first
-    if (have_stream_ && s != stream_) YMK_HIP(hipStreamSynchronize(stream_));
     stream_ = s;
     have_stream_ = true;
     const size_t pixels = (size_t)(k.in_bytes / 4 - k.C) / k.in_ld + 1;
@@ -589,10 +588,42 @@ class SplitCtx {
     size_t operator()(const Key& k) const { return std::hash<const void*>()(k.w) * 31 + (size_t)k.code; }
   };
   void* alloc(size_t bytes) {
-    void* q = nullptr;
-    YMK_HIP(hipMalloc(&q, bytes ? bytes : 4));
+    void* q = dev_malloc(bytes);
     allocs_.push_back(q);
     return q;
+  }
+  Panels build(hipStream_t s, const ConvW& w, int code) {
+    const int ns = code == 3 ? 3 : 2;
+    const size_t rows = (size_t)((w.cout + 255) / 256 * 256), real = (size_t)((w.cout + 127) / 128 * 128), n = real * w.kpad;
+    Panels pn;
+    pn.planes = alloc(rows * w.kpad * ns * 2);  // rows padded to 256: the 256-wide tile reads whole tiles
+    YMK_HIP(hipMemsetAsync(pn.planes, 0, rows * w.kpad * ns * 2, s));
+    if (code == SPLIT_F16X2 || code == SPLIT_F16X2_PERM) {
+      pn.scale = reinterpret_cast<float*>(alloc(real * sizeof(float)));
+      hipLaunchKernelGGL(k_split_panel_f16, dim3((unsigned)real), dim3(256), 0, s, w.w, reinterpret_cast<unsigned short*>(pn.planes), w.kpad,
+                         w.scale, w.cout, pn.scale, w.kh * w.kw, w.ctiles, code == SPLIT_F16X2_PERM ? 1 : 0);
+    } else {
+      const int blocks = (int)((n + 255) / 256);
+      if (ns == 2) hipLaunchKernelGGL(k_split_panel<2>, dim3(blocks), dim3(256), 0, s, w.w, reinterpret_cast<unsigned short*>(pn.planes), n, w.kpad);
+      else hipLaunchKernelGGL(k_split_panel<3>, dim3(blocks), dim3(256), 0, s, w.w, reinterpret_cast<unsigned short*>(pn.planes), n, w.kpad);
+    }
+    YMK_HIP(hipGetLastError());
+    return pn;
+  }
+  // the two max|x| words of launches whose input came without a record
+  void ensure_slots(hipStream_t s) {
+    if (slots_) return;
+    slots_ = reinterpret_cast<unsigned*>(alloc(2 * AMAX_REC_WORDS * sizeof(unsigned)));
+    YMK_HIP(hipEventCreateWithFlags(&moved_, hipEventDisableTiming));
+    if (debug_hazard_null_memset()) {
+      // the round-5 form, reachable only through YMK_DEBUG_HAZARD_NULL_MEMSET (tools/stress_call.py): the fill goes to the NULL
+      // stream, which the callers' non-blocking streams do not order with - it can land after the first k_absmax has written
+      // the word, and the model's first split launch then scales its operands for max|x| = 0
+      YMK_HIP(hipMemset(slots_, 0, 2 * AMAX_REC_WORDS * sizeof(unsigned)));
+      return;
+    }
+    // ON stream s, ahead of the first k_absmax that will use the words
+    YMK_HIP(hipMemsetAsync(slots_, 0, 2 * AMAX_REC_WORDS * sizeof(unsigned), s));
   }
   std::unordered_map<Key, Panels, KeyHash> cache_;
   std::vector<void*> allocs_;
@@ -600,6 +631,7 @@ class SplitCtx {
   int parity_ = 0;
   hipStream_t stream_ = nullptr;
   bool have_stream_ = false;
+  hipEvent_t moved_ = nullptr;
 };
 
 SplitCtx* SplitCtxOwner::get() {
@@ -607,6 +639,20 @@ SplitCtx* SplitCtxOwner::get() {
   return p_;
 }
 SplitCtxOwner::~SplitCtxOwner() { delete p_; }
+
+void Model::prebuild_split() {
+  if (debug_lazy_split()) return;
+  SplitCtx* ctx = split_ctx.get();
+  int code;
+  {
+    ConvSplitScope scope(conv_split(), ctx, SPLIT_MODEL_DEFAULT);
+    code = conv_effective_split();
+  }
+  ctx->prebuild(nullptr, pool.convs(), pool.perm_convs(), code);
+  const int enc = (int)param("conv_split_encoder", -1);  // the recogniser's evaluation switch: a second precision for the ViT blocks
+  if (enc > 0 && enc != code) ctx->prebuild(nullptr, pool.convs(), pool.perm_convs(), enc);
+  YMK_HIP(hipStreamSynchronize(nullptr));
+}
 
 // amax_check mode: the launch's record against a pass over its input (counters above).  Level 2 also waits for the answer
 // and names the launch whose record lies below the truth on stderr (a debugging aid: it serialises the stream).
@@ -666,6 +712,12 @@ static void launch_split(hipStream_t s, ConvK& k, const void* wsplit, SplitCtx* 
 //   12 / 13 / 14 = 128 x 128 x 16 waves / 256 x 128 x 16 waves / 128 x 128 x 8 waves with the stores threaded through the MFMAs
 // (bf16 only; the fp16 form keeps the shapes that won there: 0 / 3 = 128 x 128 x 16 waves, 1 = 128 x 64, 2 = 256 x 128, 11)
 static std::atomic<int> g_split_tile{0};
+// ... or, for the calling thread only, a ConvSplitTileScope (single-operator entry points: the process-wide word would
+// reroute forwards that other threads have in flight)
+static thread_local int t_split_tile = 0;
+static int split_tile_now() { return t_split_tile != 0 ? t_split_tile : g_split_tile.load(std::memory_order_relaxed); }
+ConvSplitTileScope::ConvSplitTileScope(int tile) : prev_(t_split_tile) { t_split_tile = tile; }
+ConvSplitTileScope::~ConvSplitTileScope() { t_split_tile = prev_; }
 // ymk_debug_option("astat", v): 1 (default) = the short-K pointwise layers the A-stationary kernel measured ahead on take it;
 // 0 = none does (the round-4 routing, for A/B runs); "conv_split_tile" 30 forces it for every launch it can run
 static std::atomic<int> g_astat{1};
@@ -768,7 +820,7 @@ struct RouteQuery {
 static SplitRoute route_f16(const RouteQuery& q, int& tile, bool& narrow) {
   const long mt128 = (q.M + 127) / 128;
   const long blocks128 = mt128 * ((q.cout + 127) / 128), blocks64 = mt128 * ((q.cout + 63) / 64);
-  tile = g_split_tile.load(std::memory_order_relaxed);
+  tile = split_tile_now();
   const bool auto_tile = tile == 0;
   const bool astat_forced = tile == 30;  // tests: the A-stationary kernel at any size it can run
   bool few = false;
@@ -797,7 +849,7 @@ static SplitRoute route_f16(const RouteQuery& q, int& tile, bool& narrow) {
 int conv_split_route_with_planes(long M, int cout, int kpad, int taps, bool* auto_tile) {
   int tile = 0;
   bool narrow = false;
-  *auto_tile = g_split_tile.load(std::memory_order_relaxed) == 0 && g_act_planes.load(std::memory_order_relaxed) != 0;
+  *auto_tile = split_tile_now() == 0 && g_act_planes.load(std::memory_order_relaxed) != 0;
   return (int)route_f16(RouteQuery{M, cout, kpad, taps, false, false, false, false, true}, tile, narrow);
 }
 
@@ -816,7 +868,7 @@ bool conv2d_split(hipStream_t s, ConvK& k, const ConvW& w, int code, SplitCtx* c
   } else {  // bf16 evaluation forms: the register-staged kernel, for launches that fill the chip
     const long mt128 = (k.M + 127) / 128;
     const long blocks128 = mt128 * ((w.cout + 127) / 128), blocks64 = mt128 * ((w.cout + 63) / 64);
-    tile = g_split_tile.load(std::memory_order_relaxed);
+    tile = split_tile_now();
     if (tile == 0) tile = code == 3 ? 2 : 3;
     if (tile == 20 || tile == 21 || tile == 30) tile = 3;
     if (blocks128 < 256 && blocks64 < 256) return false;

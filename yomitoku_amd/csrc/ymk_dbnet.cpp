@@ -85,6 +85,7 @@ class DBNetModel : public Model {
       deconv1_ = make_linear_raw(pool, lin.data(), nullptr, 4 * co, ci);
       deconv1_.scale = pool.upload(sc);
       deconv1_.bias = pool.upload(bi);
+      pool.note(deconv1_);  // (the panel with its scale: what the split copy folds the row's power of two into)
     }
     {
       const HostTensor& w = ws.get(d + "binarize.6.weight");  // [64][1][2][2] == [c][ab]
@@ -99,6 +100,7 @@ class DBNetModel : public Model {
   // x: device NCHW fp32 [n][3][h][w] (h, w multiples of 32); prob: device [n][1][h][w]
   void forward(const float* x_nchw, int n, int h, int w, float* prob, hipStream_t s) {
     YMK_CHECK(finalized, "model not finalized");
+    ForwardScope forward_scope;
     ConvSplitScope split_scope(conv_split(), split_ctx.get(), SPLIT_MODEL_DEFAULT);
     YMK_CHECK(n > 0 && h % 32 == 0 && w % 32 == 0 && h >= 32 && w >= 32, "dbnet input must be a multiple of 32");
     const uint64_t key = ((uint64_t)n << 40) | ((uint64_t)h << 20) | (uint64_t)w;
@@ -110,7 +112,7 @@ class DBNetModel : public Model {
       const size_t need = arena.used();
       arena.reset();
       if (need > arena.capacity()) {
-        YMK_HIP(hipStreamSynchronize(s));
+        forward_sync(s);
         arena.reserve(need);
       }
       shape_key_ = key;

@@ -32,11 +32,16 @@ static std::atomic<int> g_parseq_no_mlp_fusion{0};  // ymk_debug_option("parseq_
 static bool parseq_no_mlp_fusion() { return g_parseq_no_mlp_fusion.load(std::memory_order_relaxed) != 0; }
 static std::atomic<int> g_parseq_no_ln_fusion{0};  // ymk_debug_option("parseq_no_ln_fusion", 1): LayerNorm as its own launch (A/B, tests)
 static bool parseq_no_ln_fusion() { return g_parseq_no_ln_fusion.load(std::memory_order_relaxed) != 0; }
+// ymk_debug_option("ar_publish", v): how a greedy step tells the host whether rows are still open.  1 (default since round 6) =
+// the rows store a flag and a one-thread launch behind the greedy kernel writes the mapped host word; 0 = the rows count and the
+// kernel's last-arriving block writes it (rounds 1-5; A/B runs and tools/stress_call.py)
+static std::atomic<int> g_ar_publish{1};
 bool parseq_debug_option(const std::string& key, int value) {
   if (key == "parseq_unfused") g_parseq_unfused = value;
   else if (key == "parseq_no_rowmax") g_parseq_no_rowmax = value;
   else if (key == "parseq_no_ln_fusion") g_parseq_no_ln_fusion = value;
   else if (key == "parseq_no_mlp_fusion") g_parseq_no_mlp_fusion = value;
+  else if (key == "ar_publish") g_ar_publish = value;
   else return false;
   return true;
 }
@@ -110,6 +115,7 @@ class ParseqModel : public Model {
       b.proj = make_linear(pool, ws, p + "attn.proj");
       b.fc1 = make_linear(pool, ws, p + "mlp.fc1");
       b.fc2 = make_linear(pool, ws, p + "mlp.fc2");
+      if (b.fc1.cin == 192 && b.fc1.cout == 768) pool.note(b.fc2, /*perm=*/true);  // the fused MLP kernel's fc2 copy (ymk_vit_mlp.hip)
     }
     enc_ng_ = pool.upload(ws.get(e + "norm.weight").data);
     enc_nb_ = pool.upload(ws.get(e + "norm.bias").data);
@@ -186,11 +192,10 @@ class ParseqModel : public Model {
       std::vector<unsigned char> m((size_t)nsteps_ * nsteps_, 0);
       for (int q = 2; q < nsteps_; ++q)
         for (int k = q + 1; k < nsteps_; ++k) m[(size_t)q * nsteps_ + k] = 1;
-      void* dm = nullptr;
-      YMK_HIP(hipMalloc(&dm, m.size()));
+      void* dm = dev_malloc(m.size());
       YMK_HIP(hipMemcpy(dm, m.data(), m.size(), hipMemcpyHostToDevice));
       qmask_ = (unsigned char*)dm;
-      YMK_HIP(hipHostMalloc((void**)&host_flags_, (size_t)nsteps_ * sizeof(int), hipHostMallocMapped));
+      host_flags_ = (int*)host_malloc_pinned((size_t)nsteps_ * sizeof(int), hipHostMallocMapped);
       YMK_HIP(hipHostGetDevicePointer((void**)&host_flags_dev_, host_flags_, 0));
     }
     ws.clear();
@@ -198,9 +203,9 @@ class ParseqModel : public Model {
   }
 
   ~ParseqModel() override {
-    if (qmask_) (void)hipFree(qmask_);
-    if (host_flags_) (void)hipHostFree(host_flags_);
-    if (stage_) (void)hipHostFree(stage_);
+    dev_free(qmask_);
+    host_free_pinned(host_flags_);
+    host_free_pinned(stage_);
   }
 
   int num_classes() const { return C_; }
@@ -214,6 +219,7 @@ class ParseqModel : public Model {
   // out_len[g] / ar_steps[g]: rows valid per sample / greedy steps of group g as its own loop would have run them.
   void forward_groups(const PGroup* groups, int ng, float* logits, int* out_len, int* ar_steps, hipStream_t s) {
     YMK_CHECK(finalized, "model not finalized");
+    ForwardScope forward_scope;
     ConvSplitScope split_scope(conv_split(), split_ctx.get(), SPLIT_MODEL_DEFAULT);
     YMK_CHECK(ng > 0, "parseq: no mini-batch");
     uint64_t key = 1469598103934665603ull;
@@ -230,7 +236,7 @@ class ParseqModel : public Model {
       const size_t need = arena.used();
       arena.reset();
       if (need > arena.capacity()) {
-        YMK_HIP(hipStreamSynchronize(s));
+        forward_sync(s);
         arena.reserve(need + need / 4);  // ragged workloads change shape every call: leave head room, grow rarely
       }
       shape_key_ = key;
@@ -261,10 +267,10 @@ class ParseqModel : public Model {
     const size_t want = (size_t)3 * max_lines + (size_t)nsteps_ * max_lines + max_lines;
     if (want > stage_cap_) {
       YMK_HIP(hipStreamSynchronize(s));
-      if (stage_) YMK_HIP(hipHostFree(stage_));
+      host_free_pinned(stage_);
       stage_ = nullptr;
       stage_cap_ = 0;
-      YMK_HIP(hipHostMalloc((void**)&stage_, want * sizeof(int), hipHostMallocDefault));
+      stage_ = (int*)host_malloc_pinned(want * sizeof(int), hipHostMallocDefault);
       stage_cap_ = want;
     }
     shape_key_ = 0;
@@ -371,10 +377,10 @@ class ParseqModel : public Model {
       // greedy loop has been observed to finish, so the previous call's copy has long left the buffer
       const size_t want = (size_t)3 * B + (size_t)NS * ng + ng;  // tables out | per-step group counters back | group step counts out
       if (want > stage_cap_) {
-        if (stage_) YMK_HIP(hipHostFree(stage_));
+        host_free_pinned(stage_);
         stage_ = nullptr;
         stage_cap_ = 0;
-        YMK_HIP(hipHostMalloc((void**)&stage_, 2 * want * sizeof(int), hipHostMallocDefault));
+        stage_ = (int*)host_malloc_pinned(2 * want * sizeof(int), hipHostMallocDefault);
         stage_cap_ = 2 * want;
       }
       int row = 0, b = 0;
@@ -446,16 +452,16 @@ class ParseqModel : public Model {
     init_decode(s, tok, NS, state, bos_, pad_, B);  // tok[:, 0] = bos, rest pad; state = {0, 0, -1, 0}
     const int dhd = D / dh_;
     const float dscale = 1.f / std::sqrt((float)dhd);
-    // Early stop without stalling the queue: step i counts the rows still lacking an <eos> into
-    // not_done[i] and publishes it to mapped pinned host memory; the host reads the flag of step
+    // Early stop without stalling the queue: step i notes in not_done[i] whether any row still lacks an <eos> (0 / 1: rows
+    // store, they do not count - ymk_seq.hip) and publishes it to mapped pinned host memory; the host reads the flag of step
     // i - LAG, so up to LAG speculative steps are in flight.  A speculative step's greedy kernel sees
     // not_done[i-1] == 0 and leaves tokens / repetition state untouched, hence `steps` and every
     // result are exactly those of the reference's step-by-step test (models/parseq.py:245-250).
     constexpr int LAG = 2;
     YMK_HIP(hipMemsetAsync(not_done, 0, (size_t)2 * NS * sizeof(int), s));  // not_done[NS] | arrived[NS]
     int* arrived = not_done + NS;
-    // host_flags_ is mapped pinned memory the last-arriving block of step i's greedy kernel writes
-    // (count + 1, so 0 = "not reported yet"): no copy-engine hop, no event per step.  Only
+    // host_flags_ is mapped pinned memory a one-thread launch behind step i's greedy kernel writes
+    // (that word + 1, so 0 = "not reported yet"): no copy-engine hop, no event per step.  Only
     // non-speculative steps write, and all of those have completed before a forward returns.
     for (int i = 0; i < NS; ++i) host_flags_[i] = 0;
     auto wait_flag = [&](int i) -> int {
@@ -473,6 +479,7 @@ class ParseqModel : public Model {
       }
     };
     int steps = NS;
+    const bool publish_launch = g_ar_publish.load(std::memory_order_relaxed) != 0;
     for (int i = 0; i < NS; ++i) {
       const int* prev = i > 0 ? not_done + i - 1 : nullptr;
       if (fused) {
@@ -496,14 +503,16 @@ class ParseqModel : public Model {
         gemm(s, t1, B, D, D, sa_o_, ACT_NONE, posq_ + (size_t)i * D, 0, qcur, D);
         stream_tail(s, qcur, B, B, 1, memkv, L, mem_t, t1, t2, hdec, arlog + (size_t)i * C, NS * C);
       }
+      // who tells the host: a one-thread launch behind the greedy kernel (default), or - "ar_publish" 0 - that kernel's
+      // last-arriving block as in rounds 1-5 (the last step's word is never read)
+      int* in_kernel_flag = (!publish_launch && i + 1 < NS) ? host_flags_dev_ + i : nullptr;
       if (ar_rowmax)
         greedy_step(s, armax, (long)2 * head_tiles, head_tiles, i, NS, tok, raw, NS, state, eos_, rep_on_, rep_pmax_, rep_p1_, rep_min_,
-                    not_done + i, i > 0 ? not_done + i - 1 : nullptr, arrived + i, i + 1 < NS ? host_flags_dev_ + i : nullptr, B, gid,
-                    gop, ng, 1);
+                    not_done + i, prev, arrived + i, in_kernel_flag, B, gid, gop, ng, 1);
       else
         greedy_step(s, arlog + (size_t)i * C, (long)NS * C, C, i, NS, tok, raw, NS, state, eos_, rep_on_, rep_pmax_, rep_p1_,
-                    rep_min_, not_done + i, i > 0 ? not_done + i - 1 : nullptr, arrived + i,
-                    i + 1 < NS ? host_flags_dev_ + i : nullptr /* the last step's count is never read */, B, gid, gop, ng);
+                    rep_min_, not_done + i, prev, arrived + i, in_kernel_flag, B, gid, gop, ng);
+      if (publish_launch && i + 1 < NS) publish_open(s, not_done + i, prev, host_flags_dev_ + i);
       if (i + 1 < NS && i >= LAG && wait_flag(i - LAG) == 0) {  // every row held an <eos> after step i - LAG
         steps = i - LAG + 1;
         break;

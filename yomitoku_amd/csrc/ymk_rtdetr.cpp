@@ -71,6 +71,7 @@ class RtdetrModel : public Model {
     pack_conv_weight(k.data(), co, ci, 3, 3, false, panel, c.kpad, c.ctiles);
     c.w = pool.upload(panel);
     c.bias = pool.upload(bias);
+    pool.note(c);
     return c;
   }
   Csp csp(const std::string& name) {
@@ -187,6 +188,7 @@ class RtdetrModel : public Model {
   // x: device fp32 [B][3][H][W]; logits: [B][nq][nc]; boxes: [B][nq][4] (cxcywh in [0,1])
   void forward(const float* x, int B, int H, int W, float* logits, float* boxes, hipStream_t s) {
     YMK_CHECK(finalized, "model not finalized");
+    ForwardScope forward_scope;
     ConvSplitScope split_scope(conv_split(), split_ctx.get(), SPLIT_MODEL_DEFAULT);
     YMK_CHECK(B > 0 && H % 32 == 0 && W % 32 == 0, "rtdetr input must be a multiple of 32");
     const int tok = (H / 8) * (W / 8) + (H / 16) * (W / 16) + (H / 32) * (W / 32);
@@ -201,7 +203,7 @@ class RtdetrModel : public Model {
       const size_t need = arena.used();
       arena.reset();
       if (need > arena.capacity()) {
-        YMK_HIP(hipStreamSynchronize(s));
+        forward_sync(s);
         arena.reserve(need);
       }
       shape_key_ = key;

@@ -1,6 +1,8 @@
 // Host runtime of libymk_hip.so: error slot, arena, weight store, state-dict -> packed panels.
 #include "ymk_common.h"
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 
 namespace ymk {
 
@@ -8,17 +10,82 @@ static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
 const std::string& last_error() { return g_err; }
 
-// ---------------------------------------------------------------- Arena
-Arena::~Arena() {
-  if (base_) (void)hipFree(base_);
+// ---------------------------------------------------------------- allocation accounting (ymk_common.h)
+static thread_local int t_forward_depth = 0;
+static std::atomic<long long> g_allocs_in_forward{0}, g_arena_grows_in_forward{0}, g_lazy_panel_builds{0}, g_syncs_in_forward{0};
+ForwardScope::ForwardScope() { ++t_forward_depth; }
+ForwardScope::~ForwardScope() { --t_forward_depth; }
+bool in_forward() { return t_forward_depth > 0; }
+static void count_alloc() {
+  if (t_forward_depth > 0) ++g_allocs_in_forward;
 }
+void* dev_malloc(size_t bytes) {
+  void* p = nullptr;
+  count_alloc();
+  YMK_HIP(hipMalloc(&p, bytes ? bytes : 4));
+  return p;
+}
+void dev_free(void* p) {
+  if (!p) return;
+  count_alloc();
+  (void)hipFree(p);
+}
+void* host_malloc_pinned(size_t bytes, unsigned flags) {
+  void* p = nullptr;
+  count_alloc();
+  YMK_HIP(hipHostMalloc(&p, bytes ? bytes : 4, flags));
+  return p;
+}
+void host_free_pinned(void* p) {
+  if (!p) return;
+  count_alloc();
+  (void)hipHostFree(p);
+}
+void forward_sync(hipStream_t s) {
+  if (t_forward_depth > 0) ++g_syncs_in_forward;
+  YMK_HIP(hipStreamSynchronize(s));
+}
+void note_lazy_panel_build() {
+  if (t_forward_depth > 0) ++g_lazy_panel_builds;
+}
+void note_arena_grow() {
+  if (t_forward_depth > 0) ++g_arena_grows_in_forward;
+}
+bool runtime_stat(const std::string& key, long long* value) {
+  if (key == "allocs_in_forward") *value = g_allocs_in_forward.load();
+  else if (key == "arena_grows_in_forward") *value = g_arena_grows_in_forward.load();
+  else if (key == "lazy_panel_builds") *value = g_lazy_panel_builds.load();
+  else if (key == "syncs_in_forward") *value = g_syncs_in_forward.load();
+  else return false;
+  return true;
+}
+static bool env_flag(const char* name) {
+  const char* v = std::getenv(name);
+  return v != nullptr && v[0] != '\0' && v[0] != '0';
+}
+bool debug_lazy_split() {
+  static const bool on = env_flag("YMK_DEBUG_LAZY_SPLIT");
+  return on;
+}
+bool debug_hazard_null_memset() {
+  static const bool on = env_flag("YMK_DEBUG_HAZARD_NULL_MEMSET");
+  return on;
+}
+bool debug_hazard_no_finalize_sync() {
+  static const bool on = env_flag("YMK_DEBUG_HAZARD_NO_FINALIZE_SYNC");
+  return on;
+}
+
+// ---------------------------------------------------------------- Arena
+Arena::~Arena() { dev_free(base_); }
 void Arena::reserve(size_t bytes) {
   if (bytes <= cap_) return;
   YMK_CHECK(off_ == 0, "arena reserve while in use");
-  if (base_) YMK_HIP(hipFree(base_));
+  note_arena_grow();
+  dev_free(base_);
   base_ = nullptr;
   cap_ = 0;
-  YMK_HIP(hipMalloc((void**)&base_, bytes));
+  base_ = (char*)dev_malloc(bytes);
   cap_ = bytes;
 }
 void* Arena::alloc_bytes(size_t bytes) {
@@ -55,12 +122,20 @@ Tensor Arena::tensor(int n, int h, int w, int c) {
 
 // ---------------------------------------------------------------- DevicePool
 DevicePool::~DevicePool() {
-  for (void* p : ptrs_) (void)hipFree(p);
+  for (void* p : ptrs_) dev_free(p);
+}
+void DevicePool::note(const ConvW& c, bool perm) {
+  std::vector<ConvW>& list = perm ? perm_ : convs_;
+  for (ConvW& have : list)
+    if (have.w == c.w) {
+      have = c;
+      return;
+    }
+  list.push_back(c);
 }
 float* DevicePool::alloc(size_t n) {
-  void* p = nullptr;
   const size_t b = (n ? n : 1) * sizeof(float);
-  YMK_HIP(hipMalloc(&p, b));
+  void* p = dev_malloc(b);
   ptrs_.push_back(p);
   bytes_ += b;
   return (float*)p;
@@ -142,6 +217,7 @@ ConvW make_conv(DevicePool& pool, const WeightStore& ws, const std::string& conv
     c.bias = pool.upload(bias);
   }
   plane_bound(c, w.data.data(), w.numel() / (size_t)w.dims[0], scale, bias);
+  pool.note(c);
   return c;
 }
 
@@ -156,6 +232,7 @@ ConvW make_linear_raw(DevicePool& pool, const float* w_out_in, const float* bias
   c.w = pool.upload(panel);
   if (bias) c.bias = pool.upload(bias, out);
   plane_bound(c, w_out_in, (size_t)in, {}, bias ? std::vector<float>(bias, bias + out) : std::vector<float>());
+  pool.note(c);
   return c;
 }
 

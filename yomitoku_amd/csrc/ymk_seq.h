@@ -36,6 +36,8 @@ void greedy_step(hipStream_t s, const float* logits, long ld_b, int C, int step,
                  int ld_tok, int* state, int eos_id, int rep_on, int period_max, int min_run_p1, int min_repeats,
                  int* not_done, const int* prev_not_done, int* arrived, int* host_flag, int B, const int* gid = nullptr,
                  int* gopen = nullptr, int ng = 1, int partials = 0);  // partials: `logits` holds C (max, column) pairs per row
+// host_flag of greedy_step may be null: publish_open then reports the step from a launch of its own (what the recogniser does)
+void publish_open(hipStream_t s, const int* not_done, const int* prev_not_done, int* host_flag);
 void refine_prep(hipStream_t s, const int* raw, int ld_tok, int S, int bos_id, int eos_id, int* tok2, unsigned char* kpm,
                  int B, const int* gid = nullptr, const int* gsteps = nullptr);
 void row_argmax(hipStream_t s, const float* logits, int rows, int C, int* out);

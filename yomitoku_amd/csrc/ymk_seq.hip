@@ -753,7 +753,8 @@ __global__ __launch_bounds__(256) void k_greedy_step(const float* __restrict__ l
                                                      int period_max, int min_run_p1, int min_repeats,
                                                      int* __restrict__ not_done, const int* __restrict__ prev_not_done,
                                                      int* __restrict__ arrived, int* __restrict__ host_flag,
-                                                     const int* __restrict__ gid, int* __restrict__ gopen, int ng, int partials) {
+                                                     const int* __restrict__ gid, int* __restrict__ gopen, int ng, int partials,
+                                                     int flags) {
   const int b = blockIdx.x, t = threadIdx.x;
   // speculative step issued after every row already held an <eos>: change nothing (not_done stays 0)
   if (prev_not_done && *prev_not_done == 0) return;
@@ -794,6 +795,14 @@ __global__ __launch_bounds__(256) void k_greedy_step(const float* __restrict__ l
       __syncthreads();
     }
   }
+  // the repetition detector below is ONE thread walking back through the row's tokens: from global memory that is a chain of
+  // some tens of dependent loads (~0.4 us each: 27 us per step on average over a 101-step loop, as long as the vocabulary
+  // head next to it); the block fetches the row once, side by side, and the walk reads LDS
+  __shared__ int srow[260];
+  const bool cached = num_steps <= 256;
+  if (cached && rep_on && !frozen)
+    for (int i = t; i <= step; i += 256) srow[i] = tok[(size_t)b * ld_tok + i];
+  __syncthreads();
   if (t != 0) return;
   int* st = state + b * 4;
   // a frozen row still owns a slot of the shared token table at every step: keep it a valid id (it lies behind the
@@ -809,7 +818,9 @@ __global__ __launch_bounds__(256) void k_greedy_step(const float* __restrict__ l
       if (rep_on && !st[1] && next != eos_id) {
         // _detect_repeat_onset on seq = trow[1..j] with trow[j] = next (models/parseq.py:108-128)
         trow[j] = next;
+        if (cached) srow[j] = next;
         const int* seq = trow + 1;
+        auto at = [&](int i) { return cached ? srow[1 + i] : seq[i]; };
         const int n = j;
         for (int pp = 1; pp <= period_max; ++pp) {
           if (n < 2 * pp) continue;
@@ -817,7 +828,7 @@ __global__ __launch_bounds__(256) void k_greedy_step(const float* __restrict__ l
           while (tpos - pp >= 0) {
             bool same = true;
             for (int u = 0; u < pp; ++u)
-              if (seq[tpos - pp + u] != seq[n - pp + u]) {
+              if (at(tpos - pp + u) != at(n - pp + u)) {
                 same = false;
                 break;
               }
@@ -837,12 +848,22 @@ __global__ __launch_bounds__(256) void k_greedy_step(const float* __restrict__ l
       if (next == eos_id) st[0] = 1;
     }
     if (!st[0]) {
-      atomicAdd(not_done, 1);
-      if (gopen) atomicAdd(gopen + (size_t)step * ng + g, 1);
+      // "some row is still open" / "some row of mini-batch g is still open": every reader tests these words against zero only.
+      // `flags` (the recogniser's loop since round 6): an open row STORES 1 (zero before the loop) - a thousand atomic
+      // increments of one word per step queue up at one L2 channel; else (ymk_debug_option("ar_publish", 0): the form of
+      // rounds 1-5, kept for A/B runs) the rows count
+      if (flags) {
+        __hip_atomic_store(not_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gopen) __hip_atomic_store(gopen + (size_t)step * ng + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        atomicAdd(not_done, 1);
+        if (gopen) atomicAdd(gopen + (size_t)step * ng + g, 1);
+      }
     }
   }
   if (host_flag) {
-    // the last block to arrive publishes (rows still open) + 1 to the mapped host word the AR loop polls
+    // (rounds 1-5) the last block to arrive publishes (rows still open) + 1 to the mapped host word the AR loop polls: a
+    // device-scope fence and an atomic per block - 17 of this kernel's 27 us on a multi-XCD part; publish_open replaces it
     __threadfence();
     if (atomicAdd(arrived, 1) == (int)gridDim.x - 1) {
       const int open = atomicAdd(not_done, 0);
@@ -850,14 +871,29 @@ __global__ __launch_bounds__(256) void k_greedy_step(const float* __restrict__ l
     }
   }
 }
+// (any row still open after a step: 0 / 1) + 1 into the mapped host word the AR loop polls, as a launch of its own behind the
+// step's greedy kernel.  Inside that kernel the same store needs "the last block to arrive": a device-scope fence and an atomic
+// per block, which on this multi-XCD part means L2 write-backs - 17 of the kernel's 27 us (kernel trace with and without:
+// 26.7 against 9.6 us over 404 launches).  The kernel boundary orders the words for free.  A speculative step (issued after
+// every row already held an <eos>) writes nothing, as before: only steps that really ran report.
+__global__ void k_publish_open(const int* __restrict__ not_done, const int* __restrict__ prev_not_done, int* __restrict__ host_flag) {
+  if (prev_not_done && *prev_not_done == 0) return;
+  __hip_atomic_store(host_flag, *not_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void publish_open(hipStream_t s, const int* not_done, const int* prev_not_done, int* host_flag) {
+  hipLaunchKernelGGL(k_publish_open, dim3(1), dim3(1), 0, s, not_done, prev_not_done, host_flag);
+  YMK_HIP(hipGetLastError());
+}
+
 void greedy_step(hipStream_t s, const float* logits, long ld_b, int C, int step, int num_steps, int* tok, int* raw,
                  int ld_tok, int* state, int eos_id, int rep_on, int period_max, int min_run_p1, int min_repeats,
                  int* not_done, const int* prev_not_done, int* arrived, int* host_flag, int B, const int* gid, int* gopen,
                  int ng, int partials) {
+  // host_flag null: the open-row words are flags and publish_open reports the step; non-null: they count and the kernel reports
   YMK_CHECK(!partials || C <= 256, "greedy step: at most 256 partial (max, column) pairs per row");
   hipLaunchKernelGGL(k_greedy_step, dim3(B), dim3(256), 0, s, logits, ld_b, C, step, num_steps, tok, raw, ld_tok, state,
                      eos_id, rep_on, period_max, min_run_p1, min_repeats, not_done, prev_not_done, arrived, host_flag, gid,
-                     gopen, ng, partials);
+                     gopen, ng, partials, host_flag == nullptr ? 1 : 0);
   YMK_HIP(hipGetLastError());
 }
 

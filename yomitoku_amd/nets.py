@@ -100,6 +100,12 @@ class HipNet:
         try:
             for k, v in self.params().items():
                 _lib.check(lib.ymk_model_set_param(h, k.encode(), float(v)), f"set_param {k}")
+            # the evaluation switches go in BEFORE finalize: finalize builds the split weight copies for the precision the
+            # model will run, so that no forward has to (include/ymk.h: ymk_model_finalize)
+            if self._conv_split is not None:
+                _lib.check(lib.ymk_model_set_param(h, b"conv_split", float(self._conv_split)), "set_param conv_split")
+            for k, v in getattr(self, "_extra_params", {}).items():
+                _lib.check(lib.ymk_model_set_param(h, k.encode(), float(v)), f"set_param {k}")
             for name, t in self._sd.items():
                 if not torch.is_floating_point(t):
                     continue
@@ -109,16 +115,13 @@ class HipNet:
                     f"set_tensor {name}",
                 )
             _lib.check(lib.ymk_model_finalize(h), "ymk_model_finalize")
-            if self._conv_split is not None:
-                _lib.check(lib.ymk_model_set_param(h, b"conv_split", float(self._conv_split)), "set_param conv_split")
-            for k, v in getattr(self, "_extra_params", {}).items():
-                _lib.check(lib.ymk_model_set_param(h, k.encode(), float(v)), f"set_param {k}")
         except Exception:
             lib.ymk_model_destroy(h)
             raise
         self._h = h
         self._device_index = int(device_index)
         self._reserve_tried_for = None  # a new handle has no workspace reservation (reserve_once)
+        self._reserved = []  # (n, h, w) bounds the live handle's workspace has been sized for (ensure_workspace)
 
     def set_conv_split(self, planes):
         """Operand precision of THIS model's convolutions / linear layers (include/ymk.h, "conv_split"): 16 = fp32 operands as
@@ -157,6 +160,22 @@ class HipNet:
             self.to(device if device is not None else "cuda")
         with torch.cuda.device(self._device_index):
             _lib.check(_lib.load().ymk_model_reserve(self._h, int(n), int(h), int(w), _lib.current_stream_ptr()), "ymk_model_reserve")
+        self._reserved.append((int(n), int(h), int(w)))
+
+    def ensure_workspace(self, n: int, h: int, w: int):
+        """Called by every forward with its own shape: sizes the workspace NOW - on the caller's thread and stream, outside
+        the forward - unless an earlier reservation covers the shape.  With it a forward never reaches hipMalloc / hipFree
+        (the library would grow the workspace itself, inside the forward, as callers of the bare C ABI may let it:
+        ymk_stat("arena_grows_in_forward")); reserve_once() of the multi-page paths covers their forwards in one go."""
+        for n0, h0, w0 in self._reserved:
+            if n <= n0 and ((h <= h0 and w <= w0) or (self.kind == "dbnet" and h <= w0 and w <= h0)):
+                return
+        if getattr(self, "_reserve_tried_for", None) == self._h and not getattr(self, "_reserve_ok", True):
+            return  # a reservation failed on this handle before (reserve_once): it grows on demand
+        try:
+            self.reserve(n, h, w)
+        except _lib.YmkError:  # the forward itself reports what is wrong with the shape (or grows on demand)
+            self._reserved.append((int(n), int(h), int(w)))
 
     def reserve_once(self, n: int, h: int, w: int, device=None) -> bool:
         """reserve() once per LIVE handle (a rebuild by load_state_dict() / to() starts over).  A reservation that fails -
@@ -259,6 +278,7 @@ class PARSeq(HipNet):
         x = images.to(torch.float32).contiguous()
         b, c, h, w = x.shape
         lib = _lib.load()
+        self.ensure_workspace(b, h, w)
         ns, nc = ctypes.c_int(), ctypes.c_int()
         _lib.check(lib.ymk_parseq_dims(self._h, ctypes.byref(ns), ctypes.byref(nc)), "ymk_parseq_dims")
         logits = torch.empty((b, ns.value, nc.value), dtype=torch.float32, device=x.device)
@@ -287,6 +307,7 @@ class PARSeq(HipNet):
         xs = [t.to(torch.float32).contiguous() for t in batches]
         n = len(xs)
         lib = _lib.load()
+        self.ensure_workspace(sum(int(t.shape[0]) for t in xs), int(xs[0].shape[2]), max(int(t.shape[3]) for t in xs))
         ns, nc = ctypes.c_int(), ctypes.c_int()
         _lib.check(lib.ymk_parseq_dims(self._h, ctypes.byref(ns), ctypes.byref(nc)), "ymk_parseq_dims")
         total = sum(int(t.shape[0]) for t in xs)
@@ -364,6 +385,7 @@ class RTDETRv2(HipNet):
             self.to(x.device)
         x = x.to(torch.float32).contiguous()
         n, c, h, w = x.shape
+        self.ensure_workspace(n, h, w)
         p = self.params()
         nq, nc = int(p["num_queries"]), int(p["num_classes"])
         logits = torch.empty((n, nq, nc), dtype=torch.float32, device=x.device)
@@ -407,6 +429,7 @@ class DBNet(HipNet):
         n, c, h, w = x.shape
         if c != 3:
             raise _lib.YmkError("DBNet wants N x 3 x H x W")
+        self.ensure_workspace(n, h, w)
         out = torch.empty((n, 1, h, w), dtype=torch.float32, device=x.device)
         lib = _lib.load()
         with torch.cuda.device(x.device):
