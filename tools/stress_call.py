@@ -215,8 +215,15 @@ def parent(args) -> int:
 
     t_start = time.time()
     results, running, launched = [], [], 0
+    # host threads: every child would otherwise start one OpenMP thread per core of the box for its seeded weights - with a few
+    # children alive at once the oversubscribed barriers spin for minutes
+    for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+        env.setdefault(var, str(args.host_threads))
+    progress = open(args.out + ".progress", "w") if args.out else None
     with tempfile.TemporaryDirectory(prefix="ymk_stress_") as tmp:
         while launched < args.runs or running:
+            if args.time_budget and time.time() - t_start > args.time_budget and launched < args.runs:
+                args.runs = launched  # out of time: no further children, the ones alive are waited for
             while launched < args.runs and len(running) < args.parallel:
                 k = launched
                 report = os.path.join(tmp, f"run{k}.json")
@@ -239,14 +246,21 @@ def parent(args) -> int:
                 log.close()
                 try:
                     with open(report, encoding="utf-8") as f:
-                        results.append((k, json.load(f)))
+                        results.append((k, dict(json.load(f), process_s=round(time.time() - t0, 1))))
                 except (OSError, ValueError):
-                    results.append((k, {"error": f"exit {rc}", "stderr": tail}))
+                    results.append((k, {"error": f"exit {rc}", "stderr": tail, "process_s": round(time.time() - t0, 1)}))
+                if progress:  # survives a parent that is killed: one line per finished child
+                    r = results[-1][1]
+                    progress.write(json.dumps({"run": k, "process_s": r["process_s"], "error": r.get("error"), "schema_crc": r.get("schema_crc"),
+                                               "counts": r.get("counts"), "crc_first": r.get("crc_first"), "crc_second": r.get("crc_second")}) + "\n")
+                    progress.flush()
             running = still
             time.sleep(0.05)
     results.sort(key=lambda r: r[0])
     ok = [(k, r) for k, r in results if "error" not in r]
-    summary = {"label": args.label, "runs": args.runs, "parallel": args.parallel, "page": args.page, "env": args.env,
+    if progress:
+        progress.close()
+    summary = {"label": args.label, "runs": args.runs, "process_s_median": sorted(r["process_s"] for _, r in results)[len(results) // 2] if results else None, "parallel": args.parallel, "page": args.page, "env": args.env,
                "no_concurrent": bool(args.no_concurrent), "prewarm": bool(args.prewarm),
                "crashed": [{"run": k, **r} for k, r in results if "error" in r], "wall_s": round(time.time() - t_start, 1)}
     if ok:
@@ -285,7 +299,9 @@ def parent(args) -> int:
             "first_call_s_median": sorted(r["seconds"]["first"] for _, r in ok)[len(ok) // 2],
             "second_call_s_median": sorted(r["seconds"]["second"] for _, r in ok)[len(ok) // 2],
         })
-        summary["failures"] = len(differing) + len(summary["crashed"]) + sum(1 for d in details if d["cold_differs_from_warm"] or d["second_call_differs"])
+        failed = {d["run"] for d in differing} | {c["run"] for c in summary["crashed"]}
+        failed |= {d["run"] for d in details if d["cold_differs_from_warm"] or d["second_call_differs"]}
+        summary["failures"] = len(failed)  # distinct runs: a run that lost its tables differs in schema AND in its cold outputs
     else:
         summary["failures"] = len(results)
     text = json.dumps(summary, ensure_ascii=False, indent=1)
@@ -307,6 +323,8 @@ def main() -> int:
     ap.add_argument("--no-concurrent", action="store_true", help="DocumentAnalyzer.concurrent_chains = False")
     ap.add_argument("--prewarm", action="store_true", help="run the layout chain once before the measured call")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--time-budget", type=float, default=0.0, help="seconds after which no further child is started (0: none)")
+    ap.add_argument("--host-threads", type=int, default=8, help="OMP / MKL threads per child unless the environment says otherwise")
     ap.add_argument("--child-timeout", type=float, default=180.0, help="seconds after which a child is killed and counted as crashed")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--report", default=None, help=argparse.SUPPRESS)
