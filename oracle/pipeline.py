@@ -165,3 +165,37 @@ def tables(sd, img_bgr, table_boxes, thresh=0.4, nc=3, forward=None):
         preds = (forward or (lambda t: rtdetr_forward(sd, t)))(x)
         out.append((preds, rtdetr_post(preds["pred_logits"], preds["pred_boxes"], (tw, th), thresh, nc)[0]))
     return out
+
+
+# ------------------------------------------------------------------ DocumentAnalyzer.__call__ (document_analyzer.py:622-678), free-running
+def analyze(sds, ocfg, img_bgr, charset, rec_opts=None, det_opts=None, agg_opts=None, forwards=None, keep=None):
+    """The whole page on the CPU with nothing taken from the product: detector -> boxes -> recogniser ‖ layout -> table crops
+    -> table structure -> aggregation and reading order (oracle.hostlogic, pinned against the reference's own functions).
+    sds: state dicts {"det", "rec", "lay", "tab"}; returns the page record as plain dicts, shaped like
+    DocumentAnalyzerSchema.model_dump().  `forwards`: optional replacements for the four network forwards (timing legs);
+    `keep`: a dict that receives the continuous stage outputs (probability map, layout / table logits and boxes, the
+    thresholded detections) for margin analysis (tools/e2e_oracle_eval.py)."""
+    from . import hostlogic as hl
+
+    rec_opts = dict(dynamic_width=True, batch_bucketing=True, width_budget=8000, max_batch_size=64, batch_size=10,
+                    source_downscale=True) if rec_opts is None else rec_opts
+    forwards = forwards or {}
+    prob, quads, det_scores = detect(sds["det"], img_bgr, **(det_opts or {}))
+    contents, rec_scores, directions = recognize(sds["rec"], ocfg, img_bgr, quads, charset, forward=forwards.get("rec"), **rec_opts)
+    words = [{"points": [[int(x), int(y)] for x, y in q], "content": c, "direction": d, "rec_score": float(rs), "det_score": float(ds)}
+             for q, ds, c, rs, d in zip(quads, det_scores, contents, rec_scores, directions)]
+    lay_preds, lay_det = layout(sds["lay"], img_bgr, forward=forwards.get("lay"))
+    groups = hl.layout_elements(lay_det)
+    table_boxes = [t["box"] for t in groups["tables"]]
+    structures, tab_raw = [], []
+    for box, (preds, det) in zip(table_boxes, tables(sds["tab"], img_bgr, table_boxes, forward=forwards.get("tab"))):
+        x1, y1, x2, y2 = (int(v) for v in box)
+        th, tw = img_bgr[y1:y2, x1:x2].shape[:2]
+        table = hl.table_structure(det, (th, tw), (x1, y1))
+        tab_raw.append((preds, det, table))
+        if table["n_row"] > 0 and table["n_col"] > 0:
+            structures.append(table)
+    if keep is not None:
+        keep.update(prob=prob, quads=quads, det_scores=det_scores, rec_scores=rec_scores, lay_preds=lay_preds, lay_det=lay_det,
+                    layout_groups={k: [dict(e) for e in v] for k, v in groups.items()}, tab_raw=tab_raw)
+    return hl.aggregate(words, {"paragraphs": groups["paragraphs"], "tables": structures, "figures": groups["figures"]}, **(agg_opts or {}))

@@ -215,3 +215,33 @@ def test_stress_call_parent_names_the_runs_that_differ(tmp_path):
     clean = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_call.py"), "--fake", "--runs", "5", "--parallel", "2"],
                            capture_output=True, text=True, timeout=120)
     assert clean.returncode == 0 and json.loads(clean.stdout)["failures"] == 0
+
+
+def test_e2e_eval_counts_leaves_per_stage():
+    """tools/e2e_oracle_eval.py: the leaf comparison and the verdict of a page on hand-made records (no device)."""
+    import copy
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("e2e_oracle_eval", os.path.join(ROOT, "tools", "e2e_oracle_eval.py"))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    word = lambda i: {"points": [[i, 0], [i + 9, 0], [i + 9, 9], [i, 9]], "content": f"w{i}", "direction": "horizontal", "rec_score": 0.9, "det_score": 0.8}  # noqa: E731
+    cell = {"col": 1, "row": 1, "col_span": 1, "row_span": 1, "box": [0, 0, 5, 5], "contents": "w0"}
+    table = {"box": [0, 0, 50, 50], "n_row": 1, "n_col": 1, "rows": [{"box": [0, 0, 50, 10], "score": 0.7}], "cols": [{"box": [0, 0, 10, 50], "score": 0.6}],
+             "spans": [], "cells": [cell], "order": 1}
+    page = {"words": [word(0), word(20)], "paragraphs": [{"box": [0, 0, 9, 9], "contents": "w0", "direction": "horizontal", "order": 0, "role": None}],
+            "tables": [table], "figures": []}
+    same = ev.compare_pages(copy.deepcopy(page), page)
+    assert all(r["differing"] == 0 for k, r in same.items() if k != "max_abs_score_diff")
+    assert same["words"]["leaves"] == 2 * 10 and same["cells"]["leaves"] == 9 and same["max_abs_score_diff"] == {"det_score": 0.0, "rec_score": 0.0}
+    other = copy.deepcopy(page)
+    other["words"][1]["points"][0][0] += 1   # one coordinate
+    other["words"][1]["rec_score"] = 0.85    # a float: not a discrete leaf
+    other["tables"][0]["cells"][0]["contents"] = "x"
+    other["paragraphs"].append(dict(page["paragraphs"][0], order=2))  # an element without a partner: all of its leaves
+    rep = ev.compare_pages(other, page)
+    assert rep["words"]["differing"] == 1 and rep["cells"]["differing"] == 1 and rep["tables"]["differing"] == 1
+    assert rep["paragraphs"]["differing"] == 8 and rep["paragraphs"]["elements"] == [2, 1]
+    assert abs(rep["max_abs_score_diff"]["rec_score"] - 0.05) < 1e-12
+    assert ev.classify([], 2e-3) == "unexplained" and ev.classify([{"margin": 1e-4}], 2e-3) == "borderline"
+    assert ev.classify([{"margin": 1e-4}, {"margin": 0.3}], 2e-3) == "failure" and ev.classify([{"margin": None}], 2e-3) == "failure"

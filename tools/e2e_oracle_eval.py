@@ -1,0 +1,362 @@
+"""End-to-end parity of DocumentAnalyzer against the CPU oracle, FREE-RUNNING, tables included (round-5 review item 2).
+
+Both sides start from the same page and owe each other nothing on the way: the product goes through
+`DocumentAnalyzer.serve` (its own detector map, boxes, crops, recogniser, layout, table crops, cell grids, aggregation),
+the oracle through `oracle.pipeline.analyze` (PyTorch-CPU fp32 nets, oracle/cvlike.py, oracle/hostlogic.py - pinned
+against the reference's own functions).  The two page records are compared leaf by leaf per stage
+
+  words       points (8 integers), content, direction            (det_score / rec_score: largest difference reported)
+  paragraphs  box, contents, direction, order, role
+  tables      box, n_row, n_col, order, row / column / span boxes, cells (row, col, spans, box, contents)
+  figures     box, order, direction, their paragraphs
+
+in the product's default arithmetic (two fp16 planes) AND with exact fp32 kernels.  For every page that differs the root
+of the difference is looked for stage by stage on the CONTINUOUS outputs of both sides, and given a margin:
+
+  detector   pixels on different sides of the binarisation threshold: the largest |p_oracle - thresh| among them, and
+             box scores on different sides of box_thresh
+  layout /   detections on different sides of the score threshold: |score - thresh|; integer box coordinates that
+  tables     truncate differently: distance of the float coordinate from the integer step
+  recogniser words with equal quads and different strings: the two recognition scores
+
+A difference whose margin is below --borderline (default 2e-3: twice the 1e-3 the north star allows the continuous
+outputs) is BORDERLINE - a tie broken by the last bits; anything else is a parity failure and the tool exits 1.
+
+  python tools/e2e_oracle_eval.py --pages 16 --out profiles/r06_e2e_oracle_eval.json"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+LITE = {"ocr": {"text_detector": {"from_pretrained": False},
+                "text_recognizer": {"model_name": "parseq-tiny-dynw-v4", "from_pretrained": False, "dynamic_width": True,
+                                    "batch_bucketing": True, "source_downscale": True}},
+        "layout_analyzer": {"layout_parser": {"from_pretrained": False}, "table_structure_recognizer": {"from_pretrained": False}}}
+# Seeded heads fire on one class only, hundreds of queries or none (their logits are tightly clustered): the class logits
+# of the two RT-DETRv2 nets are spread (score_gain 3) and every class gets its own bias, set ONCE from the ORACLE's logits on
+# the calibration page (seed 3, 1000 x 1400) so that a realistic handful per class clears the module's threshold there - two
+# tables, some paragraphs, headings, a header and a footer; five rows, five columns and two spans on the first table crop.
+# The cut is put into a gap of the sorted logits (never between two equal values).  Deterministic, CPU only.
+SEEDS = {"det": (1234, {"out_bias": -2.0}), "rec": (1235, {"eos_bias": 6.0}), "lay": (1240, {"num_classes": 6, "score_gain": 3.0}),
+         "tab": (1243, {"num_classes": 3, "score_gain": 3.0})}
+LAYOUT_TARGETS = (2, 1, 6, 2, 1, 1)  # tables, figures, paragraphs, section headings, page header, page footer
+TABLE_TARGETS = (5, 5, 2)            # rows, columns, spans
+SHAPES = [(1000, 1400), (1400, 1000), (1000, 1400), (1200, 1600), (1000, 1400), (1600, 1200), (1400, 1000), (1000, 1400)]
+
+
+def _class_shifts(logits, targets, thresh, min_gap=0.02):
+    """Per class the bias shift that lets the top `target` (or a few more: the cut moves down to the first gap of at least
+    min_gap) logits of this tensor clear sigmoid^-1(thresh); a class without such a gap is switched off."""
+    import math
+
+    import torch
+
+    out = []
+    for c, target in enumerate(targets):
+        v = torch.sort(logits[..., c].flatten(), descending=True).values
+        cut = None
+        for t in range(target, min(3 * target + 3, v.numel() - 1)):
+            if (v[t - 1] - v[t]).item() >= min_gap:
+                cut = 0.5 * (v[t - 1] + v[t]).item()
+                break
+        out.append(-20.0 if cut is None else math.log(thresh / (1 - thresh)) - cut)
+    return torch.tensor(out)
+
+
+def state_dicts(log=None):
+    from oracle import hostlogic as hl
+    from oracle import pipeline as op
+    from yomitoku_amd.utils.synth import dbnet_state_dict, parseq_state_dict, synthetic_page_with_truth
+    from yomitoku_amd.utils.synth_rtdetr import rtdetr_state_dict
+
+    sds = {"det": dbnet_state_dict(SEEDS["det"][0], **SEEDS["det"][1]), "rec": parseq_state_dict(SEEDS["rec"][0], **SEEDS["rec"][1]),
+           "lay": rtdetr_state_dict(SEEDS["lay"][0], **SEEDS["lay"][1]), "tab": rtdetr_state_dict(SEEDS["tab"][0], **SEEDS["tab"][1])}
+    page = synthetic_page_with_truth(3, 1000, 1400)[0]
+    preds, _ = op.layout(sds["lay"], page)
+    sds["lay"]["decoder.dec_score_head.5.bias"] = sds["lay"]["decoder.dec_score_head.5.bias"] + _class_shifts(preds["pred_logits"], LAYOUT_TARGETS, 0.5)
+    _, det = op.layout(sds["lay"], page)
+    tables = hl.layout_elements(det)["tables"]
+    if not tables:
+        raise RuntimeError("the calibrated layout head finds no table on the calibration page")
+    (tp, _), = op.tables(sds["tab"], page, [tables[0]["box"]])
+    sds["tab"]["decoder.dec_score_head.5.bias"] = sds["tab"]["decoder.dec_score_head.5.bias"] + _class_shifts(tp["pred_logits"], TABLE_TARGETS, 0.4)
+    if log:
+        log(f"calibrated heads: layout bias {sds['lay']['decoder.dec_score_head.5.bias'].tolist()}, table bias {sds['tab']['decoder.dec_score_head.5.bias'].tolist()}")
+    return sds
+
+
+def pages(n, first_seed=3):
+    from yomitoku_amd.utils.synth import synthetic_page_with_truth
+
+    return [synthetic_page_with_truth(first_seed + i, *SHAPES[i % len(SHAPES)])[0] for i in range(n)]
+
+
+# ---------------------------------------------------------------------------------------------- leaf comparison
+STAGE_LEAVES = {
+    "words": ("points", "content", "direction"),
+    "paragraphs": ("box", "contents", "direction", "order", "role"),
+    "figures": ("box", "order", "direction"),
+}
+
+
+def _flat(value):
+    """Discrete leaves of a nested value (floats are not discrete leaves)."""
+    if isinstance(value, dict):
+        out = []
+        for k in sorted(value):
+            out += _flat(value[k])
+        return out
+    if isinstance(value, (list, tuple)):
+        out = []
+        for v in value:
+            out += _flat(v)
+        return out
+    return [] if isinstance(value, float) else [value]
+
+
+def _table_leaves(t):
+    lines = [[ln["box"] for ln in t[k]] for k in ("rows", "cols", "spans")]
+    return _flat([t["box"], t["n_row"], t["n_col"], t["order"], lines, [[c[k] for k in ("col", "row", "col_span", "row_span", "box", "contents")] for c in t["cells"]]])
+
+
+def stage_leaves(page):
+    """{"words": [leaves of word 0, leaves of word 1, ...], ...}: one list of discrete leaves per element."""
+    out = {s: [_flat([e[k] for k in keys]) for e in page[s]] for s, keys in STAGE_LEAVES.items()}
+    out["figures"] = [a + _flat([[p[k] for k in STAGE_LEAVES["paragraphs"]] for p in f["paragraphs"]]) for a, f in zip(out["figures"], page["figures"])]
+    out["tables"] = [_table_leaves(t) for t in page["tables"]]
+    out["cells"] = [_flat([c[k] for k in ("col", "row", "col_span", "row_span", "box", "contents")]) for t in page["tables"] for c in t["cells"]]
+    return out
+
+
+def compare_pages(got, want):
+    """Per stage: (leaves on the reference side, leaves differing, elements on either side).  Elements are compared in
+    order - the order IS part of the contract (detector order of the words, reading order of the rest); an element
+    without a partner counts all of its leaves."""
+    a, b = stage_leaves(got), stage_leaves(want)
+    report = {}
+    for stage in b:
+        total = differing = 0
+        for i in range(max(len(a[stage]), len(b[stage]))):
+            x = a[stage][i] if i < len(a[stage]) else None
+            y = b[stage][i] if i < len(b[stage]) else None
+            if x is None or y is None:
+                n = len(x if y is None else y)
+                total += n
+                differing += n
+            elif len(x) != len(y):
+                total += max(len(x), len(y))
+                differing += max(len(x), len(y))
+            else:
+                total += len(y)
+                differing += sum(1 for p, q in zip(x, y) if p != q)
+        report[stage] = {"leaves": total, "differing": differing, "elements": [len(a[stage]), len(b[stage])]}
+    scores = {"det_score": 0.0, "rec_score": 0.0}
+    if len(got["words"]) == len(want["words"]):
+        for w, v in zip(got["words"], want["words"]):
+            for k in scores:
+                scores[k] = max(scores[k], abs(w[k] - v[k]))
+    report["max_abs_score_diff"] = scores if len(got["words"]) == len(want["words"]) else None
+    return report
+
+
+# ---------------------------------------------------------------------------------------------- roots and margins
+def _rtdetr_roots(op, got, want, size_wh, thresh, nc, nq):
+    """Thresholded detections of the two sides from their own logits / boxes: the margins of what differs."""
+    import numpy as np
+
+    roots = []
+    post = [op.rtdetr_post(p["pred_logits"], p["pred_boxes"], size_wh, thresh, nc, nq)[0] for p in (got, want)]
+    raw = [op.rtdetr_post(p["pred_logits"], p["pred_boxes"], size_wh, -1.0, nc, nq)[0] for p in (got, want)]  # every query, sorted by score
+    if len(post[0]["labels"]) != len(post[1]["labels"]):
+        # the sides disagree about which scores clear the threshold: the scores closest to it on either side
+        near = min(float(np.abs(r["scores"] - thresh).min()) for r in raw)
+        roots.append({"what": "detections kept", "kept": [int(len(p["labels"])) for p in post], "margin": near, "unit": "score"})
+        return roots
+    if post[0]["labels"].tolist() != post[1]["labels"].tolist():
+        # same number kept, another order or class: two scores a hair apart swapped ranks
+        k = int(np.flatnonzero(post[0]["labels"] != post[1]["labels"])[0])
+        s = post[1]["scores"]
+        gap = float(min(abs(s[k] - s[k - 1]) if k > 0 else 1.0, abs(s[k] - s[k + 1]) if k + 1 < len(s) else 1.0))
+        roots.append({"what": "rank of two detections", "at": k, "margin": gap, "unit": "score"})
+        return roots
+    ib = [p["boxes"].astype(int) for p in post]
+    if not np.array_equal(ib[0], ib[1]):
+        # an integer coordinate truncates differently: how far the float is from the integer step, on the nearer side
+        where = np.argwhere(ib[0] != ib[1])
+        worst = 0.0
+        for r, c in where:
+            x, y = float(post[0]["boxes"][r, c]), float(post[1]["boxes"][r, c])
+            step = float(max(int(x), int(y)))  # the integer boundary between the two truncations
+            worst = max(worst, min(abs(x - step), abs(y - step)))
+        roots.append({"what": "integer box coordinates", "coordinates": int(len(where)), "margin": worst, "unit": "pixel"})
+    return roots
+
+
+def roots_of_difference(an, op, sds, ocfg, img, keep, product_page, oracle_page, thresholds):
+    """Stage by stage, on the continuous outputs both sides produce for this page."""
+    import numpy as np
+    import torch
+
+    roots = []
+    det, lp, ts = an.text_detector, an.layout.layout_parser, an.layout.table_structure_recognizer
+    # ---- detector: map, binarisation, box scores
+    prob = det.model(det.preprocess(img))["binary"].cpu()[0, 0].numpy()
+    ref = keep["prob"][0, 0].numpy()
+    t = thresholds["thresh"]
+    flipped = (prob > t) != (ref > t)
+    entry = {"stage": "detector", "max_abs_map_diff": float(np.abs(prob - ref).max()), "pixels_across_the_threshold": int(flipped.sum())}
+    if flipped.any():
+        entry["margin"] = float(max(np.abs(ref[flipped] - t).max(), np.abs(prob[flipped] - t).max()))
+        entry["unit"] = "probability"
+    gq, oq = [w["points"] for w in product_page["words"]], [w["points"] for w in oracle_page["words"]]
+    if gq != oq:
+        _, quads_on_product_map, scores_on_product_map = op.detect(sds["det"], img, prob=torch.from_numpy(prob)[None, None])
+        entry["boxes_differ"] = True
+        entry["oracle_boxes_on_the_product_map_equal_the_products"] = [[[int(x), int(y)] for x, y in q] for q in quads_on_product_map] == gq
+        # box scores next to box_thresh (a box present on one side only)
+        bt = thresholds["box_thresh"]
+        near = [abs(s - bt) for s in list(keep["det_scores"]) + list(scores_on_product_map)]
+        entry["nearest_box_score_to_box_thresh"] = float(min(near)) if near else None
+        if len(gq) != len(oq) and near:
+            entry["margin"] = max(entry.get("margin", 0.0), float(min(near)))
+            entry["unit"] = "probability"
+    if flipped.any() or gq != oq:
+        roots.append(entry)
+    # ---- layout
+    preds = {k: v.cpu().numpy() for k, v in lp.model(lp.preprocess(img)).items()}
+    want = {k: v.numpy() for k, v in keep["lay_preds"].items()}
+    h, w = img.shape[:2]
+    for r in _rtdetr_roots(op, preds, want, (w, h), 0.5, 6, 300):
+        roots.append(dict(r, stage="layout", max_abs_logit_diff=float(np.abs(np.sort(preds["pred_logits"].ravel()) - np.sort(want["pred_logits"].ravel())).max())))
+    # ---- tables: the oracle's own table boxes, through both nets
+    boxes = [t_["box"] for t_ in keep["layout_groups"]["tables"]]
+    if boxes:
+        batch, metas = ts.preprocess(img, boxes)
+        tp = ts.model(batch)
+        for i, (meta, (rp, _, _)) in enumerate(zip(metas, keep["tab_raw"])):
+            one = {"pred_logits": tp["pred_logits"][i : i + 1].cpu().numpy(), "pred_boxes": tp["pred_boxes"][i : i + 1].cpu().numpy()}
+            th, tw = meta["size"]
+            for r in _rtdetr_roots(op, one, {k: v.numpy() for k, v in rp.items()}, (tw, th), 0.4, 3, 300):
+                roots.append(dict(r, stage="tables", table=i))
+    # ---- recogniser: words with the same quad and another string
+    if gq == oq:
+        for k, (a, b) in enumerate(zip(product_page["words"], oracle_page["words"])):
+            if a["content"] != b["content"]:
+                roots.append({"stage": "recogniser", "word": k, "strings": [a["content"][:16], b["content"][:16]], "rec_scores": [a["rec_score"], b["rec_score"]],
+                              "margin": None, "unit": "none: an arg-max moved (scores of both sides given)"})
+    return roots
+
+
+def classify(roots, borderline):
+    """borderline: every root has a margin below the bound; failure: some root has a larger one or none at all."""
+    if not roots:
+        return "unexplained"
+    return "borderline" if all(r.get("margin") is not None and r["margin"] < borderline for r in roots) else "failure"
+
+
+# ---------------------------------------------------------------------------------------------- the run
+def evaluate(n_pages, borderline=2e-3, modes=("split", "exact"), first_seed=3, log=print, only=None):
+    """`only`: indices into the page list to keep (the GPU test runs two pages that carry tables)."""
+    import torch
+
+    from oracle import pipeline as op
+    from oracle.parseq import PRESETS, make_cfg
+    from yomitoku_amd import DocumentAnalyzer
+
+    sds = state_dicts(log)
+    imgs = pages(n_pages, first_seed)
+    if only is not None:
+        imgs = [imgs[i] for i in only]
+        n_pages = len(imgs)
+    an = DocumentAnalyzer(configs=LITE, device="cuda:0")
+    nets = {"det": an.text_detector.model, "rec": an.text_recognizer.model, "lay": an.layout.layout_parser.model,
+            "tab": an.layout.table_structure_recognizer.model}
+    for k, net in nets.items():
+        net.load_state_dict(sds[k])
+    ocfg = make_cfg(**PRESETS["parseq-tiny-dynw-v4"])
+    thresholds = {"thresh": float(an.text_detector.post_processor.thresh), "box_thresh": float(an.text_detector.post_processor.box_thresh)}
+    product = {}
+    for mode in modes:
+        for net in nets.values():
+            net.set_conv_split(0 if mode == "exact" else None)
+        t0 = time.perf_counter()
+        out = an.serve(imgs)
+        torch.cuda.synchronize()
+        bad = [i for i, o in enumerate(out) if isinstance(o, Exception)]
+        if bad:
+            raise RuntimeError(f"serve failed on pages {bad}: {out[bad[0]]!r}")
+        product[mode] = [o.model_dump() for o in out]
+        log(f"product, {mode}: {len(imgs)} pages in {time.perf_counter() - t0:.1f} s")
+    result = {"pages": n_pages, "first_seed": first_seed, "borderline": borderline, "modes": {m: {"stages": {}, "pages_differing": [], "verdicts": {}} for m in modes},
+              "seeds": {k: v[0] for k, v in SEEDS.items()}, "per_page": []}
+    t_oracle = 0.0
+    for i, img in enumerate(imgs):
+        keep = {}
+        t0 = time.perf_counter()
+        want = op.analyze(sds, ocfg, img, an.text_recognizer.charset, keep=keep)
+        t_oracle += time.perf_counter() - t0
+        row = {"page": i, "shape": list(img.shape[:2]), "oracle_counts": {"words": len(want["words"]), "paragraphs": len(want["paragraphs"]), "tables": len(want["tables"]),
+                                                                             "cells": sum(len(t["cells"]) for t in want["tables"]), "figures": len(want["figures"])}}
+        for mode in modes:
+            rep = compare_pages(product[mode][i], want)
+            acc = result["modes"][mode]["stages"]
+            for stage, r in rep.items():
+                if stage == "max_abs_score_diff":
+                    continue
+                s = acc.setdefault(stage, {"leaves": 0, "differing": 0})
+                s["leaves"] += r["leaves"]
+                s["differing"] += r["differing"]
+            differs = any(r["differing"] for k, r in rep.items() if k != "max_abs_score_diff")
+            row[mode] = {"stages": {k: r for k, r in rep.items() if k != "max_abs_score_diff" and r["differing"]}, "max_abs_score_diff": rep["max_abs_score_diff"]}
+            if differs:
+                for net in nets.values():
+                    net.set_conv_split(0 if mode == "exact" else None)
+                roots = roots_of_difference(an, op, sds, ocfg, img, keep, product[mode][i], want, thresholds)
+                verdict = classify(roots, borderline)
+                row[mode].update(roots=roots, verdict=verdict)
+                result["modes"][mode]["pages_differing"].append(i)
+                result["modes"][mode]["verdicts"][verdict] = result["modes"][mode]["verdicts"].get(verdict, 0) + 1
+        result["per_page"].append(row)
+        log(f"page {i} {row['shape']}: oracle {row['oracle_counts']} " + " ".join(f"{m}: {row[m].get('verdict', 'equal')}" for m in modes))
+    for net in nets.values():
+        net.set_conv_split(None)
+    an.close()
+    result["oracle_seconds_per_page"] = round(t_oracle / max(1, n_pages), 2)
+    result["totals"] = {k: sum(r["oracle_counts"][k] for r in result["per_page"]) for k in ("words", "paragraphs", "tables", "cells", "figures")}
+    result["failures"] = sum(v for m in modes for k, v in result["modes"][m]["verdicts"].items() if k != "borderline")
+    return result
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--pages", type=int, default=16)
+    ap.add_argument("--first-seed", type=int, default=3)
+    ap.add_argument("--borderline", type=float, default=2e-3)
+    ap.add_argument("--modes", default="split,exact")
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    import torch
+
+    torch.set_num_threads(max(1, min(int(os.environ.get("YMK_ORACLE_THREADS", 32)), torch.get_num_threads())))
+    result = evaluate(args.pages, args.borderline, tuple(args.modes.split(",")), args.first_seed, log=lambda s: print(s, file=sys.stderr, flush=True))
+    text = json.dumps(result, ensure_ascii=False, indent=1)
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        with open(args.out, "w", encoding="utf-8") as f:
+            f.write(text + "\n")
+    summary = {k: result[k] for k in ("pages", "totals", "failures", "oracle_seconds_per_page")}
+    summary["modes"] = {m: {"stages": v["stages"], "pages_differing": v["pages_differing"], "verdicts": v["verdicts"]} for m, v in result["modes"].items()}
+    print(json.dumps(summary, ensure_ascii=False))
+    return 0 if result["failures"] == 0 else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -23,11 +23,17 @@ def main():
                     "text_recognizer": {"model_name": "parseq-tiny-dynw-v4", "from_pretrained": False, "dynamic_width": True, "batch_bucketing": True, "source_downscale": True}},
             "layout_analyzer": {"layout_parser": {"from_pretrained": False}, "table_structure_recognizer": {"from_pretrained": False}}}
     an = DocumentAnalyzer(configs=lite, device="cuda:0")
-    an.text_detector.model.load_state_dict(dbnet_state_dict(1234, out_bias=-2.0))
-    an.text_recognizer.model.load_state_dict(parseq_state_dict(1235, eos_bias=6.0))
-    an.layout.layout_parser.model.load_state_dict(rtdetr_state_dict(1240, num_classes=6, score_bias=-2.0))
-    an.layout.table_structure_recognizer.model.load_state_dict(rtdetr_state_dict(1241, num_classes=3, score_bias=-1.0))
-    pages = [synthetic_page_with_truth(100 + i, *((1600, 1200) if i % 3 else (1200, 1600)))[0] for i in range(n)]
+    # checkpoints and pages of tools/e2e_oracle_eval.py: class logits spread and biased per class (from the CPU oracle's logits
+    # on one calibration page) so that the pages carry paragraphs with roles AND tables with rows, columns and cells - with the
+    # plain seeded heads of rounds 4-5 this tool's pages had no table at all
+    import e2e_oracle_eval as ev
+
+    sds = ev.state_dicts()
+    an.text_detector.model.load_state_dict(sds["det"])
+    an.text_recognizer.model.load_state_dict(sds["rec"])
+    an.layout.layout_parser.model.load_state_dict(sds["lay"])
+    an.layout.table_structure_recognizer.model.load_state_dict(sds["tab"])
+    pages = ev.pages(n)
     every = [an.text_detector.model, an.layout.layout_parser.model, an.layout.table_structure_recognizer.model, an.text_recognizer.model]
     for m in every:
         m.set_conv_split(0)  # the yardstick: EXACT fp32 in all four nets (the models' default is the fp16 split since round 4)
@@ -64,7 +70,7 @@ def main():
             arms.append(("exact_fp32_other_summation_order_vs_fp32", [r.model_dump() for r in an.serve(pages)]))
         finally:
             _lib.debug_option("splitk_force", -1)
-    out = {"conv_split": code, "nets": "all four" if len(nets) == 4 else "detector + layout + table", "pages": n, "words": sum(len(d["words"]) for d in base), "tables": sum(len(d["tables"]) for d in base),
+    out = {"conv_split": code, "nets": "all four" if len(nets) == 4 else "detector + layout + table", "pages": n, "words": sum(len(d["words"]) for d in base), "tables": sum(len(d["tables"]) for d in base), "cells": sum(len(t["cells"]) for d in base for t in d["tables"]),
            "paragraphs": sum(len(d["paragraphs"]) for d in base)}
     for label, other in arms:
         st = {"discrete": 0, "leaves": 0, "float_rel": 0.0}
