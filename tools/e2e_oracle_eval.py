@@ -71,7 +71,7 @@ def _class_shifts(logits, targets, thresh, min_gap=0.02):
     return torch.tensor(out)
 
 
-def state_dicts(log=None):
+def state_dicts(log=None, layout_targets=None):
     from oracle import hostlogic as hl
     from oracle import pipeline as op
     from yomitoku_amd.utils.synth import dbnet_state_dict, parseq_state_dict, synthetic_page_with_truth
@@ -81,7 +81,7 @@ def state_dicts(log=None):
            "lay": rtdetr_state_dict(SEEDS["lay"][0], **SEEDS["lay"][1]), "tab": rtdetr_state_dict(SEEDS["tab"][0], **SEEDS["tab"][1])}
     page = synthetic_page_with_truth(3, 1000, 1400)[0]
     preds, _ = op.layout(sds["lay"], page)
-    sds["lay"]["decoder.dec_score_head.5.bias"] = sds["lay"]["decoder.dec_score_head.5.bias"] + _class_shifts(preds["pred_logits"], LAYOUT_TARGETS, 0.5)
+    sds["lay"]["decoder.dec_score_head.5.bias"] = sds["lay"]["decoder.dec_score_head.5.bias"] + _class_shifts(preds["pred_logits"], layout_targets or LAYOUT_TARGETS, 0.5)
     _, det = op.layout(sds["lay"], page)
     tables = hl.layout_elements(det)["tables"]
     if not tables:
@@ -263,7 +263,7 @@ def classify(roots, borderline):
 
 
 # ---------------------------------------------------------------------------------------------- the run
-def evaluate(n_pages, borderline=2e-3, modes=("split", "exact"), first_seed=3, log=print, only=None):
+def evaluate(n_pages, borderline=2e-3, modes=("split", "exact"), first_seed=3, log=print, only=None, layout_targets=None):
     """`only`: indices into the page list to keep (the GPU test runs two pages that carry tables)."""
     import torch
 
@@ -271,7 +271,7 @@ def evaluate(n_pages, borderline=2e-3, modes=("split", "exact"), first_seed=3, l
     from oracle.parseq import PRESETS, make_cfg
     from yomitoku_amd import DocumentAnalyzer
 
-    sds = state_dicts(log)
+    sds = state_dicts(log, layout_targets)
     imgs = pages(n_pages, first_seed)
     if only is not None:
         imgs = [imgs[i] for i in only]
@@ -341,12 +341,16 @@ def main() -> int:
     ap.add_argument("--first-seed", type=int, default=3)
     ap.add_argument("--borderline", type=float, default=2e-3)
     ap.add_argument("--modes", default="split,exact")
+    ap.add_argument("--layout-targets", default=None, help="six counts (tables, figures, paragraphs, headings, header, footer) for the calibration; "
+                    "more tables per page: 6,1,6,2,1,1")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     import torch
 
     torch.set_num_threads(max(1, min(int(os.environ.get("YMK_ORACLE_THREADS", 32)), torch.get_num_threads())))
-    result = evaluate(args.pages, args.borderline, tuple(args.modes.split(",")), args.first_seed, log=lambda s: print(s, file=sys.stderr, flush=True))
+    result = evaluate(args.pages, args.borderline, tuple(args.modes.split(",")), args.first_seed, log=lambda s: print(s, file=sys.stderr, flush=True),
+                      layout_targets=tuple(int(v) for v in args.layout_targets.split(",")) if args.layout_targets else None)
+    result["layout_targets"] = args.layout_targets
     text = json.dumps(result, ensure_ascii=False, indent=1)
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
