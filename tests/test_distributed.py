@@ -116,7 +116,8 @@ def _sharded_worker(rank, world, port, q):
     ok = server.analyzer.bias == 15.0 and server.replicas["ranks"] == world and server.replicas["weights_crc_equal"]
     ok = ok and server.shard(len(sources)) == list(range(rank, 7, world))
     ok = ok and server.budget["stage_threads"] == 9 and 1 <= server.budget["box_threads"] <= 4 and server.cores >= 1
-    res = server.run(sources, wave=2, in_flight=1)
+    res = server.run(sources, gather="objects", wave=2, in_flight=1)  # dealt dynamically, two sources per claim
+    ok = ok and server.last_run["assign"] == "dynamic" and server.last_run["claims"] >= 1
     if rank == 0:
         lanes = server.budget["rec_lanes"]
         ok = ok and [r if isinstance(r, tuple) else type(r).__name__ for r in res] == [
@@ -150,7 +151,7 @@ def test_serve_sharded_single_process():
 
     env = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
     try:
-        res = yd.serve_sharded([1, 2, [3, 4]], _StubAnalyzer, {"net": {"w": torch.ones(3)}}, backend="gloo", wave=4)
+        res = yd.serve_sharded([1, 2, [3, 4]], _StubAnalyzer, {"net": {"w": torch.ones(3)}}, backend="gloo", wave=4, gather="objects")
     finally:
         for k, v in env.items():
             if v is not None:
@@ -203,7 +204,7 @@ def _failing_worker(rank, world, port, q, mode):
 
     sources = [10, 11, -1, 13]
     try:
-        res = yd.serve_sharded(sources, _FailingAnalyzer, ck if rank == 0 else None, backend="gloo", wave=2)
+        res = yd.serve_sharded(sources, _FailingAnalyzer, ck if rank == 0 else None, backend="gloo", wave=2, gather="objects")
         outcome = ("ok", [e if isinstance(e, tuple) else f"{type(e).__name__}: {e}" for e in res] if res is not None else None)
     except yd.ShardedJobError as exc:
         outcome = ("job-error", sorted(exc.failures), str(exc))
@@ -269,8 +270,8 @@ def _forms_worker(rank, world, port, q):
     ck = (lambda: {"net": {"w": torch.arange(6, dtype=torch.float32)}}) if rank == 0 else None
     sources = [10, 11, -1, 13, 14]
     server = yd.ShardedServer(_StubAnalyzer, ck, backend="gloo", device="cpu")
-    as_json = server.run(sources, gather="json", wave=2)
-    mine = server.run(sources, gather=None, wave=2)
+    as_json = server.run(sources, wave=2)  # the default form: JSON text to rank 0
+    mine = server.run(sources, gather=None, assign="static", wave=2)
     server.close()
     ok = True
     if rank == 0:
@@ -296,3 +297,92 @@ def test_gather_forms_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == {0: True, 1: True}
+
+
+# ---------------------------------------------------------------------------------------------- dynamic page assignment
+class _TimedAnalyzer:
+    """A stub whose pages COST something: `heavy` pages (multiples of the world size: the whole static share of rank 0) take
+    ten times as long as the others - the 8 ... 30 ms spread of real pages with and without tables.  Reads its sources
+    lazily, a wave at a time, as DocumentAnalyzer.serve does."""
+
+    def __init__(self, device, checkpoints, budget):
+        self.world = int(os.environ["WORLD_SIZE"])
+        self.light = float(os.environ.get("YMK_TEST_LIGHT_S", "0.004"))
+
+    def serve(self, sources, wave=8, in_flight=4, with_source=False, rec_lanes=2):
+        import time
+
+        out = []
+        for si, page in enumerate(sources):
+            time.sleep(self.light * (10 if page % self.world == 0 else 1))
+            out.append((si, 0, {"page": page}))
+        self.finished = time.time()
+        return out
+
+    def close(self):
+        pass
+
+
+def _dealer_worker(rank, world, port, q, n_sources, wave):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import json
+    import time
+
+    from yomitoku_amd import distributed as yd
+
+    server = yd.ShardedServer(_TimedAnalyzer, None, backend="gloo", device="cpu", pin_cores=False)
+    sources = list(range(n_sources))
+    out = {}
+    for assign in ("dynamic", "static"):
+        server.barrier()
+        t0 = time.time()
+        res = server.run(sources, assign=assign, wave=wave)
+        mine = server.last_run["sources"]
+        out[assign] = {"seconds": server.analyzer.finished - t0, "sources": mine, "claims": server.last_run["claims"],
+                       "pages": [json.loads(t)["page"] for t in res] if rank == 0 else None}
+    again = server.run(sources, wave=wave)  # a second dynamic job deals from a fresh counter
+    out["again"] = [json.loads(t)["page"] for t in again] if rank == 0 else None
+    server.close()
+    q.put((rank, out))
+
+
+def _run_dealer(world, n_sources, wave):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dealer_worker, args=(r, world, port, q, n_sources, wave)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return got
+
+
+def _check_dealing(world, n_sources, wave, light=0.004):
+    got = _run_dealer(world, n_sources, wave)
+    for assign in ("dynamic", "static"):
+        assert got[0][assign]["pages"] == list(range(n_sources))          # every page once, in order, on rank 0
+        assert sum(got[r][assign]["sources"] for r in range(world)) == n_sources
+    assert got[0]["again"] == list(range(n_sources))
+    dyn = [got[r]["dynamic"]["seconds"] for r in range(world)]
+    sta = [got[r]["static"]["seconds"] for r in range(world)]
+    # static: rank 0 owns every heavy page (10 x) and finishes long after the others; dynamic: the ranks finish within about
+    # one chunk of each other - a chunk is `wave` pages, at most ceil(wave / world) of them heavy
+    heavy_per_chunk = -(-wave // world)
+    one_chunk = light * (heavy_per_chunk * 10 + (wave - heavy_per_chunk))
+    assert max(dyn) - min(dyn) <= 2.0 * one_chunk + 0.15, (dyn, one_chunk)
+    assert max(sta) - min(sta) > 3.0 * (max(dyn) - min(dyn)) and max(dyn) < 0.8 * max(sta), (dyn, sta)
+    # the busy rank asked less often: claims differ, and every rank claimed once more than it was served (the miss that ends its loop)
+    claims = [got[r]["dynamic"]["claims"] for r in range(world)]
+    assert sum(claims) == -(-n_sources // wave) + world, claims
+
+
+def test_pages_are_pulled_not_dealt_up_front_world2():
+    _check_dealing(2, 96, 4)
+
+
+def test_pages_are_pulled_not_dealt_up_front_world8():
+    _check_dealing(8, 512, 8)

@@ -55,12 +55,17 @@ def make_analyzer_factory(args, pages):
         with gpu:  # ONE GPU per rank: its stages never overlap in this model (the real streams overlap a little)
             time.sleep(SHARE[stage] * scale * n_pages / 16.0)
 
+    def cost(wave):
+        """Pages of device time in the wave: a page marked heavy (second byte of its first pixel: a page full of tables, 35
+        against 123 pages/s in bench.py's two serve legs) counts --heavy-factor times."""
+        return sum(args.heavy_factor if int(img[0, 0, 1]) == 255 else 1.0 for img in wave.imgs)
+
     class HostStageAnalyzer(da.DocumentAnalyzer):
         def _truth(self, wave):
             return [pages[int(img[0, 0, 0]) % len(pages)] for img in wave.imgs]
 
         def _stage_detect(self, wave):
-            device("detect", len(wave))
+            device("detect", cost(wave))
             wave.maps = [t[1] for t in self._truth(wave)]
 
         # _stage_boxes: the product's (C++ extraction on the rendered maps)
@@ -69,10 +74,10 @@ def make_analyzer_factory(args, pages):
             rec._collate_jobs = lambda jobs, flip=False, fixed_width=False: [None] * len(jobs)
             fake_pages = [torch.empty((p.shape[0], p.shape[1], 0), dtype=torch.uint8) for p in wave.pages]  # shape carriers
             wave.rec_plan = rec.plan_pages(fake_pages, [d.points for d in wave.dets])  # planner, bucketing, batching, chunking
-            device("crops", len(wave))
+            device("crops", cost(wave))
 
         def _stage_recognize(self, wave, lane=0):
-            device("recognize", len(wave))
+            device("recognize", cost(wave))
             rng = np.random.default_rng(wave.seq)
             stats = []
             for _, plans in wave.rec_plan["jobs"]:
@@ -85,7 +90,7 @@ def make_analyzer_factory(args, pages):
 
         # _stage_decode: the product's (token decode, NFKC, un-permutation)
         def _stage_layout(self, wave):
-            device("layout", len(wave))
+            device("layout", cost(wave))
             lp = self.layout.layout_parser
             cat = {c: i for i, c in lp.label_mapper.items()}
             nq, nc = int(lp._cfg.RTDETRTransformerv2.num_queries), int(lp._cfg.RTDETRTransformerv2.num_classes)
@@ -105,7 +110,7 @@ def make_analyzer_factory(args, pages):
             lp, ts = self.layout.layout_parser, self.layout.table_structure_recognizer
             wave.lay_parsed = lp.pages_from_raw(wave.lay_raw)  # the product's post-processor + containment filters
             wave.lay_raw = None
-            device("tables", len(wave))
+            device("tables", cost(wave))
             nq, nc = int(ts._cfg.RTDETRTransformerv2.num_queries), int(ts._cfg.RTDETRTransformerv2.num_classes)
             cat = {c: i for i, c in ts.label_mapper.items()}
             raw = []
@@ -165,11 +170,17 @@ def rank_main(rank, world, port, args, q):
         pages.append((img, render_truth_map(quads, (h, w), imaging.resize_shortest_edge_dims(h, w, 1280, 1600)), quads, tables, paragraphs))
     server = yd.ShardedServer(make_analyzer_factory(args, pages), None, backend="gloo", device="cpu")
     sources = [pages[i % len(pages)][0] for i in range(args.pages)]
-    server.serve_local(sources[: 2 * args.wave * world], wave=args.wave, in_flight=args.in_flight)  # warm-up: imports, pools, pydantic
+    if args.heavy != "none":  # a mix of page costs: every world-th page (a whole static share) or a seeded quarter of the pages
+        rng = np.random.default_rng(7)
+        for i in range(args.pages):
+            if (i % world == 0) if args.heavy == "one-rank" else (rng.random() < 0.25):
+                sources[i] = sources[i].copy()
+                sources[i][0, 0, 1] = 255
+    server.serve_local(sources[: 2 * args.wave * world], wave=args.wave, in_flight=args.in_flight, assign=args.assign)  # warm-up: imports, pools, pydantic
     server.barrier()
     cpu0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
-    local = server.serve_local(sources, wave=args.wave, in_flight=args.in_flight)
+    local = server.serve_local(sources, wave=args.wave, in_flight=args.in_flight, assign=args.assign)
     t_serve = time.perf_counter() - t0
     cpu1 = resource.getrusage(resource.RUSAGE_SELF)
     t1 = time.perf_counter()
@@ -179,7 +190,7 @@ def rank_main(rank, world, port, args, q):
     failed = sum(isinstance(e, BaseException) for _, _, e in local)
     row = {"rank": rank, "pages": n_local, "failed": failed, "serve_s": round(t_serve, 3), "pages_per_s": round(n_local / t_serve, 1),
            "cpu_s_per_page": round(((cpu1.ru_utime - cpu0.ru_utime) + (cpu1.ru_stime - cpu0.ru_stime)) / max(1, n_local), 4),
-           "gather_s": round(t_gather, 3), "cores": server.cores, "budget": server.budget}
+           "gather_s": round(t_gather, 3), "cores": server.cores, "budget": server.budget, "claims": server.last_run["claims"]}
     if rank == 0:
         import pickle
 
@@ -218,7 +229,11 @@ def main():
     ap.add_argument("--wave", type=int, default=16)
     ap.add_argument("--in-flight", type=int, default=4)
     ap.add_argument("--gpu-ms-per-wave", type=float, default=145.0, help="device time of a 16-page wave (110 pages/s)")
-    ap.add_argument("--gather", default="objects", choices=["objects", "json", "none"], help="what travels to rank 0 (ShardedServer.run)")
+    ap.add_argument("--gather", default="json", choices=["objects", "json", "none"], help="what travels to rank 0 (ShardedServer.run)")
+    ap.add_argument("--assign", default="dynamic", choices=["dynamic", "static"], help="pages pulled a wave at a time (PageDealer) or dealt round-robin up front")
+    ap.add_argument("--heavy", default="none", choices=["none", "one-rank", "random"],
+                    help="page cost mix: every world-th page heavy (the whole static share of rank 0) or a seeded quarter of the pages")
+    ap.add_argument("--heavy-factor", type=float, default=3.5, help="device time of a heavy page in light pages (123 / 35 pages/s)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     import socket
@@ -243,6 +258,8 @@ def main():
                 "failed": sum(r["failed"] for r in rows),
                 "pages_per_s_per_rank_min": min(r["pages_per_s"] for r in rows), "pages_per_s_per_rank_max": max(r["pages_per_s"] for r in rows),
                 "job_pages_per_s": round(sum(r["pages"] for r in rows) / (max(r["serve_s"] for r in rows) + r0["gather_s"]), 1),
+                "assign": args.assign, "heavy": args.heavy, "serve_s_min": min(r["serve_s"] for r in rows), "serve_s_max": max(r["serve_s"] for r in rows),
+                "pages_per_rank": [r["pages"] for r in rows], "claims_per_rank": [r["claims"] for r in rows],
                 "gpu_bound_pages_per_s_per_rank": round(16e3 / args.gpu_ms_per_wave, 1),
                 "cpu_s_per_page": round(float(np.mean([r["cpu_s_per_page"] for r in rows])), 4),
                 "gather": args.gather, "rank0_gather_s": r0["gather_s"], "pickled_kb_per_page": r0.get("pickled_kb_per_page"), "json_kb_per_page": r0.get("json_kb_per_page"),

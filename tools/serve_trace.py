@@ -84,14 +84,30 @@ def main():
     ap.add_argument("--wave", type=int, default=8)
     ap.add_argument("--in-flight", type=int, default=3)
     ap.add_argument("--pages", type=int, default=64)
+    ap.add_argument("--unmodified", action="store_true", help="the product's own DocumentAnalyzer on the calibrated heads' own detections "
+                    "(bench.py's `pages_per_s_unmodified_serve` leg: ~10 tables / ~340 cells per page) instead of the headline's hand-overs")
+    ap.add_argument("--max-tables", type=int, default=0, help="TableStructureRecognizer.MAX_TABLES_PER_FORWARD for this run (0: the product's)")
     args = ap.parse_args()
+    if args.max_tables > 0:
+        from yomitoku_amd.table_structure_recognizer import TableStructureRecognizer
+
+        TableStructureRecognizer.MAX_TABLES_PER_FORWARD = args.max_tables
     sys.setswitchinterval(float(os.environ.get("YMK_SWITCH_INTERVAL", 2e-4)))
     device = bench.rank_device(0)
     sds = bench.make_checkpoints("lite")
     sds = bench.calibrate_heads(sds, device, bench.Page(0, device))
     pages = bench.make_pages(list(range(args.pages)), device)
-    an = bench.build_analyzer(device, sds, "lite")
-    an.truth = pages
+    if args.unmodified:
+        from yomitoku_amd import DocumentAnalyzer
+        from yomitoku_amd.utils.synth import dbnet_state_dict
+
+        sds = dict(sds, det=dbnet_state_dict(8, out_bias=-1.5))  # as bench.unmodified_serve_metrics: a detector whose noise yields boxes
+        an = DocumentAnalyzer(configs=bench.MODEL_SETS["lite"], device=str(device))
+        for net, key in zip(bench.analyzer_nets(an), ("det", "rec", "lay", "tab")):
+            net.load_state_dict(sds[key])
+    else:
+        an = bench.build_analyzer(device, sds, "lite")
+        an.truth = pages
     host = [p.img for p in pages]
     an.serve(host, wave=args.wave, in_flight=args.in_flight)  # warm-up: shapes, workspaces, pinned rings
     torch.cuda.synchronize()
@@ -154,7 +170,12 @@ def main():
     stages = {}
     for name, seq, n, a, b in trace:
         stages.setdefault(name, []).append((a - t0, b - t0, n))
-    out = {"pages_per_s": round(len(res) / dt, 2), "wall_s": round(dt, 4), "waves": len(stages.get("finish", [])),
+    ok = [r for r in res if not isinstance(r, BaseException)]
+    out = {"workload": "unmodified serve" if args.unmodified else "headline hand-overs", "max_tables_per_forward": an.layout.table_structure_recognizer.MAX_TABLES_PER_FORWARD,
+           "table_workspace_gb": round(an.layout.table_structure_recognizer.model.workspace_bytes / 2 ** 30, 2),
+           "units_per_page": {"words": round(float(np.mean([len(r.words) for r in ok])), 1), "tables": round(float(np.mean([len(r.tables) for r in ok])), 2),
+                              "cells": round(float(np.mean([sum(len(t.cells) for t in r.tables) for r in ok])), 1)} if ok else None,
+           "pages_per_s": round(len(res) / dt, 2), "wall_s": round(dt, 4), "waves": len(stages.get("finish", [])),
            "failed": sum(isinstance(r, BaseException) for r in res), "stages": {}}
     for name, spans in stages.items():
         d = np.array([b - a for a, b, _ in spans])

@@ -2,9 +2,11 @@
 
 The reference has no distributed code: pages are independent units (cli/main.py:116-120 loops
 them sequentially).  Here every rank (one process per GPU) holds a full replica of the models and
-takes a strided share of the pages; the only collective is a one-off broadcast of the packed
-checkpoint from rank 0 (RCCL over xGMI when the backend is "nccl"), so that weights are read /
-generated once.  There is no collective on the per-page path.
+PULLS its pages in chunks of one wave from a counter that rank 0 hosts (a TCPStore word: one atomic
+add per chunk, host sockets only) - a page costs anything between 8 and 30 ms depending on its
+tables, so a fixed share per rank would end ragged; the only collective is a one-off broadcast of
+the packed checkpoint from rank 0 (RCCL over xGMI when the backend is "nccl"), so that weights
+are read / generated once.  There is no collective on the per-page path.
 """
 
 from __future__ import annotations
@@ -37,8 +39,56 @@ def init(backend: str | None = None):
 
 def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     """Round-robin page assignment: item i goes to rank i % world (keeps ranks within one page
-    of each other for any n_items)."""
+    of each other for any n_items).  The static form (`ShardedServer.run(assign="static")`): page COUNTS are level, page
+    costs are not - `PageDealer` is what the sharded job uses by default."""
     return list(range(rank, n_items, world))
+
+
+class PageDealer:
+    """Dynamic page assignment for the ranks of one node: chunk k of the source list belongs to whichever rank asks for
+    "the next chunk" k-th.  The counter is one word of a TCPStore that rank 0 hosts (host sockets; `add` is atomic on the
+    server): no collective, nothing on the GPU path, and a rank that is busy with table-heavy pages simply asks less often.
+
+        dealer = PageDealer(rank, world)            # once per process group (rank 0 hosts, the port travels by broadcast)
+        for first, stop in dealer.chunks(job, n_sources, chunk):   # on every rank, lazily: a claim per chunk
+            ...
+
+    World size 1 needs no store: the chunks are dealt in order by a local counter."""
+
+    def __init__(self, rank: int, world: int, host: str | None = None):
+        self.rank, self.world = rank, world
+        self.store = None
+        self._local = {}
+        self.claims = 0
+        if world > 1:
+            from datetime import timedelta
+
+            host = host or os.environ.get("MASTER_ADDR", "127.0.0.1")
+            port = [None]
+            if rank == 0:
+                # port 0: the server picks a free one; the number travels to the other ranks through the process group
+                self.store = dist.TCPStore(host, 0, world, True, timeout=timedelta(seconds=300), wait_for_workers=False)
+                port[0] = self.store.port
+            dist.broadcast_object_list(port, src=0)
+            if rank != 0:
+                self.store = dist.TCPStore(host, int(port[0]), world, False, timeout=timedelta(seconds=300))
+
+    def claim(self, job: int, chunk: int) -> int:
+        """First source index of the next unclaimed chunk of `job` (may lie beyond the job's end: then there is none left)."""
+        self.claims += 1
+        if self.store is None:
+            first = self._local.get(job, 0)
+            self._local[job] = first + chunk
+            return first
+        return int(self.store.add(f"ymk/job{job}/next", chunk)) - chunk
+
+    def chunks(self, job: int, n_sources: int, chunk: int):
+        chunk = max(1, int(chunk))
+        while True:
+            first = self.claim(job, chunk)
+            if first >= n_sources:
+                return
+            yield first, min(first + chunk, n_sources)
 
 
 def gather_in_order(local: Sequence, n_items: int, rank: int, world: int) -> list | None:
@@ -117,11 +167,16 @@ def broadcast_state_dict(sd: Mapping[str, torch.Tensor] | None, src: int = 0, de
     meta = meta[0]
     if device is None:
         device = _collective_device()
-    bufs = _flat_buffers(meta, device, sd if rank == src else None)
+    bufs = _exchange(_flat_buffers(meta, device, sd if rank == src else None), src)
+    return sd if rank == src else _unflatten(bufs, meta)
+
+
+def _exchange(bufs: dict, src: int) -> dict:
+    """The collectives proper: nothing here can fail on one rank alone (buffers exist on every rank when it is entered)."""
     for c, (buf, numel) in bufs.items():
         if numel:
             dist.broadcast(buf, src=src)
-    return sd if rank == src else _unflatten(bufs, meta)
+    return bufs
 
 
 def state_dict_crc(sd: Mapping[str, torch.Tensor]) -> int:
@@ -240,12 +295,12 @@ class ShardedServer:
     WORLD_SIZE), each a full replica.
 
         server = ShardedServer(make_analyzer, checkpoints)      # init -> core slice -> broadcast -> replica report -> analyzer
-        results = server.run(sources, wave=8, in_flight=4)       # shard -> DocumentAnalyzer.serve -> ordered gather (rank 0)
+        results = server.run(sources, wave=16, in_flight=4)      # deal (PageDealer) -> DocumentAnalyzer.serve -> ordered gather (rank 0)
         server.close()
 
     make_analyzer(device, checkpoints, budget) builds this rank's DocumentAnalyzer from the broadcast checkpoints ({name:
     state dict}; `checkpoints` is that mapping - or a callable returning it - on rank 0 and ignored elsewhere).  Sources are
-    dealt round-robin BY SOURCE (a multi-frame file stays on one rank); an entry that failed stays an exception object in
+    dealt BY SOURCE (a multi-frame file stays on one rank), a wave's worth at a time, to whichever rank asks next; an entry that failed stays an exception object in
     its place, exactly as `serve` reports it, and cannot hold the other ranks (nothing on the per-page path communicates).
 
     Failures of the JOB (rank 0 cannot produce the checkpoints, a rank cannot build its analyzer, `serve` itself raises on a
@@ -265,11 +320,15 @@ class ShardedServer:
         self.device = torch.device(device)
         if self.device.type == "cuda":
             torch.cuda.set_device(self.device)
-        sds, head = None, [None]
+        sds, head, prepared = None, [None], {}
         if self.rank == 0:
             try:
                 sds = checkpoints() if callable(checkpoints) else checkpoints
-                head[0] = ("names", list(sds) if sds is not None else None)
+                if sds is not None:  # everything that can fail on the sender alone happens BEFORE the first collective: the
+                    for k in sds:    # flat messages are packed here, and a failure travels in `head` like a missing file does
+                        meta = _checkpoint_meta(sds[k])
+                        prepared[k] = (meta, _flat_buffers(meta, self.device, sds[k]))
+                head[0] = ("names", [(k, prepared[k][0]) for k in sds] if sds is not None else None)
             except Exception as exc:  # noqa: BLE001 - carried to the other ranks through the broadcast they are waiting in
                 head[0] = ("error", _describe(exc))
         if self.world > 1:
@@ -280,15 +339,40 @@ class ShardedServer:
         names = head[0][1]
         self.checkpoints = None
         if names is not None:
-            self.checkpoints = OrderedDict((k, broadcast_state_dict(sds[k] if self.rank == 0 else None, src=0, device=self.device))
-                                           for k in names)
+            error = None
+            if self.rank != 0:
+                try:
+                    prepared = {k: (meta, _flat_buffers(meta, self.device, None)) for k, meta in names}
+                except Exception as exc:  # noqa: BLE001 - a receiver that cannot hold the message says so before anybody sends
+                    error = _describe(exc)
+            self._agree("allocating the broadcast buffers", error)
+            if dist.is_initialized():
+                for k, _ in names:
+                    _exchange(prepared[k][1], 0)
+            self.checkpoints = OrderedDict((k, sds[k] if self.rank == 0 else _unflatten(prepared[k][1], meta)) for k, meta in names)
+            prepared = None
         self.replicas = replica_report(self.checkpoints, self.device) if self.checkpoints else None
         error = None
         try:
             self.analyzer = make_analyzer(self.device, self.checkpoints, self.budget)
         except Exception as exc:  # noqa: BLE001 - reported to every rank below
             error = _describe(exc)
-        self._agree("building the analyzer", error)
+        try:
+            self._agree("building the analyzer", error)
+        except ShardedJobError:
+            self._close_analyzer()  # a rank that DID build one gives its workspaces (tens of GB) back before it leaves
+            raise
+        self.dealer = PageDealer(self.rank, self.world)
+        self._jobs = 0
+        self.last_run = None
+
+    def _close_analyzer(self):
+        close = getattr(self.analyzer, "close", None)
+        if close is not None:
+            try:
+                close()
+            except Exception:  # noqa: BLE001 - on the way out of a failed job
+                pass
 
     def _agree(self, what: str, error: str | None):
         """One tiny all-gather of every rank's (ok | error text): raises ShardedJobError on ALL ranks when any rank failed."""
@@ -304,14 +388,35 @@ class ShardedServer:
     def shard(self, n_sources: int) -> List[int]:
         return shard_indices(n_sources, self.rank, self.world)
 
-    def serve_local(self, sources: Sequence, **serve_kwargs) -> list:
-        """This rank's share through DocumentAnalyzer.serve: [(global source index, frame index, entry)], in order."""
-        mine = self.shard(len(sources))
+    def serve_local(self, sources: Sequence, assign: str = "dynamic", chunk: int | None = None, **serve_kwargs) -> list:
+        """This rank's share through DocumentAnalyzer.serve: [(global source index, frame index, entry)], in order.
+        assign "dynamic" (default): the share is whatever this rank PULLS - `serve` reads its sources lazily (a new wave
+        only when a wave slot is free), and every `chunk` sources (default: one wave) the generator claims the next chunk
+        from the node's PageDealer; "static": source i belongs to rank i % world, known up front."""
+        if assign not in ("dynamic", "static"):
+            raise ValueError(f"assign must be 'dynamic' or 'static', got {assign!r}")
         serve_kwargs.setdefault("rec_lanes", self.budget["rec_lanes"])
-        local = self.analyzer.serve([sources[i] for i in mine], with_source=True, **serve_kwargs)
+        self._jobs += 1  # run() is called by every rank for every job: the job number is the same everywhere
+        if assign == "static":
+            mine = self.shard(len(sources))
+            feed = [sources[i] for i in mine]
+            claims0 = self.dealer.claims
+        else:
+            mine, claims0 = [], self.dealer.claims
+            size = int(chunk) if chunk else int(serve_kwargs.get("wave", 16))
+
+            def pull():
+                for first, stop in self.dealer.chunks(self._jobs, len(sources), size):
+                    for i in range(first, stop):
+                        mine.append(i)
+                        yield sources[i]
+
+            feed = pull()
+        local = self.analyzer.serve(feed, with_source=True, **serve_kwargs)
+        self.last_run = {"assign": assign, "sources": len(mine), "claims": self.dealer.claims - claims0}
         return [(mine[si], fi, portable_entry(entry)) for si, fi, entry in local]
 
-    def gather(self, local, form: str = "objects") -> list | None:
+    def gather(self, local, form: str = "json") -> list | None:
         """Every rank's (source, frame, entry) triples on rank 0, ordered by (source, frame): the entries alone are returned
         there, None elsewhere.  A host-side gather of Python objects, not a data-path collective.  `local` may also be
         {"error": text} - a rank whose share failed as a whole: the collectives still run on every rank and then all of them
@@ -328,7 +433,11 @@ class ShardedServer:
             raise ValueError(f"gather form must be 'objects' or 'json', got {form!r}")
         failed = local.get("error") if isinstance(local, dict) else None
         if form == "json" and failed is None:
-            local = [(si, fi, _entry_json(entry)) for si, fi, entry in local]
+            try:
+                local = [(si, fi, _entry_json(entry)) for si, fi, entry in local]
+            except Exception as exc:  # noqa: BLE001 - a schema that cannot be serialised fails this rank's share, IN the collective below
+                failed = _describe(exc)
+                local = {"error": failed}
         parts = [local if isinstance(local, dict) else list(local)]
         if self.world > 1:
             # all ranks learn about a failed rank (all_gather of one short string), rank 0 alone receives the results
@@ -350,13 +459,14 @@ class ShardedServer:
         merged = sorted((t for part in parts for t in part), key=lambda t: (t[0], t[1]))
         return [entry for _, _, entry in merged]
 
-    def run(self, sources: Sequence, gather: str | None = "objects", **serve_kwargs) -> list | None:
-        """shard -> serve -> gather.  gather: "objects" (default: rank 0 gets every page's DocumentAnalyzerSchema / exception
-        object, the others None), "json" (rank 0 gets the schemas as JSON text: see `gather`), or None - no result travels at
+    def run(self, sources: Sequence, gather: str | None = "json", assign: str = "dynamic", chunk: int | None = None, **serve_kwargs) -> list | None:
+        """deal -> serve -> gather.  assign / chunk: see `serve_local`.  gather: "json" (default: rank 0 gets every page as the
+        JSON text of its DocumentAnalyzerSchema - what a caller that writes the pages out wants, and nothing for rank 0 to
+        rebuild: see `gather`), "objects" (rank 0 gets the schema / exception objects themselves), or None - no result travels at
         all: EVERY rank returns its own [(global source index, frame index, entry)] and writes / forwards them itself, which is
         how a node of 8 GPUs keeps rank 0 out of the per-page path; a failed rank still fails the job on every rank."""
         try:
-            local = self.serve_local(sources, **serve_kwargs)
+            local = self.serve_local(sources, assign=assign, chunk=chunk, **serve_kwargs)
         except Exception as exc:  # noqa: BLE001 - the job failed on this rank: say so IN the collective the others will enter
             local = {"error": _describe(exc)}
         if gather is None:
@@ -372,6 +482,7 @@ class ShardedServer:
         close = getattr(self.analyzer, "close", None)
         if close is not None:
             close()
+        self.dealer = None  # (rank 0's store server goes with it)
         if destroy_group and self.world > 1 and dist.is_initialized():
             if not self.failed:  # after a job failure the peers may already be gone: no rendezvous, just leave
                 dist.barrier()

@@ -282,9 +282,12 @@ class PagePipeline:
         self._release(wave)
 
     # ------------------------------------------------------------------ caller side
-    def _launch(self, job, ids, imgs, retry=False):
-        t_start = time.perf_counter()
-        ring = self._rings.get()  # blocks while `in_flight` waves are out: back-pressure on decoding and staging
+    def _launch(self, job, ids, imgs, retry=False, ring=None, waited=0.0):
+        """`ring`: a wave slot the caller already holds (serve() takes the slot BEFORE it pulls the wave's sources; `waited`:
+        how long it waited for it), or None: taken here."""
+        t_start = time.perf_counter() - waited
+        if ring is None:
+            ring = self._rings.get()  # blocks while `in_flight` waves are out: back-pressure on decoding and staging
         t_ring = time.perf_counter()
         try:
             if self._gpu:
@@ -320,12 +323,15 @@ class PagePipeline:
             origin = []  # page id -> (source index, frame index)
             pend_ids, pend_imgs = [], []
 
+            held = [None, 0.0]  # the wave slot taken for the wave being collected, and how long the caller waited for it
+
             def flush():
                 nonlocal pend_ids, pend_imgs
                 if pend_ids:
                     ids, imgs, pend_ids, pend_imgs = pend_ids, pend_imgs, [], []
+                    ring, held[0] = held[0], None
                     try:
-                        self._launch(job, ids, imgs)
+                        self._launch(job, ids, imgs, ring=ring, waited=held[1] if ring is not None else 0.0)
                     except Exception as exc:  # noqa: BLE001 - e.g. a page that is not uint8 H x W x 3
                         if len(ids) == 1:
                             job.results[ids[0]] = exc
@@ -345,7 +351,20 @@ class PagePipeline:
                     except Exception as exc:  # noqa: BLE001
                         job.results[idx] = exc
 
-            for si, src in enumerate(sources):
+            # The slot of a wave is taken BEFORE the wave's first source is pulled: `sources` may be a generator that claims
+            # work from a shared counter (distributed.PageDealer) - a rank must not claim pages it has no room for yet, or the
+            # end of a sharded job is as ragged as a static deal.  (A slot held while nothing is pending is given back below.)
+            it = enumerate(sources)
+            while True:
+                if not pend_ids and held[0] is None:
+                    drain_retries()
+                    t_wait = time.perf_counter()
+                    held[0] = self._rings.get()
+                    held[1] = time.perf_counter() - t_wait
+                try:
+                    si, src = next(it)
+                except StopIteration:
+                    break
                 if isinstance(src, np.ndarray):
                     frames = [src]
                 else:
@@ -363,9 +382,11 @@ class PagePipeline:
                     pend_imgs.append(frame)
                     n += 1
                     if len(pend_ids) == self.wave:
-                        drain_retries()
                         flush()
             flush()
+            if held[0] is not None:  # the source list ended on a wave boundary
+                self._rings.put(held[0])
+                held[0] = None
             while True:
                 drain_retries()
                 with job.cond:
