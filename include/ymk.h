@@ -116,6 +116,12 @@ int ymk_det_preprocess(const unsigned char* bgr_dev, int h, int w, int oh, int o
 int ymk_pil_resize_to_chw(const unsigned char* page_dev, int page_w, int x0, int y0, const int* xbounds_dev,
                           const int* xcoef_dev, int ksize_x, const int* ybounds_dev, const int* ycoef_dev, int ksize_y,
                           int oh, int ow, float* x_dev, void* stream);
+/* ymk_pil_resize_batch_to_chw: ymk_pil_resize_to_chw for n crops in one launch (TableStructureRecognizer.preprocess loops over
+ *   the table boxes, table_structure_recognizer.py:169-186; here all crops of a forward share a launch).  blob_dev: int32
+ *   words - n records of ymk_pil_batch_record_words() words {page address low, high; page width; x0; y0; ksize_x; ksize_y;
+ *   word offsets into the blob of xbounds, xcoefs, ybounds, ycoefs; 0}, followed by the tables; x_dev: fp32 [n][3][oh][ow]. */
+int ymk_pil_resize_batch_to_chw(const int* blob_dev, int n, int oh, int ow, float* x_dev, void* stream);
+int ymk_pil_batch_record_words(void);
 int ymk_crop_batch(const unsigned char* page_dev, int page_h, int page_w, const void* descs_dev, int n, int max_warp_w,
                    int max_warp_h, unsigned char* scratch_dev, float* out_dev, int batch_w, int out_h, void* stream);
 /* ymk_crop_batch_levels: the same with `source_downscale` (data/dataset.py:26-41,64-79): descriptor.level picks the
@@ -171,8 +177,12 @@ int ymk_prof_begin(void);
  *                        5-10 / 12-14 (bf16 only): 64-k stages, loads two stages ahead, stores threaded through the MFMAs
  *   "gemm_row_limit" (0) > 0: linear layers cut their rows into chunks of at most this many (rounded down to 1024s) - the chunking
  *                        that keeps an A operand view below the 4 GiB a buffer descriptor addresses, forced at test sizes
- *   "astat" (1)          1: chip-filling pointwise layers with K <= 256 and Cout > 64 run on the A-stationary kernel; 0: the round-4
- *                        routing (A/B runs).  "conv_split_tile" 30 forces that kernel for every launch it can run (tests)
+ *   "astat" (1)          1: chip-filling pointwise layers with K <= 192 and Cout > 64 run on the A-stationary kernel (K = 256 stays on
+ *                        the register-staged kernel, where it measured ahead); 0: the round-4 routing (A/B runs).
+ *                        "conv_split_tile" 30 forces that kernel for every launch it can run, K <= 256 (tests)
+ *   "ar_publish" (1)     how a greedy step of the recogniser tells the host whether rows are still open: 1 = a one-thread launch
+ *                        behind the greedy kernel writes the mapped host word (rows store a flag), 0 = the kernel's
+ *                        last-arriving block does (rows count: rounds 1-5; A/B runs, tools/stress_call.py)
  *   "parseq_no_ln_fusion" (0)  1: the ViT blocks' LayerNorms as launches of their own (A/B runs, tests); 0: folded into the
  *                        operand load of the q|k|v and fc1 GEMMs wherever the A-stationary kernel takes them
  *   "act_planes" (1)     1: the tensor between a bottleneck's 1 x 1 reduction and its 3 x 3 convolution lives in HBM as the two fp16
@@ -188,7 +198,15 @@ int ymk_debug_option(const char* key, int value);
 /* Launch counters since the process started, for tests that must know a route was really taken: "astat_launches" (the
  * A-stationary short-K kernel), "ln_fused_launches" (those of them that carried a LayerNorm in their operand load),
  * "planes_written_launches" / "planes_read_launches" (convolutions whose output / input lives in HBM as fp16 planes),
- * "mlp_fused_launches" (ViT MLP halves run as one launch). */
+ * "mlp_fused_launches" (ViT MLP halves run as one launch).
+ * And what a forward must NOT do (round 6): a ymk_*_forward whose workspace the caller sized first (ymk_model_reserve) never
+ * allocates or frees device / pinned memory, never builds a weight copy and never waits for a stream - the split weight
+ * copies and the max|x| words of the precision a model runs are built by ymk_model_finalize (and by ymk_model_set_param
+ * when "conv_split" changes afterwards).  The fallbacks remain for callers of the bare ABI and are counted:
+ * "allocs_in_forward" (hipMalloc / hipFree / hipHostMalloc / hipHostFree issued inside a forward), "arena_grows_in_forward"
+ * (of those: the workspace grown because no reservation covered the shape), "lazy_panel_builds" (weight copies built on
+ * first use: the process-wide precision switched after finalize), "syncs_in_forward" (stream waits those fallbacks made).
+ * tests/test_serving_gpu.py holds all four at zero over both entry points of the analyzer. */
 int ymk_stat(const char* key, int64_t* value);
 /* out4 = {launches checked, records below the true max|x| (a bug), records more than 2^8 above it, largest record / truth
  * exponent distance} since the process started; synchronises the device. */

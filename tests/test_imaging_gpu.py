@@ -40,6 +40,33 @@ def test_rtdetr_preprocess_is_pillow_exact(dev, h, w, box):
     assert torch.equal(out.cpu(), ref[0])
 
 
+def test_rtdetr_batch_of_crops_is_pillow_exact(dev):
+    """imaging.rtdetr_batch_tensor (every crop of a forward in ONE launch, one blob of coefficient tables): each crop equals
+    Pillow's resize of it - crops of two pages of different sizes, whole pages, repeated sizes, out-of-range boxes clamped as
+    numpy slices them, a second call through the other staging buffer."""
+    from oracle.preprocess import rtdetr_preprocess
+    from yomitoku_amd import imaging
+
+    imgs = [_page(11, 1600, 1200), _page(12, 1000, 1400)]
+    pages = [imaging.page_to_device(img, dev) for img in imgs]
+    crops = [(0, None), (1, None), (0, (100, 200, 900, 700)), (1, (3, 5, 77, 41)), (1, (200, 100, 1400, 1000)), (0, (100, 200, 900, 700)),
+             (0, (-5, -7, 300, 2000)), (1, (640, 0, 1280, 640))]
+    for turn in range(3):  # three calls: both pinned staging buffers of the thread, and one of them a second time
+        out, metas = imaging.rtdetr_batch_tensor(pages, crops[turn:])
+        assert out.shape == (len(crops) - turn, 3, 640, 640)
+        for k, (p, box) in enumerate(crops[turn:]):
+            clamped = None if box is None else (max(box[0], 0), max(box[1], 0), min(box[2], imgs[p].shape[1]), min(box[3], imgs[p].shape[0]))
+            ref, size = rtdetr_preprocess(imgs[p], clamped)
+            assert metas[k]["size"] == size and metas[k]["offset"] == ((0, 0) if clamped is None else clamped[:2])
+            assert torch.equal(out[k].cpu(), ref[0]), (turn, k)
+            one, osize, off = imaging.rtdetr_tensor(pages[p], box)
+            assert torch.equal(one, out[k]) and osize == size and off == metas[k]["offset"]
+    empty, metas = imaging.rtdetr_batch_tensor(pages, [])
+    assert empty.shape == (0, 3, 640, 640) and metas == []
+    with pytest.raises(ValueError):
+        imaging.rtdetr_batch_tensor(pages, [(0, (50, 50, 50, 90))])
+
+
 def _quads(rng, h, w, n):
     quads = []
     for k in range(n):

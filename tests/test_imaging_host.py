@@ -52,3 +52,20 @@ def test_planner_edge_cases():
         plans = planner((100, 100), quads)
         assert [p is None for p in plans] == [True, False, True] and plans[1].index == 1
     assert imaging.plan_crops((100, 100), quads[:1]) == [None]
+
+
+def test_pil_coefficient_tables_in_array_form_equal_the_loop():
+    """imaging.pil_bilinear_coeffs (all outputs at once, float64, weights summed tap by tap) against the statement-for-statement
+    form of Pillow's precompute_coeffs / normalize_coeffs_8bpc it replaced: bounds and 22-bit coefficients equal, bit for bit,
+    at up-scales, down-scales by 1 ... 8, odd sizes and the sizes around a power of two (a table crop has any size)."""
+    import random
+
+    from yomitoku_amd import imaging as im
+
+    rng = random.Random(1)
+    cases = [(1, 640), (2, 640), (37, 640), (333, 640), (639, 640), (640, 640), (641, 640), (1000, 640), (1279, 640), (1280, 640), (1281, 640),
+             (1400, 640), (4800, 640), (5000, 640), (100, 960), (2000, 960), (7, 3), (3, 7)] + [(rng.randint(1, 3000), 640) for _ in range(60)]
+    for a, b in cases:
+        want, got = im._pil_bilinear_coeffs_scalar(a, b), im.pil_bilinear_coeffs(a, b)
+        assert want[2] == got[2] and got[0].dtype == np.int32 and got[1].dtype == np.int32, (a, b)
+        assert np.array_equal(want[0], got[0]) and np.array_equal(want[1], got[1]), (a, b)

@@ -39,6 +39,8 @@ SIGNATURES = {
         [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
          c_void_p],
     ),
+    "ymk_pil_resize_batch_to_chw": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ymk_pil_batch_record_words": (c_int, []),
     "ymk_crop_batch": (
         c_int,
         [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p],

@@ -1,6 +1,7 @@
-// A-stationary fp16-split 1 x 1 convolution for short K (K <= 256).  Round 4 built and validated it behind a test operator;
-// round 5 routes the library's short-K pointwise layers to it (conv2d_split in ymk_conv_split.hip: the PARSeq encoder's qkv /
-// proj / fc1, the ResNet expands with their residual, the decoders' 256 -> 256 projections) and folds the LayerNorm in front of
+// A-stationary fp16-split 1 x 1 convolution for short K (the kernel runs K <= 256; the router sends it K <= 192: at K = 256 its
+// 64-column form measured behind the register-staged kernel wherever a residual is read, ymk_conv_split.hip route_f16).  Round 4
+// built and validated it behind a test operator; round 5 routes the library's short-K pointwise layers to it (conv2d_split: the
+// PARSeq encoder's qkv / proj / fc1, the ResNet expands 64 -> 256 / 128 -> 512 with their residual, the vocabulary head) and folds the LayerNorm in front of
 // a linear layer into its operand load.  Why it exists: profiles/r04_conv_two_roof_by_layer.md (the K = 192 linear layers of
 // the PARSeq encoder at 0.22-0.45 of their HBM roof, the ResNet expands at 0.38-0.57) and
 // profiles/r04_conv_f16_short_k_pmc_pass*.csv (their waves wait two thirds of their cycles, 16 VALU + 12.6 SALU instructions

@@ -222,6 +222,55 @@ __global__ void k_pil_resize_to_chw(PilRes p) {
 #pragma unroll
   for (int c = 0; c < 3; ++c) p.dst[c * plane + (size_t)y * p.ow + x] = (float)clip8(acc[c]) / 255.0f;  // ToTensor
 }
+// The same for n crops in ONE launch (a wave's table crops: ~170, each with its own size and coefficient tables).  `blob`: int32
+// words on the device - n records of PIL_BATCH_REC words {page address low, high; page width; x0; y0; ksx; ksy; and the word
+// offsets into the blob of xbounds, xcoefs, ybounds, ycoefs}, then the tables themselves.  Crop z writes out[z][3][oh][ow].
+constexpr int PIL_BATCH_REC = 12;
+__global__ void k_pil_resize_batch(const int* __restrict__ blob, int oh, int ow, float* __restrict__ out) {
+  const int* rec = blob + (size_t)blockIdx.z * PIL_BATCH_REC;
+  PilRes p;
+  p.src = reinterpret_cast<const unsigned char*>(((unsigned long long)(unsigned)rec[1] << 32) | (unsigned long long)(unsigned)rec[0]);
+  p.W = rec[2];
+  p.x0 = rec[3];
+  p.y0 = rec[4];
+  p.ksx = rec[5];
+  p.ksy = rec[6];
+  p.xb = blob + rec[7];
+  p.xk = blob + rec[8];
+  p.yb = blob + rec[9];
+  p.yk = blob + rec[10];
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= ow) return;
+  const int xmin = p.xb[2 * x], xn = p.xb[2 * x + 1];
+  const int ymin = p.yb[2 * y], yn = p.yb[2 * y + 1];
+  const int* kx = p.xk + (size_t)x * p.ksx;
+  const int* ky = p.yk + (size_t)y * p.ksy;
+  int acc[3] = {1 << 21, 1 << 21, 1 << 21};
+  for (int r = 0; r < yn; ++r) {
+    const unsigned char* row = p.src + ((size_t)(p.y0 + ymin + r) * p.W + p.x0 + xmin) * 3;
+    int h0 = 1 << 21, h1 = 1 << 21, h2 = 1 << 21;
+    for (int c = 0; c < xn; ++c) {
+      const int k = kx[c];
+      h0 += row[c * 3 + 2] * k;  // R
+      h1 += row[c * 3 + 1] * k;  // G
+      h2 += row[c * 3 + 0] * k;  // B
+    }
+    acc[0] += clip8(h0) * ky[r];
+    acc[1] += clip8(h1) * ky[r];
+    acc[2] += clip8(h2) * ky[r];
+  }
+  const size_t plane = (size_t)oh * ow;
+  float* dst = out + (size_t)blockIdx.z * 3 * plane;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) dst[c * plane + (size_t)y * ow + x] = (float)clip8(acc[c]) / 255.0f;  // ToTensor
+}
+void pil_resize_batch_to_chw(hipStream_t s, const int* blob, int n, int oh, int ow, float* out) {
+  if (n <= 0) return;
+  YMK_CHECK(n <= 65535, "pil_resize_batch: at most 65535 crops per launch");
+  hipLaunchKernelGGL(k_pil_resize_batch, dim3((ow + 255) / 256, oh, n), dim3(256), 0, s, blob, oh, ow, out);
+  YMK_HIP(hipGetLastError());
+}
+
 void pil_resize_to_chw(hipStream_t s, const unsigned char* page, int W, int x0, int y0, const int* xb, const int* xk, int ksx,
                        const int* yb, const int* yk, int ksy, int oh, int ow, float* out) {
   PilRes p{page, W, x0, y0, xb, xk, yb, yk, ksx, ksy, oh, ow, out};
@@ -415,6 +464,17 @@ int ymk_pil_resize_to_chw(const unsigned char* page_dev, int page_w, int x0, int
     return 1;
   }
 }
+int ymk_pil_resize_batch_to_chw(const int* blob_dev, int n, int oh, int ow, float* x_dev, void* stream) {
+  try {
+    YMK_CHECK(blob_dev && x_dev && n >= 0 && oh > 0 && ow > 0, "bad argument");
+    ymk::pil_resize_batch_to_chw((hipStream_t)stream, blob_dev, n, oh, ow, x_dev);
+    return 0;
+  } catch (const std::exception& e) {
+    ymk::set_error(e.what());
+    return 1;
+  }
+}
+int ymk_pil_batch_record_words(void) { return ymk::PIL_BATCH_REC; }
 int ymk_crop_batch(const unsigned char* page_dev, int page_h, int page_w, const void* descs_dev, int n, int max_warp_w,
                    int max_warp_h, unsigned char* scratch_dev, float* out_dev, int batch_w, int out_h, void* stream) {
   try {

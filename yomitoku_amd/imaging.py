@@ -61,6 +61,35 @@ def detector_tensor(page_dev: torch.Tensor, shortest: int, limit: int, out: torc
 # ---------------------------------------------------------------------------------------------
 # Pillow bilinear resample coefficients (Resample.c: precompute_coeffs + normalize_coeffs_8bpc)
 def pil_bilinear_coeffs(in_size: int, out_size: int):
+    """(bounds int32 [out][2], coefs int32 [out][ksize], ksize).  All outputs at once in float64: the same operations in the
+    same order as the per-output loop of Resample.c (`_pil_bilinear_coeffs_scalar`, which tests hold this form to) - the
+    weights of an output are summed tap by tap, never pairwise.  A table crop has its own (width, height), so a wave of
+    table-heavy pages asks for ~340 new tables: as Python loops that was ~3 ms per crop and THE cost of the tables stage."""
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    ss = 1.0 / filterscale
+    center = (np.arange(out_size, dtype=np.float64) + 0.5) * scale
+    xmin = np.maximum((center - support + 0.5).astype(np.int64), 0)          # (int) truncates; the operand is > -1
+    xmax = np.minimum((center + support + 0.5).astype(np.int64), in_size) - xmin
+    taps = np.arange(ksize, dtype=np.int64)[None, :]
+    inside = taps < xmax[:, None]
+    a = np.abs((taps + xmin[:, None]).astype(np.float64) - center[:, None] + 0.5) * ss
+    w = np.where(inside & (a < 1.0), 1.0 - a, 0.0)
+    ww = np.zeros(out_size, dtype=np.float64)
+    for x in range(ksize):  # sequential, like `ww += w` in the C loop (taps beyond xmax add an exact 0.0)
+        ww = ww + w[:, x]
+    k = np.where((ww != 0.0)[:, None], w / np.where(ww != 0.0, ww, 1.0)[:, None], w)
+    coefs = np.where(k < 0, (-0.5 + k * float(1 << 22)), (0.5 + k * float(1 << 22))).astype(np.int64).astype(np.int32)
+    coefs[~inside] = 0
+    bounds = np.stack([xmin, xmax], axis=1).astype(np.int32)
+    return bounds, coefs, ksize
+
+
+def _pil_bilinear_coeffs_scalar(in_size: int, out_size: int):
+    """One output at a time, statement for statement after precompute_coeffs / normalize_coeffs_8bpc (the array form above is
+    tested against it, tests/test_imaging_host.py)."""
     scale = in_size / out_size
     filterscale = max(scale, 1.0)
     support = 1.0 * filterscale
@@ -146,6 +175,90 @@ def rtdetr_tensor(page_dev: torch.Tensor, box: Optional[Sequence[int]], out_hw=(
             "ymk_pil_resize_to_chw",
         )
     return out, (ch, cw), (x1, y1)
+
+
+def _clamped_box(page_dev, box):
+    H, W = page_dev.shape[:2]
+    if box is None:
+        return 0, 0, W, H
+    x1, y1, x2, y2 = (int(v) for v in box)
+    return max(x1, 0), max(y1, 0), min(x2, W), min(y2, H)  # numpy slicing semantics of img[y1:y2, x1:x2]
+
+
+_BLOB_STAGING = __import__("threading").local()  # per thread: two pinned int32 buffers used in turn, each with its copy's event
+
+
+def _stage_blob(words: np.ndarray, device) -> torch.Tensor:
+    """int32 words -> device through a pinned buffer of the calling thread, asynchronously on the current stream.  A buffer
+    is written again only after the copy that last read it has completed (its event)."""
+    st = getattr(_BLOB_STAGING, "slots", None)
+    if st is None:
+        st = _BLOB_STAGING.slots = [{"buf": None, "event": None}, {"buf": None, "event": None}]
+        _BLOB_STAGING.turn = 0
+    slot = st[_BLOB_STAGING.turn]
+    _BLOB_STAGING.turn ^= 1
+    if slot["event"] is not None:
+        slot["event"].synchronize()
+    n = int(words.size)
+    if slot["buf"] is None or slot["buf"].numel() < n:
+        slot["buf"] = torch.empty(max(n, 1 << 18), dtype=torch.int32, pin_memory=True)
+    host = slot["buf"][:n]
+    np.copyto(host.numpy(), words)
+    dev = torch.empty(n, dtype=torch.int32, device=device)
+    dev.copy_(host, non_blocking=True)
+    slot["event"] = torch.cuda.Event()
+    slot["event"].record(torch.cuda.current_stream(device))
+    return dev
+
+
+def rtdetr_batch_tensor(pages_dev: Sequence[torch.Tensor], crops: Sequence, out_hw=(640, 640), out: torch.Tensor = None):
+    """`rtdetr_tensor` for many crops in ONE launch: crops = [(page index, box or None)] -> (fp32 n x 3 x H x W on the device,
+    [{"size": (crop height, crop width), "offset": (x1, y1)}]).  The coefficient tables of all crops travel in one
+    host-to-device copy (a pinned buffer of the calling thread, on the current stream); every crop's values are those of
+    the one-crop form (tests/test_imaging_gpu.py)."""
+    oh, ow = (int(v) for v in out_hw)
+    n = len(crops)
+    dev = pages_dev[0].device if len(pages_dev) else torch.device("cpu")
+    if out is None:
+        out = torch.empty((n, 3, oh, ow), dtype=torch.float32, device=dev)
+    if n == 0:
+        return out, []
+    lib = _lib.load()
+    rec_words = lib.ymk_pil_batch_record_words()
+    tables, index, metas = [], {}, []
+    off = n * rec_words
+    head = np.zeros((n, rec_words), dtype=np.int64)
+
+    def table(in_size, out_size):
+        nonlocal off
+        hit = index.get((in_size, out_size))
+        if hit is None:
+            b, c, k = pil_bilinear_coeffs(in_size, out_size)
+            hit = index[(in_size, out_size)] = (off, off + b.size, k)
+            tables.append(b.reshape(-1))
+            tables.append(c.reshape(-1))
+            off += b.size + c.size
+        return hit
+
+    for i, (p, box) in enumerate(crops):
+        page = pages_dev[p]
+        x1, y1, x2, y2 = _clamped_box(page, box)
+        cw, ch = x2 - x1, y2 - y1
+        if cw <= 0 or ch <= 0:
+            raise ValueError(f"empty crop {box}")
+        xb, xk, ksx = table(cw, ow)
+        yb, yk, ksy = table(ch, oh)
+        ptr = int(page.data_ptr())
+        head[i, :11] = (ptr & 0xFFFFFFFF, ptr >> 32, int(page.shape[1]), x1, y1, ksx, ksy, xb, xk, yb, yk)
+        metas.append({"size": (ch, cw), "offset": (x1, y1)})
+    words = np.concatenate([head.astype(np.uint32).view(np.int32).reshape(-1)] + tables)
+    blob = _stage_blob(words, dev)
+    if tuple(out.shape) != (n, 3, oh, ow) or not out.is_contiguous():
+        raise ValueError(f"rtdetr_batch_tensor: out must be a contiguous {n} x 3 x {oh} x {ow} tensor")
+    with torch.cuda.device(dev):
+        _lib.check(lib.ymk_pil_resize_batch_to_chw(blob.data_ptr(), n, oh, ow, out.data_ptr(), _lib.current_stream_ptr()),
+                   "ymk_pil_resize_batch_to_chw")
+    return out, metas
 
 
 # ---------------------------------------------------------------------------------------------

@@ -198,9 +198,7 @@ class LayoutParser(BaseModule):
         per = -(-len(pages) // max(1, -(-len(pages) // self.MAX_PAGES_PER_FORWARD))) if pages else 1  # forwards of equal size
         for start in range(0, len(pages), per):
             chunk = pages[start : start + per]
-            x = torch.empty((len(chunk), 3, oh, ow), dtype=torch.float32, device=chunk[0].device)
-            for k, page in enumerate(chunk):
-                imaging.rtdetr_tensor(page, None, (oh, ow), out=x[k])
+            x, _ = imaging.rtdetr_batch_tensor(chunk, [(k, None) for k in range(len(chunk))], (oh, ow))  # the wave's pages in one launch
             preds = self.model(x)
             logits = preds["pred_logits"].cpu().numpy()
             boxes = preds["pred_boxes"].cpu().numpy()

@@ -75,7 +75,11 @@ def filter_contained_cells_within_spancell(cells, span_boxes):
 
 class TableStructureRecognizer(BaseModule):
     model_catalog = TableStructureRecognizerModelCatalog()
-    MAX_TABLES_PER_FORWARD = 16  # bounds the activation workspace (80x80x512 fp32 maps per table)
+    # bounds the activation workspace (0.6 GB of fp32 maps per table crop: 38 GB of 288 for 64).  64, not 16, since round 6: a page
+    # full of tables brings ten crops, a wave of such pages 170 - three forwards instead of eleven, and the 20 x 20 level of the
+    # net (400 rows per crop) fills the chip: one crop costs 0.71 ms at 64 per forward against 0.88 at 16
+    # (profiles/r06_rtdetr_forward_alone_*.txt; the table-heavy serve leg 36 -> 44 pages/s with this alone)
+    MAX_TABLES_PER_FORWARD = 64
 
     def __init__(self, model_name="rtdetrv2", path_cfg=None, device="cuda", visualize=False, from_pretrained=True,
                  infer_onnx=False):
@@ -98,13 +102,7 @@ class TableStructureRecognizer(BaseModule):
     def preprocess(self, img, boxes):
         """All table crops of the page as one N x 3 x 640 x 640 device tensor + per-crop metadata."""
         page = img if isinstance(img, torch.Tensor) else imaging.page_to_device(img, self.device)
-        oh, ow = self._cfg.data.img_size
-        batch = torch.empty((len(boxes), 3, oh, ow), dtype=torch.float32, device=page.device)
-        metas = []
-        for i, box in enumerate(boxes):
-            _, size, offset = imaging.rtdetr_tensor(page, box, (oh, ow), out=batch[i])
-            metas.append({"size": size, "offset": offset})
-        return batch, metas
+        return imaging.rtdetr_batch_tensor([page], [(0, box) for box in boxes], tuple(self._cfg.data.img_size))  # one launch for the page's crops
 
     def postprocess(self, preds, data):
         h, w = data["size"]
@@ -146,11 +144,7 @@ class TableStructureRecognizer(BaseModule):
         per = -(-len(flat) // n_fwd) if flat else 1
         for start in range(0, len(flat), per):
             chunk = flat[start : start + per]
-            batch = torch.empty((len(chunk), 3, oh, ow), dtype=torch.float32, device=pages[chunk[0][0]].device)
-            metas = []
-            for k, (p, box) in enumerate(chunk):
-                _, size, offset = imaging.rtdetr_tensor(pages[p], box, (oh, ow), out=batch[k])
-                metas.append({"size": size, "offset": offset})
+            batch, metas = imaging.rtdetr_batch_tensor(pages, chunk, (oh, ow))  # every crop of the forward in one launch
             preds = self.model(batch)
             logits = preds["pred_logits"].cpu().numpy()
             bxs = preds["pred_boxes"].cpu().numpy()
