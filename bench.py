@@ -289,54 +289,37 @@ class Page:
         self.truth_map = render_truth_map(self.quads, (h, w), imaging.resize_shortest_edge_dims(h, w, 1280, 1600))
 
 
+class _TruthView:
+    """`an.truth = pages` / `an.stats = {...}` of the tools and legs of this file, forwarded to the analyzer's handover."""
+
+    def __init__(self, key):
+        self.key = key
+
+    def __get__(self, obj, owner=None):
+        return None if obj is None else getattr(obj.handover, self.key)
+
+    def __set__(self, obj, value):
+        setattr(obj.handover, self.key, value)
+
+
 def build_analyzer(device, sds, model_set="lite"):
-    """The analyzer of this rank: DocumentAnalyzer whose DISCRETE stage hand-overs use the pages' ground truth (module
-    doc).  `an.truth` is the list of Page objects the served pages come from (page id i -> truth[i % len(truth)])."""
+    """The analyzer of this rank: the product's DocumentAnalyzer - its own stage bodies, nothing overridden - whose DISCRETE
+    stage hand-overs carry the pages' ground truth through the product's documented hook (DocumentAnalyzer.handover,
+    yomitoku_amd/testing.py: TruthHandover).  `an.truth` is the list of Page objects the served pages come from (page id i ->
+    truth[i % len(truth)])."""
     import logging
 
     from yomitoku_amd import document_analyzer as da
-    from yomitoku_amd.schemas import Element, LayoutAnalyzerSchema, TextDetectorSchema
+    from yomitoku_amd.testing import TruthHandover
 
     logging.getLogger("yomitoku_amd.base").setLevel(logging.WARNING)
 
-    class TruthDrivenAnalyzer(da.DocumentAnalyzer):
-        truth = None
-        stats = None
-
-        def _truth(self, wave):
-            return [self.truth[i % len(self.truth)] for i in wave.ids]
-
-        # _stage_detect is the product's: pre-processing, DBNet forwards, maps back to the host - full cost
-        def _stage_boxes(self, wave):
-            truth = self._truth(wave)
-            assert all(m.shape == t.truth_map.shape for m, t in zip(wave.maps, truth))
-            boxes = self.text_detector.extract_boxes([t.truth_map for t in truth], wave.sizes)  # C++ extraction on rendered maps
-            wave.dets = [TextDetectorSchema(points=t.quads, scores=[1.0] * len(t.quads)) for t in truth]
-            if self.stats is not None:
-                self.stats["det_boxes"].extend(len(b.points) for b in boxes)
-
-        # _stage_crops / _stage_recognize / _stage_decode are the product's, on the true text-line quads;
-        # _stage_layout (layout forward over the wave) is the product's too
-        def _stage_tables(self, wave):
-            truth = self._truth(wave)
-            noise = self.layout.layout_parser.pages_from_raw(wave.lay_raw)  # full layout post-processing, result not propagated
-            wave.lay_raw = None
-            wave.tab_raw = self.layout.table_structure_recognizer.forward_tables(wave.pages, [t.tables for t in truth])
-            if self.stats is not None:
-                self.stats["layout_boxes"].extend(len(n.paragraphs) + len(n.tables) + len(n.figures) for n in noise)
-
-        def _stage_cells(self, wave):
-            truth = self._truth(wave)
-            tables = self.layout.table_structure_recognizer.tables_from_raw(wave.tab_raw, len(wave.pages))
-            wave.tab_raw = None
-            wave.lays = []
-            for t, tb in zip(truth, tables):
-                paragraphs = [Element(id=None, box=b, score=1.0, role=None, contents=None) for b in t.paragraphs]
-                wave.lays.append(LayoutAnalyzerSchema(paragraphs=paragraphs, tables=tb, figures=[]))
-            if self.stats is not None:
-                self.stats["cells"].extend(sum(len(x.cells) for x in tb) for tb in tables)
+    class TruthDrivenAnalyzer(da.DocumentAnalyzer):  # no method of the product is overridden: two attribute views, nothing else
+        truth = _TruthView("truth")
+        stats = _TruthView("stats")
 
     an = TruthDrivenAnalyzer(configs=MODEL_SETS[model_set], device=str(device))
+    an.handover = TruthHandover()
     an.text_detector.model.load_state_dict(sds["det"])
     an.text_recognizer.model.load_state_dict(sds["rec"])
     an.layout.layout_parser.model.load_state_dict(sds["lay"])
@@ -669,34 +652,13 @@ def stage_control_metrics(args, device, sds, pages):
     cell grids, then aggregation.  Two warm-up waves, two timed passes over the pages as one job."""
     from yomitoku_amd import DocumentAnalyzer
 
-    class NetOutputDrivenAnalyzer(DocumentAnalyzer):
-        truth = None
+    from yomitoku_amd.testing import NetOutputHandover
 
-        def _truth(self, wave):
-            return [self.truth[i % len(self.truth)] for i in wave.ids]
-
-        def _stage_detect(self, wave):
-            super()._stage_detect(wave)  # pre-processing, DBNet forwards, maps back to the host: full cost
-            truth = self._truth(wave)
-            assert all(m.shape == t.truth_map.shape for m, t in zip(wave.maps, truth))
-            wave.maps = [t.truth_map for t in truth]
-
-        def _stage_layout(self, wave):
-            super()._stage_layout(wave)  # the layout forward over the wave: full cost
-            lp = self.layout.layout_parser
-            cat = {c: i for i, c in lp.label_mapper.items()}
-            raw = []
-            for (logits, boxes, (h, w)), t in zip(wave.lay_raw, self._truth(wave)):
-                lg = np.full_like(logits, -12.0)
-                bx = np.zeros_like(boxes)
-                units = [(b, cat["paragraphs"]) for b in t.paragraphs] + [(b, cat["tables"]) for b in t.tables]
-                for q, ((x0, y0, x1, y1), c) in enumerate(units[: lg.shape[1]]):
-                    lg[0, q, c] = 4.0
-                    bx[0, q] = ((x0 + x1) / 2 / w, (y0 + y1) / 2 / h, (x1 - x0) / w, (y1 - y0) / h)
-                raw.append((lg, bx, (h, w)))
-            wave.lay_raw = raw
+    class NetOutputDrivenAnalyzer(DocumentAnalyzer):  # the product's stage bodies; `truth` is a view of the handover's
+        truth = _TruthView("truth")
 
     an = NetOutputDrivenAnalyzer(configs=MODEL_SETS[args.model_set], device=str(device))
+    an.handover = NetOutputHandover(categories={c: i for i, c in an.layout.layout_parser.label_mapper.items()})
     try:
         for net, key in zip(analyzer_nets(an), ("det", "rec", "lay", "tab")):
             net.load_state_dict(sds[key])

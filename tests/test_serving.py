@@ -250,3 +250,42 @@ def test_two_jobs_at_once_restore_the_switch_interval_once_the_last_one_leaves()
     ta.join(10), tb.join(10)
     assert inside["after_a_left"] == pytest.approx(2e-4, rel=0.02) and inside["b_still_in"] == pytest.approx(2e-4, rel=0.02)  # (the interpreter stores microseconds)
     assert sys.getswitchinterval() == before
+
+
+def test_handover_objects_replace_only_what_they_say():
+    """yomitoku_amd.testing: the identity hook returns what it is given; TruthHandover puts the pages' truth into the discrete
+    hand-overs and keeps the PRODUCT'S table structures; NetOutputHandover writes one query per true unit into the layout
+    net's raw output and touches nothing else."""
+    from types import SimpleNamespace as NS
+
+    import numpy as np
+
+    from yomitoku_amd import schemas as sch
+    from yomitoku_amd.testing import Handover, NetOutputHandover, TruthHandover
+
+    truth = [NS(quads=[[[1, 1], [9, 1], [9, 5], [1, 5]]], tables=[[10, 10, 50, 40]], paragraphs=[[0, 0, 60, 8], [0, 50, 60, 58]],
+                truth_map=np.full((4, 6), 0.5, np.float32)),
+             NS(quads=[], tables=[], paragraphs=[[5, 5, 20, 20]], truth_map=np.zeros((4, 6), np.float32))]
+    table = sch.TableStructureRecognizerSchema(box=[10, 10, 50, 40], n_row=1, n_col=1, rows=[], cols=[], spans=[], cells=[], order=0)
+    lay = sch.LayoutAnalyzerSchema(paragraphs=[sch.Element(id=None, box=[1, 2, 3, 4], score=0.6, role=None, contents=None)], tables=[table], figures=[])
+    parsed = [sch.LayoutParserSchema(paragraphs=lay.paragraphs, tables=[], figures=[]), sch.LayoutParserSchema(paragraphs=[], tables=[], figures=[])]
+    wave = NS(ids=[2, 5], lay_parsed=parsed)  # page ids 2 and 5 -> truth[0] and truth[1]
+    maps = [np.ones((4, 6), np.float32), np.ones((4, 6), np.float32)]
+    dets = [sch.TextDetectorSchema(points=[], scores=[]), sch.TextDetectorSchema(points=[], scores=[])]
+    ident = Handover()
+    assert ident.maps(wave, maps) is maps and ident.boxes(wave, dets) is dets and ident.layouts(wave, [lay]) == [lay]
+    stats = {}
+    th = TruthHandover(truth, stats)
+    assert [m.tolist() for m in th.maps(wave, maps)] == [truth[0].truth_map.tolist(), truth[1].truth_map.tolist()]
+    got = th.boxes(wave, dets)
+    assert got[0].points == truth[0].quads and got[0].scores == [1.0] and got[1].points == []
+    assert th.table_boxes(wave, [[[0, 0, 1, 1]], []]) == [[[10, 10, 50, 40]], []]
+    out = th.layouts(wave, [lay, sch.LayoutAnalyzerSchema(paragraphs=[], tables=[], figures=[])])
+    assert [p.box for p in out[0].paragraphs] == truth[0].paragraphs and out[0].tables == [table] and out[1].tables == []
+    assert stats == {"det_boxes": [0, 0], "layout_boxes": [1, 0], "cells": [0, 0]}
+    nh = NetOutputHandover(truth, categories={"tables": 0, "paragraphs": 2})
+    raw = [(np.zeros((1, 300, 6), np.float32), np.zeros((1, 300, 4), np.float32), (100, 200)) for _ in range(2)]
+    lg, bx, hw = nh.layout_raw(wave, raw)[0]
+    assert hw == (100, 200) and (lg[0, :3] > 0).sum() == 3 and lg[0, 0, 2] == 4.0 and lg[0, 2, 0] == 4.0 and (lg[0, 3:] == -12.0).all()
+    assert np.allclose(bx[0, 2], (30 / 200, 25 / 100, 40 / 200, 30 / 100))
+    assert nh.boxes(wave, dets) is dets and nh.table_boxes(wave, [[], []]) == [[], []]

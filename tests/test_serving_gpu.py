@@ -168,3 +168,35 @@ def test_a_bare_abi_caller_may_let_the_library_grow_the_workspace(dev):
     assert _lib.stat("arena_grows_in_forward") == grows + 1
     assert torch.equal(net(x)["binary"].cpu(), want)
     net.close()
+
+
+def test_the_handover_hook_sees_the_stages_outputs_and_identity_changes_nothing(dev, imgs):
+    """DocumentAnalyzer.handover (yomitoku_amd/testing.py): with the pass-through object every page's result equals the
+    result without a hook, and the hook was shown every hand-over of every wave - the product's own stage bodies ran."""
+    from yomitoku_amd.testing import Handover
+
+    class Recorder(Handover):
+        def __init__(self):
+            super().__init__()
+            self.seen = {k: 0 for k in ("maps", "boxes", "layout_raw", "table_boxes", "layouts")}
+
+        def __getattribute__(self, name):
+            if name in ("maps", "boxes", "layout_raw", "table_boxes", "layouts"):
+                seen = object.__getattribute__(self, "seen")
+
+                def counted(wave, value, _inner=getattr(Handover, name)):
+                    seen[name] += len(wave.ids)
+                    return _inner(self, wave, value)
+
+                return counted
+            return object.__getattribute__(self, name)
+
+    an = _analyzer()
+    plain = [r.model_dump() for r in an.serve(imgs, wave=3, in_flight=2)]
+    rec = an.handover = Recorder()
+    hooked = [r.model_dump() for r in an.serve(imgs, wave=3, in_flight=2)]
+    for a, b in zip(plain, hooked):
+        _assert_same_schema(a, b, score_rtol=0.0)
+    assert rec.seen == {k: len(imgs) for k in rec.seen}
+    an.handover = None
+    an.close()

@@ -342,6 +342,13 @@ class DocumentAnalyzer:
         # HIP stream priority per chain (0 = default, -1 = high).  Measured on the analyzer bench: raising either chain
         # LOWERS the throughput (66.9 -> 62.3 layout high, 64.2 ocr high), so the default is no priority
         self.chain_priority = _chain_priorities()
+        # `handover`: an object with any of maps / boxes / layout_raw / table_boxes / layouts (yomitoku_amd.testing.Handover) that
+        # sees - and may replace - what one stage of the multi-page paths hands to the next, AFTER the stage has produced it at
+        # full cost.  None (always, outside measurements): the stages hand over what they computed.  It exists so that a
+        # throughput measurement with seeded weights (whose detections are noise) can feed realistic unit counts downstream
+        # without a subclass that re-states the stage bodies (bench.py; tests/test_serving_gpu.py holds the hook to
+        # "identity in, identical results out")
+        self.handover = None
 
     # ---- aggregation (:487-601)
     def aggregate(self, ocr_res, layout_res, img=None):
@@ -446,13 +453,17 @@ class DocumentAnalyzer:
     # batch-1 RT-DETR / PARSeq launches are grid-starved and every page pays its own greedy-decode loop).  The stages of
     # a wave (yomitoku_amd.serving.Wave) are separate methods: `analyze_pages` runs them as two concurrent chains,
     # `serve` as a pipeline with one thread and HIP stream per stage.
+    def _handed(self, what, wave, value):
+        fn = getattr(self.handover, what, None) if self.handover is not None else None
+        return value if fn is None else fn(wave, value)
+
     def _stage_detect(self, wave):
         """DBNet forwards over same-size pages of the wave; the maps come back into the wave slot's pinned buffers."""
-        wave.maps = self.text_detector.forward_pages(wave.pages, ring=wave.ring)
+        wave.maps = self._handed("maps", wave, self.text_detector.forward_pages(wave.pages, ring=wave.ring))
 
     def _stage_boxes(self, wave):
         """DB box extraction (C++, GIL released), the pages of the wave concurrently."""
-        wave.dets = self.text_detector.extract_boxes(wave.maps, wave.sizes)
+        wave.dets = self._handed("boxes", wave, self.text_detector.extract_boxes(wave.maps, wave.sizes))
 
     def _stage_split(self, wave):
         wave.dets = [_split_text_across_cells(d, l) for d, l in zip(wave.dets, wave.lays)]
@@ -477,20 +488,21 @@ class DocumentAnalyzer:
 
     def _stage_layout(self, wave):
         """One RT-DETRv2 layout forward over the pages (device half)."""
-        wave.lay_raw = self.layout.layout_parser.forward_pages(wave.pages)
+        wave.lay_raw = self._handed("layout_raw", wave, self.layout.layout_parser.forward_pages(wave.pages))
 
     def _stage_tables(self, wave):
         """Layout boxes on the host, then one table-structure forward over all table crops of the wave."""
         wave.lay_parsed = self.layout.layout_parser.pages_from_raw(wave.lay_raw)
         wave.lay_raw = None
-        boxes = [[t.box for t in l.tables] for l in wave.lay_parsed]
+        boxes = self._handed("table_boxes", wave, [[t.box for t in l.tables] for l in wave.lay_parsed])
         wave.tab_raw = self.layout.table_structure_recognizer.forward_tables(wave.pages, boxes)
 
     def _stage_cells(self, wave):
         """Row / column / span filters and the cell grids on the host."""
         tables = self.layout.table_structure_recognizer.tables_from_raw(wave.tab_raw, len(wave.pages))
         wave.tab_raw = None
-        wave.lays = [LayoutAnalyzerSchema(paragraphs=l.paragraphs, tables=t, figures=l.figures) for l, t in zip(wave.lay_parsed, tables)]
+        lays = [LayoutAnalyzerSchema(paragraphs=l.paragraphs, tables=t, figures=l.figures) for l, t in zip(wave.lay_parsed, tables)]
+        wave.lays = self._handed("layouts", wave, lays)
 
     def _stage_finish(self, wave, k):
         """Aggregation of page k of the wave -> DocumentAnalyzerSchema."""
