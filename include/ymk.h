@@ -168,6 +168,11 @@ int ymk_prof_begin(void);
  *   "dec_rows" (0)       samples per block of the fused greedy step: 0 = by row count, 1 / 2 / 4 forced (bit-identical results)
  *   "parseq_no_rowmax" (0)  1: the fused greedy loop writes every step's logits and arg-maxes them from memory (round-2 form);
  *                        0: the vocabulary head's epilogue reduces each 64-column tile to (max, column) and no AR logits exist
+ * GELU: every kernel of the library (the exact-fp32 mode "conv_split" = 0 included, and the greedy decoder step) evaluates
+ *   0.5 v (1 + erf(v / sqrt 2)) through one branch-free function (csrc/ymk_common.h gelu_f32: a rational erfc form on v_rcp_f32 /
+ *   v_exp_f32) since round 5: absolute error < 5e-7 over the whole line (tests/test_ops_gpu.py), the size of the rounding of
+ *   v x a libm-grade erff; the RELATIVE error of the negative tail (|GELU(v)| < 1e-6 beyond v = -5) is not bounded.  Results of
+ *   "conv_split" = 0 are therefore not bit-comparable with rounds 1-4, whose kernels called erff.
  *   "conv_split" (-1)    process-wide operand precision of every model whose own "conv_split" parameter is unset, and of
  *                        ymk_op_conv2d: 0 = exact fp32 MFMA, 16 = two fp16 planes, 2 / 3 = bf16 planes (ymk_model_set_param above);
  *                        -1 = unset: models run their default (16), ymk_op_conv2d exact fp32.  Also set for a whole process by

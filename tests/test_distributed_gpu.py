@@ -54,7 +54,7 @@ class Stub:
 
 
 server = yd.ShardedServer(Stub, {"dbnet": sd}, pin_cores=False)
-out = server.run(["a", "b", "c"], wave=2)
+out = server.run(["a", "b", "c"], wave=2, gather="objects")
 dist.barrier()
 torch.cuda.synchronize()
 dist.destroy_process_group()
