@@ -882,7 +882,8 @@ def main():
         else:
             prof_step, units = step, args.pages
         roof = conv_roofline(lib, prof_step, units, "page", kern)
-        pmc = os.path.join(ROOT, "profiles", f"r05_{args.workload}_pmc_conv_traffic.json")
+        pmc = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_{args.workload}_pmc_conv_traffic.json") for r in (6, 5)) if os.path.exists(p)),
+                   os.path.join(ROOT, "profiles", f"r06_{args.workload}_pmc_conv_traffic.json"))  # the newest round's measurement
         if roof is not None and os.path.exists(pmc):
             # HBM bytes per conv launch from the PMC passes of this same serial pass (rocprofv3 cannot run inside bench.py:
             # profiles/README.md has the commands); compare with algorithmic_bytes_per_launch.  The file carries the hash of the

@@ -223,6 +223,14 @@ def test_whole_page_schema_vs_oracle_chain(dev, page_hw):
     assert_same_detections(preds["pred_logits"].cpu().numpy(), preds["pred_boxes"].cpu().numpy(),
                            ref_preds["pred_logits"].numpy(), ref_preds["pred_boxes"].numpy())
     lay = lp.postprocess(preds, img.shape[:2])
+    # ---- from here on the ORACLE's own host logic (oracle/hostlogic.py, pinned against the reference's functions): box filters,
+    # cell grids, aggregation and reading order owe nothing to yomitoku_amd - until round 5 `want` was built by an.aggregate
+    from oracle import hostlogic as hl
+
+    h, w = img.shape[:2]
+    groups = hl.layout_elements(op.rtdetr_post(preds["pred_logits"].cpu(), preds["pred_boxes"].cpu(), (w, h), 0.5, 6)[0])
+    for key, mine in (("tables", lay.tables), ("paragraphs", lay.paragraphs), ("figures", lay.figures)):  # product's filters == oracle's
+        _assert_same_schema(groups[key], [e.model_dump() for e in mine], score_rtol=1e-6)
     tables = []
     if lay.tables:
         batch, metas = ts.preprocess(img, [t.box for t in lay.tables])
@@ -232,15 +240,17 @@ def test_whole_page_schema_vs_oracle_chain(dev, page_hw):
                 (rp, _), = op.tables(sds["tab"], img, [t.box])
                 assert_same_detections(tp["pred_logits"][i : i + 1].cpu().numpy(), tp["pred_boxes"][i : i + 1].cpu().numpy(),
                                        rp["pred_logits"].numpy(), rp["pred_boxes"].numpy())
-            table = ts.postprocess({"pred_logits": tp["pred_logits"][i : i + 1], "pred_boxes": tp["pred_boxes"][i : i + 1]}, meta)
-            if table.n_row > 0 and table.n_col > 0:
+            th, tw = meta["size"]
+            det = op.rtdetr_post(tp["pred_logits"][i : i + 1].cpu(), tp["pred_boxes"][i : i + 1].cpu(), (tw, th), 0.4, 3)[0]
+            table = hl.table_structure(det, (th, tw), meta["offset"])
+            _assert_same_schema(table, ts.postprocess({"pred_logits": tp["pred_logits"][i : i + 1], "pred_boxes": tp["pred_boxes"][i : i + 1]}, meta).model_dump(),
+                                score_rtol=1e-6)
+            if table["n_row"] > 0 and table["n_col"] > 0:
                 tables.append(table)
-    # ---- the schema the reference's aggregation builds from the ORACLE-side stage results
-    det_s = TextDetectorSchema(points=quads, scores=det_scores)
-    rec_s = TextRecognizerSchema(contents=contents, scores=rec_scores, points=quads, directions=directions)
-    an.img = img
-    want = DocumentAnalyzerSchema(**an.aggregate(OCRSchema(words=ocr_aggregate(det_s, rec_s)),
-                                               LayoutAnalyzerSchema(paragraphs=lay.paragraphs, tables=tables, figures=lay.figures)))
+    # ---- the page record the reference's aggregation builds from the ORACLE-side stage results
+    words = [{"points": [[int(x), int(y)] for x, y in q], "content": c, "direction": d, "rec_score": float(rs), "det_score": float(ds)}
+             for q, ds, c, rs, d in zip(quads, det_scores, contents, rec_scores, directions)]
+    want = DocumentAnalyzerSchema(**hl.aggregate(words, {"paragraphs": groups["paragraphs"], "tables": tables, "figures": groups["figures"]}))
     try:
         _assert_same_schema(want.model_dump(), got.model_dump(), score_rtol=1e-3)
     except AssertionError:  # say which elements differ before failing (the first differing leaf alone rarely tells)
