@@ -456,3 +456,59 @@ def aggregate(words, layout, ignore_meta=False, reading_order_opt="auto", ignore
             "tables": sorted(layout["tables"], key=lambda t: t["order"]),
             "words": words,
             "figures": sorted(figures, key=lambda f: f["order"])}
+
+
+# ------------------------------------------------------------------------------------------ document_analyzer.py:239-423
+def _edge(p, q):
+    return math.sqrt((p[0] - q[0]) ** 2 + (p[1] - q[1]) ** 2)
+
+
+def quad_is_vertical(quad, aspect=2):
+    return _edge(quad[1], quad[2]) > _edge(quad[0], quad[1]) * aspect
+
+
+def quad_is_noise(quad, thresh=15):
+    return _edge(quad[0], quad[1]) < thresh or _edge(quad[1], quad[2]) < thresh
+
+
+def split_text_across_cells(points, scores, tables):
+    """The detector's quads cut at the cell borders of the tables they lie in (split_text_across_cells=True): a word at least half
+    inside a table goes to the row (horizontal text) or column (vertical text: taller than twice its width) it overlaps most -
+    the first one on ties - and is cut to every cell of that line it touches; pieces shorter than 15 px on either side are noise.
+    Table words come first, table by table (horizontal pieces, then vertical ones), the untouched words after them in their
+    order.  -> (points, scores)"""
+    taken = [False] * len(points)
+    out_p, out_s = [], []
+    for table in tables:
+        lying, standing = [], []
+        for i, (quad, score) in enumerate(zip(points, scores)):
+            if contains(table["box"], quad_box(quad), threshold=0.5):
+                (standing if quad_is_vertical(quad) else lying).append((quad, score))
+                taken[i] = True
+        for words, lines, vertical in ((lying, table["rows"], False), (standing, table["cols"], True)):
+            for quad, score in words:
+                box = quad_box(quad)
+                shares = [overlap_of_b(line["box"], box)[0] for line in lines]
+                line_no = shares.index(max(shares)) + 1
+                for cell in table["cells"]:
+                    first, span = (cell["col"], cell["col_span"]) if vertical else (cell["row"], cell["row_span"])
+                    if not (first <= line_no < first + span):
+                        continue
+                    inter = overlap_of_b(cell["box"], box)[1]
+                    if inter is None:
+                        continue
+                    x1, y1, x2, y2 = inter
+                    if vertical:
+                        piece = [[quad[0][0], max(quad[0][1], y1)], [quad[1][0], max(quad[1][1], y1)],
+                                 [quad[2][0], min(quad[2][1], y2)], [quad[3][0], min(quad[3][1], y2)]]
+                    else:
+                        piece = [[max(quad[0][0], x1), quad[0][1]], [min(quad[1][0], x2), quad[1][1]],
+                                 [min(quad[2][0], x2), quad[2][1]], [max(quad[3][0], x1), quad[3][1]]]
+                    if not quad_is_noise(piece):
+                        out_p.append(piece)
+                        out_s.append(score)
+    for i, used in enumerate(taken):
+        if not used:
+            out_p.append(points[i])
+            out_s.append(scores[i])
+    return out_p, out_s

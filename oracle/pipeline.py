@@ -168,9 +168,10 @@ def tables(sd, img_bgr, table_boxes, thresh=0.4, nc=3, forward=None):
 
 
 # ------------------------------------------------------------------ DocumentAnalyzer.__call__ (document_analyzer.py:622-678), free-running
-def analyze(sds, ocfg, img_bgr, charset, rec_opts=None, det_opts=None, agg_opts=None, forwards=None, keep=None):
+def analyze(sds, ocfg, img_bgr, charset, rec_opts=None, det_opts=None, agg_opts=None, forwards=None, keep=None, split_text_across_cells=False):
     """The whole page on the CPU with nothing taken from the product: detector -> boxes -> recogniser ‖ layout -> table crops
     -> table structure -> aggregation and reading order (oracle.hostlogic, pinned against the reference's own functions).
+    `split_text_across_cells`: the option of the same name (the quads are cut at cell borders before they are recognised).
     sds: state dicts {"det", "rec", "lay", "tab"}; returns the page record as plain dicts, shaped like
     DocumentAnalyzerSchema.model_dump().  `forwards`: optional replacements for the four network forwards (timing legs);
     `keep`: a dict that receives the continuous stage outputs (probability map, layout / table logits and boxes, the
@@ -181,9 +182,6 @@ def analyze(sds, ocfg, img_bgr, charset, rec_opts=None, det_opts=None, agg_opts=
                     source_downscale=True) if rec_opts is None else rec_opts
     forwards = forwards or {}
     prob, quads, det_scores = detect(sds["det"], img_bgr, **(det_opts or {}))
-    contents, rec_scores, directions = recognize(sds["rec"], ocfg, img_bgr, quads, charset, forward=forwards.get("rec"), **rec_opts)
-    words = [{"points": [[int(x), int(y)] for x, y in q], "content": c, "direction": d, "rec_score": float(rs), "det_score": float(ds)}
-             for q, ds, c, rs, d in zip(quads, det_scores, contents, rec_scores, directions)]
     lay_preds, lay_det = layout(sds["lay"], img_bgr, forward=forwards.get("lay"))
     groups = hl.layout_elements(lay_det)
     table_boxes = [t["box"] for t in groups["tables"]]
@@ -195,6 +193,11 @@ def analyze(sds, ocfg, img_bgr, charset, rec_opts=None, det_opts=None, agg_opts=
         tab_raw.append((preds, det, table))
         if table["n_row"] > 0 and table["n_col"] > 0:
             structures.append(table)
+    if split_text_across_cells:  # document_analyzer.py:636-655: the detector's quads are cut at the cell borders BEFORE recognition
+        quads, det_scores = hl.split_text_across_cells([[[int(x), int(y)] for x, y in q] for q in quads], list(det_scores), structures)
+    contents, rec_scores, directions = recognize(sds["rec"], ocfg, img_bgr, quads, charset, forward=forwards.get("rec"), **rec_opts)
+    words = [{"points": [[int(x), int(y)] for x, y in q], "content": c, "direction": d, "rec_score": float(rs), "det_score": float(ds)}
+             for q, ds, c, rs, d in zip(quads, det_scores, contents, rec_scores, directions)]
     if keep is not None:
         keep.update(prob=prob, quads=quads, det_scores=det_scores, rec_scores=rec_scores, lay_preds=lay_preds, lay_det=lay_det,
                     layout_groups={k: [dict(e) for e in v] for k, v in groups.items()}, tab_raw=tab_raw)

@@ -107,3 +107,17 @@ def test_aggregate_matches_reference():
         seen["ruby"] += int(opts["ignore_ruby"])
         seen["vertical"] += sum(p["direction"] == "vertical" for p in out["paragraphs"])
     assert all(v > 0 for v in seen.values()), seen  # the cases do reach every branch
+
+
+def test_split_text_across_cells_matches_reference():
+    from oracle import hostlogic as hl
+
+    cut = untouched = 0
+    for case in _gold("aggregate.json"):
+        words = case["input"]["ocr"]["words"]
+        points, scores = [w["points"] for w in words], [w["det_score"] for w in words]
+        got_p, got_s = hl.split_text_across_cells(copy.deepcopy(points), list(scores), case["input"]["layout"]["tables"])
+        assert {"points": got_p, "scores": got_s} == case["split"]
+        cut += sum(1 for q in got_p if q not in points)
+        untouched += sum(1 for q in got_p if q in points)
+    assert cut > 20 and untouched > 100, (cut, untouched)  # the cases do cut words at cell borders

@@ -71,14 +71,14 @@ def _class_shifts(logits, targets, thresh, min_gap=0.02):
     return torch.tensor(out)
 
 
-def state_dicts(log=None, layout_targets=None):
+def state_dicts(log=None, layout_targets=None, lay_seed=None):
     from oracle import hostlogic as hl
     from oracle import pipeline as op
     from yomitoku_amd.utils.synth import dbnet_state_dict, parseq_state_dict, synthetic_page_with_truth
     from yomitoku_amd.utils.synth_rtdetr import rtdetr_state_dict
 
     sds = {"det": dbnet_state_dict(SEEDS["det"][0], **SEEDS["det"][1]), "rec": parseq_state_dict(SEEDS["rec"][0], **SEEDS["rec"][1]),
-           "lay": rtdetr_state_dict(SEEDS["lay"][0], **SEEDS["lay"][1]), "tab": rtdetr_state_dict(SEEDS["tab"][0], **SEEDS["tab"][1])}
+           "lay": rtdetr_state_dict(lay_seed or SEEDS["lay"][0], **SEEDS["lay"][1]), "tab": rtdetr_state_dict(SEEDS["tab"][0], **SEEDS["tab"][1])}
     page = synthetic_page_with_truth(3, 1000, 1400)[0]
     preds, _ = op.layout(sds["lay"], page)
     sds["lay"]["decoder.dec_score_head.5.bias"] = sds["lay"]["decoder.dec_score_head.5.bias"] + _class_shifts(preds["pred_logits"], layout_targets or LAYOUT_TARGETS, 0.5)
@@ -263,7 +263,8 @@ def classify(roots, borderline):
 
 
 # ---------------------------------------------------------------------------------------------- the run
-def evaluate(n_pages, borderline=2e-3, modes=("split", "exact"), first_seed=3, log=print, only=None, layout_targets=None):
+def evaluate(n_pages, borderline=2e-3, modes=("split", "exact"), first_seed=3, log=print, only=None, layout_targets=None, lay_seed=None,
+             split_text_across_cells=False):
     """`only`: indices into the page list to keep (the GPU test runs two pages that carry tables)."""
     import torch
 
@@ -271,12 +272,12 @@ def evaluate(n_pages, borderline=2e-3, modes=("split", "exact"), first_seed=3, l
     from oracle.parseq import PRESETS, make_cfg
     from yomitoku_amd import DocumentAnalyzer
 
-    sds = state_dicts(log, layout_targets)
+    sds = state_dicts(log, layout_targets, lay_seed)
     imgs = pages(n_pages, first_seed)
     if only is not None:
         imgs = [imgs[i] for i in only]
         n_pages = len(imgs)
-    an = DocumentAnalyzer(configs=LITE, device="cuda:0")
+    an = DocumentAnalyzer(configs=LITE, device="cuda:0", split_text_across_cells=split_text_across_cells)
     nets = {"det": an.text_detector.model, "rec": an.text_recognizer.model, "lay": an.layout.layout_parser.model,
             "tab": an.layout.table_structure_recognizer.model}
     for k, net in nets.items():
@@ -301,7 +302,7 @@ def evaluate(n_pages, borderline=2e-3, modes=("split", "exact"), first_seed=3, l
     for i, img in enumerate(imgs):
         keep = {}
         t0 = time.perf_counter()
-        want = op.analyze(sds, ocfg, img, an.text_recognizer.charset, keep=keep)
+        want = op.analyze(sds, ocfg, img, an.text_recognizer.charset, keep=keep, split_text_across_cells=split_text_across_cells)
         t_oracle += time.perf_counter() - t0
         row = {"page": i, "shape": list(img.shape[:2]), "oracle_counts": {"words": len(want["words"]), "paragraphs": len(want["paragraphs"]), "tables": len(want["tables"]),
                                                                              "cells": sum(len(t["cells"]) for t in want["tables"]), "figures": len(want["figures"])}}
@@ -343,14 +344,17 @@ def main() -> int:
     ap.add_argument("--modes", default="split,exact")
     ap.add_argument("--layout-targets", default=None, help="six counts (tables, figures, paragraphs, headings, header, footer) for the calibration; "
                     "more tables per page: 6,1,6,2,1,1")
+    ap.add_argument("--lay-seed", type=int, default=None, help="another seeded layout head (1248: its figure and footer classes are not ties)")
+    ap.add_argument("--split-text-across-cells", action="store_true", help="the analyzer option of that name, on both sides")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     import torch
 
     torch.set_num_threads(max(1, min(int(os.environ.get("YMK_ORACLE_THREADS", 32)), torch.get_num_threads())))
     result = evaluate(args.pages, args.borderline, tuple(args.modes.split(",")), args.first_seed, log=lambda s: print(s, file=sys.stderr, flush=True),
-                      layout_targets=tuple(int(v) for v in args.layout_targets.split(",")) if args.layout_targets else None)
-    result["layout_targets"] = args.layout_targets
+                      layout_targets=tuple(int(v) for v in args.layout_targets.split(",")) if args.layout_targets else None,
+                      lay_seed=args.lay_seed, split_text_across_cells=args.split_text_across_cells)
+    result.update(layout_targets=args.layout_targets, lay_seed=args.lay_seed, split_text_across_cells=bool(args.split_text_across_cells))
     text = json.dumps(result, ensure_ascii=False, indent=1)
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
