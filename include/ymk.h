@@ -200,6 +200,10 @@ int ymk_prof_begin(void);
  *                        input and compares (ymk_amax_check_counters) - the self-check of the record plumbing; 2: also names every
  *                        launch whose record lies BELOW the measured maximum on stderr (serialises the stream) */
 int ymk_debug_option(const char* key, int value);
+/* Tracing: with YMK_ROCTX=1 in the environment every forward (ymk_dbnet_forward, ymk_parseq_forward[_groups], ymk_rtdetr_forward),
+ * ymk_parseq_token_stats, ymk_model_finalize and ymk_model_reserve runs inside a roctx range of its own name
+ * (`rocprofv3 --marker-trace --kernel-trace`: which call a kernel belongs to).  The marker library is opened at run time
+ * (librocprofiler-sdk-roctx.so, else libroctx64.so); without it, or without the variable, no range is pushed. */
 /* Launch counters since the process started, for tests that must know a route was really taken: "astat_launches" (the
  * A-stationary short-K kernel), "ln_fused_launches" (those of them that carried a LayerNorm in their operand load),
  * "planes_written_launches" / "planes_read_launches" (convolutions whose output / input lives in HBM as fp16 planes),

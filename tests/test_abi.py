@@ -48,3 +48,16 @@ def test_debug_options_exist_and_their_documented_defaults_agree():
     assert int(re.search(r"g_conv_fast\{(\d+)\}", src).group(1)) == _lib.CONV_FAST_DEFAULT
     header = open(os.path.join(ROOT, "include", "ymk.h")).read()
     assert int(re.search(r'"conv_fast" \((\d+)\)', header).group(1)) == _lib.CONV_FAST_DEFAULT
+
+
+def test_library_loads_with_roctx_ranges_asked_for():
+    """YMK_ROCTX=1: the marker library is looked up at run time (dlopen) at the first range - asking for ranges must never be
+    the reason the library does not load or a host-only entry point fails, with or without a marker library on the box."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "from yomitoku_amd import _lib; l = _lib.load(); assert l.ymk_version() >= 100; print(l.ymk_device_count() >= -1)"
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, YMK_ROCTX="1"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("True"), r.stderr[-500:]

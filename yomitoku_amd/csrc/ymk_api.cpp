@@ -32,6 +32,43 @@ struct ymk_model {
   int device = 0;
 };
 
+// roctx ranges around the forwards and the pre-processing entry points ("rocprofv3 / roctx ranges around each
+// C-ABI call"), so that a `rocprofv3 --marker-trace` timeline shows which call a kernel belongs to.  Off unless YMK_ROCTX=1: the
+// library links only libamdhip64, the marker library (librocprofiler-sdk-roctx.so, else libroctx64.so) is opened at the first
+// range and a box without it simply gets no ranges.
+#include <dlfcn.h>
+namespace {
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char* on = std::getenv("YMK_ROCTX");
+    if (on == nullptr || on[0] == '\0' || on[0] == '0') return;
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+      if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (push && pop) return;
+        push = nullptr;
+        pop = nullptr;
+      }
+    }
+  }
+};
+struct RoctxRange {
+  explicit RoctxRange(const char* name) {
+    static Roctx r;
+    pop_ = r.pop;
+    if (r.push) (void)r.push(name);
+    else pop_ = nullptr;
+  }
+  ~RoctxRange() {
+    if (pop_) (void)pop_();
+  }
+  int (*pop_)() = nullptr;
+};
+}  // namespace
+
 #define YMK_API_BEGIN try {
 #define YMK_API_END                                 \
   return 0;                                         \
@@ -106,6 +143,7 @@ int ymk_model_set_tensor(ymk_model* m, const char* name, const float* host_data,
 
 int ymk_model_finalize(ymk_model* m) {
   YMK_API_BEGIN
+  RoctxRange roctx_range("ymk_model_finalize");
   YMK_CHECK(m, "null model");
   YMK_HIP(hipSetDevice(m->device));
   m->impl->finalize();
@@ -121,6 +159,7 @@ int ymk_model_finalize(ymk_model* m) {
 
 int ymk_model_reserve(ymk_model* m, int n, int h, int w, void* stream) {
   YMK_API_BEGIN
+  RoctxRange roctx_range("ymk_model_reserve");
   YMK_CHECK(m && m->impl, "null argument");
   YMK_HIP(hipSetDevice(m->device));
   m->impl->reserve(n, h, w, (hipStream_t)stream);
@@ -132,6 +171,7 @@ int64_t ymk_model_workspace_bytes(const ymk_model* m) { return m ? (int64_t)m->i
 
 int ymk_dbnet_forward(ymk_model* m, const float* x_dev, int n, int h, int w, float* prob_dev, void* stream) {
   YMK_API_BEGIN
+  RoctxRange roctx_range("ymk_dbnet_forward");
   YMK_CHECK(m && x_dev && prob_dev, "null argument");
   YMK_HIP(hipSetDevice(m->device));
   ymk::dbnet_forward(m->impl, x_dev, n, h, w, prob_dev, (hipStream_t)stream);
@@ -148,6 +188,7 @@ int ymk_parseq_dims(ymk_model* m, int* num_steps, int* num_classes) {
 int ymk_parseq_forward(ymk_model* m, const float* x_dev, int b, int w, float* logits_dev, int* out_len, int* ar_steps,
                        void* stream) {
   YMK_API_BEGIN
+  RoctxRange roctx_range("ymk_parseq_forward");
   YMK_CHECK(m && x_dev && logits_dev && out_len && ar_steps, "null argument");
   YMK_HIP(hipSetDevice(m->device));
   ymk::parseq_forward(m->impl, x_dev, b, w, logits_dev, out_len, ar_steps, (hipStream_t)stream);
@@ -157,6 +198,7 @@ int ymk_parseq_forward(ymk_model* m, const float* x_dev, int b, int w, float* lo
 int ymk_parseq_forward_groups(ymk_model* m, const float* const* x_dev, const int* b, const int* w, int n_groups,
                               float* logits_dev, int* out_len, int* ar_steps, void* stream) {
   YMK_API_BEGIN
+  RoctxRange roctx_range("ymk_parseq_forward_groups");
   YMK_CHECK(m && x_dev && b && w && logits_dev && out_len && ar_steps, "null argument");
   YMK_HIP(hipSetDevice(m->device));
   ymk::parseq_forward_groups(m->impl, x_dev, b, w, n_groups, logits_dev, out_len, ar_steps, (hipStream_t)stream);
@@ -166,6 +208,7 @@ int ymk_parseq_forward_groups(ymk_model* m, const float* const* x_dev, const int
 int ymk_parseq_token_stats(const float* logits_dev, int rows, int num_classes, int* ids_dev, float* probs_dev,
                            void* stream) {
   YMK_API_BEGIN
+  RoctxRange roctx_range("ymk_parseq_token_stats");
   YMK_CHECK(logits_dev && ids_dev && probs_dev, "null argument");
   ymk::row_maxprob((hipStream_t)stream, logits_dev, rows, num_classes, ids_dev, probs_dev);
   YMK_API_END
@@ -174,6 +217,7 @@ int ymk_parseq_token_stats(const float* logits_dev, int rows, int num_classes, i
 int ymk_rtdetr_forward(ymk_model* m, const float* x_dev, int b, int h, int w, float* logits_dev, float* boxes_dev,
                        void* stream) {
   YMK_API_BEGIN
+  RoctxRange roctx_range("ymk_rtdetr_forward");
   YMK_CHECK(m && x_dev && logits_dev && boxes_dev, "null argument");
   YMK_HIP(hipSetDevice(m->device));
   ymk::rtdetr_forward(m->impl, x_dev, b, h, w, logits_dev, boxes_dev, (hipStream_t)stream);
