@@ -162,7 +162,12 @@ def rtdetr_decoder(sd, feats, prefix="decoder.", num_queries=300, num_layers=6):
     om = _ln(sd, _lin(sd, valid.to(memory.dtype) * memory, prefix + "enc_output.proj"), prefix + "enc_output.norm")
     logits = _lin(sd, om, prefix + "enc_score_head")
     coords = _mlp(sd, om, prefix + "enc_bbox_head", 3) + anchors
-    _, ind = torch.topk(logits.max(-1).values, num_queries, dim=-1)
+    token_scores = logits.max(-1).values
+    _, ind = torch.topk(token_scores, num_queries, dim=-1)
+    # how far the last selected token's score lies above the first one left out: an implementation within 1e-3 of these logits
+    # may legitimately select another token when this is smaller (tools/e2e_oracle_eval.py reads it)
+    cut = torch.topk(token_scores, min(num_queries + 1, token_scores.shape[-1]), dim=-1).values
+    topk_margin = (cut[:, num_queries - 1] - cut[:, -1]) if cut.shape[-1] > num_queries else torch.full((cut.shape[0],), float("inf"))
     target = om.gather(1, ind.unsqueeze(-1).repeat(1, 1, om.shape[-1]))
     ref_unact = coords.gather(1, ind.unsqueeze(-1).repeat(1, 1, 4))
     ref = torch.sigmoid(ref_unact)
@@ -176,7 +181,7 @@ def rtdetr_decoder(sd, feats, prefix="decoder.", num_queries=300, num_layers=6):
         out = _ln(sd, out + _lin(sd, F.relu(_lin(sd, out, p + "linear1")), p + "linear2"), p + "norm3")
         box = torch.sigmoid(_mlp(sd, out, f"{prefix}dec_bbox_head.{i}", 3) + _inverse_sigmoid(ref))
         if i == num_layers - 1:
-            return {"pred_logits": _lin(sd, out, f"{prefix}dec_score_head.{i}"), "pred_boxes": box, "topk_index": ind}
+            return {"pred_logits": _lin(sd, out, f"{prefix}dec_score_head.{i}"), "pred_boxes": box, "topk_index": ind, "topk_margin": topk_margin}
         ref = box
 
 

@@ -51,7 +51,8 @@ def test_rtdetr_batch_of_crops_is_pillow_exact(dev):
     pages = [imaging.page_to_device(img, dev) for img in imgs]
     crops = [(0, None), (1, None), (0, (100, 200, 900, 700)), (1, (3, 5, 77, 41)), (1, (200, 100, 1400, 1000)), (0, (100, 200, 900, 700)),
              (0, (-5, -7, 300, 2000)), (1, (640, 0, 1280, 640))]
-    for turn in range(3):  # three calls: both pinned staging buffers of the thread, and one of them a second time
+    for turn in range(10):  # ten calls: every pinned staging buffer of the thread's ring, and two of them a second time
+        turn %= 5
         out, metas = imaging.rtdetr_batch_tensor(pages, crops[turn:])
         assert out.shape == (len(crops) - turn, 3, 640, 640)
         for k, (p, box) in enumerate(crops[turn:]):
@@ -65,6 +66,22 @@ def test_rtdetr_batch_of_crops_is_pillow_exact(dev):
     assert empty.shape == (0, 3, 640, 640) and metas == []
     with pytest.raises(ValueError):
         imaging.rtdetr_batch_tensor(pages, [(0, (50, 50, 50, 90))])
+
+
+def test_to_host_hands_out_copies_equal_to_cpu(dev):
+    """imaging.to_host: several device tensors of different dtypes through one pinned buffer - equal to `.cpu()`, owned by the
+    caller (a second call does not change the first call's arrays), odd sizes, a non-contiguous view."""
+    from yomitoku_amd import imaging
+
+    g = torch.Generator().manual_seed(4)
+    a = torch.randint(0, 7000, (37, 101), generator=g, dtype=torch.int32).to(dev)
+    b = torch.rand((37, 101), generator=g).to(dev)
+    c = torch.rand((5, 3, 7), generator=g).to(dev).permute(2, 0, 1)
+    ha, hb, hc = imaging.to_host(a, b, c)
+    again = imaging.to_host(b * 2.0)[0]
+    assert np.array_equal(ha, a.cpu().numpy()) and np.array_equal(hb, b.cpu().numpy()) and np.array_equal(hc, c.cpu().numpy())
+    assert np.array_equal(again, (b * 2.0).cpu().numpy()) and ha.flags.owndata and hb.dtype == np.float32 and hc.shape == (7, 5, 3)
+    assert imaging.to_host() == ()
 
 
 def _quads(rng, h, w, n):

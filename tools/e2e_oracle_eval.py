@@ -15,8 +15,9 @@ of the difference is looked for stage by stage on the CONTINUOUS outputs of both
 
   detector   pixels on different sides of the binarisation threshold: the largest |p_oracle - thresh| among them, and
              box scores on different sides of box_thresh
-  layout /   detections on different sides of the score threshold: |score - thresh|; integer box coordinates that
-  tables     truncate differently: distance of the float coordinate from the integer step
+  layout /   the query set itself (RT-DETRv2's top-k of 8400 encoder-token scores: queries of one side without a partner on the
+  tables     other; margin = the oracle's gap at the cut), then detections on different sides of the score threshold:
+             |score - thresh|; integer box coordinates that truncate differently: distance of the float from the integer step
   recogniser words with equal quads and different strings: the two recognition scores
 
 A difference whose margin is below --borderline (default 2e-3: twice the 1e-3 the north star allows the continuous
@@ -200,6 +201,23 @@ def _rtdetr_roots(op, got, want, size_wh, thresh, nc, nq):
     return roots
 
 
+def _query_selection_root(got, want, tol_logit=1e-3, tol_box=1e-4):
+    """RT-DETRv2 picks its 300 queries as the top-k of 8400 encoder-token scores: two scores a hair apart at the cut and an
+    implementation within tolerance selects ANOTHER token - one query (logits and box) is then a different object altogether and
+    everything downstream of the net may move.  Detected on the outputs: queries of one side without a partner on the other
+    (logits within tol_logit and box within tol_box); margin: the oracle's own gap at the cut (oracle/rtdetr.py)."""
+    import numpy as np
+
+    a = np.concatenate([got["pred_logits"][0] / tol_logit, got["pred_boxes"][0] / tol_box], axis=1)
+    b = np.concatenate([want["pred_logits"][0] / tol_logit, want["pred_boxes"][0] / tol_box], axis=1)
+    d = np.abs(a[:, None, :] - b[None, :, :]).max(-1)
+    lonely = int((d.min(1) > 1.0).sum()), int((d.min(0) > 1.0).sum())
+    if max(lonely) == 0:
+        return None
+    margin = float(np.asarray(want["topk_margin"]).reshape(-1)[0]) if "topk_margin" in want else None
+    return {"what": "encoder top-k cut: queries without a partner on the other side", "queries": list(lonely), "margin": margin, "unit": "encoder logit"}
+
+
 def roots_of_difference(an, op, sds, ocfg, img, keep, product_page, oracle_page, thresholds):
     """Stage by stage, on the continuous outputs both sides produce for this page."""
     import numpy as np
@@ -234,17 +252,26 @@ def roots_of_difference(an, op, sds, ocfg, img, keep, product_page, oracle_page,
     preds = {k: v.cpu().numpy() for k, v in lp.model(lp.preprocess(img)).items()}
     want = {k: v.numpy() for k, v in keep["lay_preds"].items()}
     h, w = img.shape[:2]
-    for r in _rtdetr_roots(op, preds, want, (w, h), 0.5, 6, 300):
-        roots.append(dict(r, stage="layout", max_abs_logit_diff=float(np.abs(np.sort(preds["pred_logits"].ravel()) - np.sort(want["pred_logits"].ravel())).max())))
+    cut = _query_selection_root(preds, want)
+    if cut is not None:  # another query set: what the layout net hands on, and every table crop cut from it, is downstream of this
+        roots.append(dict(cut, stage="layout"))
+    else:
+        for r in _rtdetr_roots(op, preds, want, (w, h), 0.5, 6, 300):
+            roots.append(dict(r, stage="layout", max_abs_logit_diff=float(np.abs(preds["pred_logits"] - want["pred_logits"]).max())))
     # ---- tables: the oracle's own table boxes, through both nets
     boxes = [t_["box"] for t_ in keep["layout_groups"]["tables"]]
-    if boxes:
+    if boxes and cut is None:
         batch, metas = ts.preprocess(img, boxes)
         tp = ts.model(batch)
         for i, (meta, (rp, _, _)) in enumerate(zip(metas, keep["tab_raw"])):
             one = {"pred_logits": tp["pred_logits"][i : i + 1].cpu().numpy(), "pred_boxes": tp["pred_boxes"][i : i + 1].cpu().numpy()}
             th, tw = meta["size"]
-            for r in _rtdetr_roots(op, one, {k: v.numpy() for k, v in rp.items()}, (tw, th), 0.4, 3, 300):
+            ref = {k: v.numpy() for k, v in rp.items()}
+            tcut = _query_selection_root(one, ref)
+            if tcut is not None:
+                roots.append(dict(tcut, stage="tables", table=i))
+                continue
+            for r in _rtdetr_roots(op, one, ref, (tw, th), 0.4, 3, 300):
                 roots.append(dict(r, stage="tables", table=i))
     # ---- recogniser: words with the same quad and another string
     if gq == oq:

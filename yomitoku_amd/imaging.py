@@ -185,23 +185,25 @@ def _clamped_box(page_dev, box):
     return max(x1, 0), max(y1, 0), min(x2, W), min(y2, H)  # numpy slicing semantics of img[y1:y2, x1:x2]
 
 
-_BLOB_STAGING = __import__("threading").local()  # per thread: two pinned int32 buffers used in turn, each with its copy's event
+_BLOB_STAGING = __import__("threading").local()  # per thread: a ring of pinned int32 buffers, each with the event of its last copy
+_BLOB_SLOTS = 8
 
 
 def _stage_blob(words: np.ndarray, device) -> torch.Tensor:
-    """int32 words -> device through a pinned buffer of the calling thread, asynchronously on the current stream.  A buffer
-    is written again only after the copy that last read it has completed (its event)."""
+    """int32 words -> device through a pinned buffer of the calling thread, asynchronously on the current stream: no pageable
+    staging inside the runtime (a blocking copy in small chunks) and no wait for the stream.  A buffer is written again only
+    after the copy that last read it has completed (its event; eight buffers in turn, so that is long past)."""
     st = getattr(_BLOB_STAGING, "slots", None)
     if st is None:
-        st = _BLOB_STAGING.slots = [{"buf": None, "event": None}, {"buf": None, "event": None}]
+        st = _BLOB_STAGING.slots = [{"buf": None, "event": None} for _ in range(_BLOB_SLOTS)]
         _BLOB_STAGING.turn = 0
     slot = st[_BLOB_STAGING.turn]
-    _BLOB_STAGING.turn ^= 1
+    _BLOB_STAGING.turn = (_BLOB_STAGING.turn + 1) % _BLOB_SLOTS
     if slot["event"] is not None:
         slot["event"].synchronize()
     n = int(words.size)
     if slot["buf"] is None or slot["buf"].numel() < n:
-        slot["buf"] = torch.empty(max(n, 1 << 18), dtype=torch.int32, pin_memory=True)
+        slot["buf"] = torch.empty(max(n, 1 << 16), dtype=torch.int32, pin_memory=True)
     host = slot["buf"][:n]
     np.copyto(host.numpy(), words)
     dev = torch.empty(n, dtype=torch.int32, device=device)
@@ -209,6 +211,33 @@ def _stage_blob(words: np.ndarray, device) -> torch.Tensor:
     slot["event"] = torch.cuda.Event()
     slot["event"].record(torch.cuda.current_stream(device))
     return dev
+
+
+_HOST_STAGING = __import__("threading").local()  # per thread: one pinned byte buffer for results on their way to numpy
+
+
+def to_host(*tensors: torch.Tensor):
+    """Device tensors -> numpy arrays (copies the caller owns) through ONE pinned buffer of the calling thread: every tensor is
+    queued as one asynchronous DMA, the current stream is waited for once, and the arrays are copied out of the buffer.  The
+    `.cpu()` of a device tensor lands in pageable memory, which the runtime fills through a staging buffer in small chunks
+    - a blit launch and a wait per chunk."""
+    if not tensors:
+        return ()
+    dev = tensors[0].device
+    srcs = [t.detach().contiguous() for t in tensors]
+    sizes = [(t.numel() * t.element_size() + 63) // 64 * 64 for t in srcs]
+    total = sum(sizes)
+    buf = getattr(_HOST_STAGING, "buf", None)
+    if buf is None or buf.numel() < total:
+        buf = _HOST_STAGING.buf = torch.empty(max(total, 1 << 20), dtype=torch.uint8, pin_memory=True)
+    views, off = [], 0
+    for t, nbytes in zip(srcs, sizes):
+        view = buf[off : off + t.numel() * t.element_size()].view(t.dtype).view(t.shape)
+        view.copy_(t, non_blocking=True)
+        views.append(view)
+        off += nbytes
+    torch.cuda.current_stream(dev).synchronize()
+    return tuple(v.numpy().copy() for v in views)
 
 
 def rtdetr_batch_tensor(pages_dev: Sequence[torch.Tensor], crops: Sequence, out_hw=(640, 640), out: torch.Tensor = None):
@@ -525,7 +554,7 @@ def build_crop_batch(page_dev, plans: Sequence[CropPlan], out_h: int = 32, batch
     off = int(ends[-1])
     max_w, max_h = max(1, int(arr["ww"].max())), max(1, int(arr["wh"].max()))
     dev = page0.device
-    descs = torch.from_numpy(arr.view(np.uint8)).to(dev)
+    descs = _stage_blob(arr.view(np.int32).reshape(-1), dev)  # one asynchronous upload from pinned memory (was: a blocking pageable copy per mini-batch)
     scratch = torch.empty(max(off, 16), dtype=torch.uint8, device=dev)
     out = torch.empty((n, 3, out_h, batch_w), dtype=torch.float32, device=dev)
     nl = len(levels)

@@ -200,8 +200,7 @@ class LayoutParser(BaseModule):
             chunk = pages[start : start + per]
             x, _ = imaging.rtdetr_batch_tensor(chunk, [(k, None) for k in range(len(chunk))], (oh, ow))  # the wave's pages in one launch
             preds = self.model(x)
-            logits = preds["pred_logits"].cpu().numpy()
-            boxes = preds["pred_boxes"].cpu().numpy()
+            logits, boxes = imaging.to_host(preds["pred_logits"], preds["pred_boxes"])
             for k, page in enumerate(chunk):
                 raw.append((logits[k : k + 1], boxes[k : k + 1], (int(page.shape[0]), int(page.shape[1]))))
         return raw

@@ -146,8 +146,7 @@ class TableStructureRecognizer(BaseModule):
             chunk = flat[start : start + per]
             batch, metas = imaging.rtdetr_batch_tensor(pages, chunk, (oh, ow))  # every crop of the forward in one launch
             preds = self.model(batch)
-            logits = preds["pred_logits"].cpu().numpy()
-            bxs = preds["pred_boxes"].cpu().numpy()
+            logits, bxs = imaging.to_host(preds["pred_logits"], preds["pred_boxes"])
             for k, ((p, _), data) in enumerate(zip(chunk, metas)):
                 raw.append((p, logits[k : k + 1], bxs[k : k + 1], data))
         return raw
