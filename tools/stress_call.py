@@ -160,12 +160,15 @@ def child(args) -> int:
     log = []
     modules = {"det": an.text_detector, "rec": an.text_recognizer, "lay": an.layout.layout_parser,
                "tab": an.layout.table_structure_recognizer}
-    for name, module in modules.items():
-        module.model = _Recorder(module.model, name, log)
+    if not args.serve:  # (serve builds a second recogniser handle from the first one's type: the stand-in cannot stand there)
+        for name, module in modules.items():
+            module.model = _Recorder(module.model, name, log)
     if args.prewarm:  # the layout lane's first forwards before the concurrent call (bisection)
         an.layout(img)
         torch.cuda.synchronize()
         log.clear()
+    if args.serve:
+        return serve_child(args, an, log, _lib)
     t0 = time.perf_counter()
     first, _, _ = an(img)
     torch.cuda.synchronize()
@@ -199,6 +202,52 @@ def child(args) -> int:
     return _emit(args, report)
 
 
+def serve_child(args, an, log, _lib) -> int:
+    """--serve N: the multi-page entry point cold - N pages (the page with tables among two other sizes) through
+    DocumentAnalyzer.serve in waves of 4 with 2 in flight: nine stage threads and six streams start their first forwards next to
+    each other - then the same job warm.  Report: schema per page of the cold job (the parent compares processes) and cold
+    against warm per page.  (No per-stage output CRCs here; and a serve process reserves ~100 GB of workspaces: --parallel 2.)"""
+    import torch
+
+    from yomitoku_amd.utils.synth import synthetic_page_with_truth
+
+    shapes = [(1000, 1400), (1400, 1000), (1200, 1600)]
+    imgs = [synthetic_page_with_truth(3 + i, *shapes[i % 3])[0] for i in range(args.serve)]
+    t0 = time.perf_counter()
+    cold = an.serve(imgs, wave=4, in_flight=2)
+    torch.cuda.synchronize()
+    t_first = time.perf_counter() - t0
+    cold_log, log[:] = list(log), []
+    stats = {k: _lib.stat(k) for k in ("allocs_in_forward", "arena_grows_in_forward", "lazy_panel_builds", "syncs_in_forward")}
+    t0 = time.perf_counter()
+    warm = an.serve(imgs, wave=4, in_flight=2)
+    torch.cuda.synchronize()
+    t_second = time.perf_counter() - t0
+    warm_log = list(log)
+    stats_after = {k: _lib.stat(k) for k in stats}
+    bad = [i for i, (a, b) in enumerate(zip(cold, warm)) if isinstance(a, BaseException) or isinstance(b, BaseException)]
+    if bad:
+        raise RuntimeError(f"serve failed on pages {bad}: {cold[bad[0]]!r} / {warm[bad[0]]!r}")
+    d1, d2 = [r.model_dump() for r in cold], [r.model_dump() for r in warm]
+
+    def by_stage(entries):  # forwards of a stage run in wave order on one thread: the sequence per stage is comparable
+        out = {s: [] for s in STAGES}
+        for name, value in entries:
+            out[name].append(_crc(value))
+        return out
+
+    report = {
+        "schema": d1, "schema_crc": zlib.crc32(json.dumps(d1, sort_keys=True, ensure_ascii=False).encode()),
+        "second_call_differs": _first_difference(d1, d2),
+        "counts": {"words": sum(len(r.words) for r in cold), "paragraphs": sum(len(r.paragraphs) for r in cold), "tables": sum(len(r.tables) for r in cold),
+                   "cells": sum(len(t.cells) for r in cold for t in r.tables), "figures": sum(len(r.figures) for r in cold)},
+        "crc_first": by_stage(cold_log), "crc_second": by_stage(warm_log),
+        "stats_first_call": stats, "stats_second_call": {k: stats_after[k] - stats[k] for k in stats},
+        "seconds": {"first": round(t_first, 4), "second": round(t_second, 4)},
+    }
+    return _emit(args, report)
+
+
 def parent(args) -> int:
     env = dict(os.environ)
     for item in args.env:
@@ -209,6 +258,8 @@ def parent(args) -> int:
         cmd.append("--no-concurrent")
     if args.prewarm:
         cmd.append("--prewarm")
+    if args.serve:
+        cmd += ["--serve", str(args.serve)]
     if args.fake:
         cmd.append("--fake")
     import tempfile
@@ -260,7 +311,7 @@ def parent(args) -> int:
     ok = [(k, r) for k, r in results if "error" not in r]
     if progress:
         progress.close()
-    summary = {"label": args.label, "runs": args.runs, "process_s_median": sorted(r["process_s"] for _, r in results)[len(results) // 2] if results else None, "parallel": args.parallel, "page": args.page, "env": args.env,
+    summary = {"label": args.label, "entry_point": f"serve({args.serve} pages, wave 4, 2 in flight)" if args.serve else "__call__", "runs": args.runs, "process_s_median": sorted(r["process_s"] for _, r in results)[len(results) // 2] if results else None, "parallel": args.parallel, "page": args.page, "env": args.env,
                "no_concurrent": bool(args.no_concurrent), "prewarm": bool(args.prewarm),
                "crashed": [{"run": k, **r} for k, r in results if "error" in r], "wall_s": round(time.time() - t_start, 1)}
     if ok:
@@ -322,6 +373,7 @@ def main() -> int:
     ap.add_argument("--env", action="append", default=[], help="KEY=VALUE for the children (repeatable)")
     ap.add_argument("--no-concurrent", action="store_true", help="DocumentAnalyzer.concurrent_chains = False")
     ap.add_argument("--prewarm", action="store_true", help="run the layout chain once before the measured call")
+    ap.add_argument("--serve", type=int, default=0, help="N > 0: the children run DocumentAnalyzer.serve over N pages (cold, then warm) instead of __call__")
     ap.add_argument("--out", default=None)
     ap.add_argument("--time-budget", type=float, default=0.0, help="seconds after which no further child is started (0: none)")
     ap.add_argument("--host-threads", type=int, default=8, help="OMP / MKL threads per child unless the environment says otherwise")
