@@ -151,3 +151,39 @@ def test_pretrained_weights_resolution(tmp_path, monkeypatch):
         monkeypatch.undo()
         importlib.reload(hc)
         importlib.reload(fd)
+
+
+def test_ensure_workspace_reserves_only_what_no_earlier_reservation_covers():
+    """nets.HipNet.ensure_workspace (called by every forward with its own shape): a shape inside an earlier reservation costs
+    nothing; a larger one reserves once; DBNet's reservations cover either orientation; a handle whose big reservation failed
+    (reserve_once) grows on demand and is left alone.  No device: `reserve` is replaced by a recorder."""
+    from yomitoku_amd import nets
+
+    calls = []
+
+    class Probe(nets.HipNet):
+        kind = "rtdetr"
+
+        def reserve(self, n, h, w, device=None):
+            calls.append((n, h, w))
+            self._reserved.append((int(n), int(h), int(w)))
+
+    net = Probe()
+    net._h, net._reserved = object(), []
+    net.ensure_workspace(1, 640, 640)
+    net.ensure_workspace(1, 640, 640)
+    net.ensure_workspace(4, 640, 640)
+    net.ensure_workspace(2, 640, 640)
+    assert calls == [(1, 640, 640), (4, 640, 640)]
+    det = Probe()
+    det.kind, det._h, det._reserved = "dbnet", object(), []
+    det.ensure_workspace(8, 1600, 1280)
+    det.ensure_workspace(8, 1280, 1600)   # the other orientation of the same reservation
+    det.ensure_workspace(2, 1184, 1600)
+    det.ensure_workspace(8, 1600, 1600)   # wider than anything reserved: a new one
+    assert calls[2:] == [(8, 1600, 1280), (8, 1600, 1600)]
+    sad = Probe()
+    sad._h, sad._reserved = object(), []
+    sad._reserve_tried_for, sad._reserve_ok = sad._h, False
+    sad.ensure_workspace(64, 640, 640)
+    assert len(calls) == 4
