@@ -188,16 +188,29 @@ def _rtdetr_roots(op, got, want, size_wh, thresh, nc, nq):
         gap = float(min(abs(s[k] - s[k - 1]) if k > 0 else 1.0, abs(s[k] - s[k + 1]) if k + 1 < len(s) else 1.0))
         roots.append({"what": "rank of two detections", "at": k, "margin": gap, "unit": "score"})
         return roots
-    ib = [p["boxes"].astype(int) for p in post]
-    if not np.array_equal(ib[0], ib[1]):
-        # an integer coordinate truncates differently: how far the float is from the integer step, on the nearer side
-        where = np.argwhere(ib[0] != ib[1])
-        worst = 0.0
-        for r, c in where:
-            x, y = float(post[0]["boxes"][r, c]), float(post[1]["boxes"][r, c])
-            step = float(max(int(x), int(y)))  # the integer boundary between the two truncations
-            worst = max(worst, min(abs(x - step), abs(y - step)))
-        roots.append({"what": "integer box coordinates", "coordinates": int(len(where)), "margin": worst, "unit": "pixel"})
+    # the same classes in the same order - but two detections of ONE class whose scores are a hair apart may still have
+    # swapped places: pair every detection of one side with the nearest box of its class on the other before comparing
+    fa, fb = post[0]["boxes"], post[1]["boxes"]
+    la = post[0]["labels"]
+    partner = []
+    for i in range(len(la)):
+        same = np.flatnonzero(post[1]["labels"] == la[i])
+        partner.append(int(same[np.abs(fb[same] - fa[i]).max(1).argmin()]))
+    moved = [i for i, j in enumerate(partner) if i != j]
+    if moved:
+        s1 = post[1]["scores"]
+        gap = float(max(abs(s1[i] - s1[partner[i]]) for i in moved))
+        roots.append({"what": "rank of detections of one class", "detections": len(moved), "margin": gap, "unit": "score"})
+    worst, count = 0.0, 0
+    for i, j in enumerate(partner):
+        for c in range(4):
+            x, y = float(fa[i, c]), float(fb[j, c])
+            if int(x) != int(y):
+                count += 1
+                step = float(max(int(x), int(y)))  # the integer boundary between the two truncations
+                worst = max(worst, max(abs(x - step), abs(y - step)))  # both sides within `worst` of the step
+    if count:
+        roots.append({"what": "integer box coordinates", "coordinates": count, "margin": worst, "unit": "pixel"})
     return roots
 
 
