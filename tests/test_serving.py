@@ -289,3 +289,26 @@ def test_handover_objects_replace_only_what_they_say():
     assert hw == (100, 200) and (lg[0, :3] > 0).sum() == 3 and lg[0, 0, 2] == 4.0 and lg[0, 2, 0] == 4.0 and (lg[0, 3:] == -12.0).all()
     assert np.allclose(bx[0, 2], (30 / 200, 25 / 100, 40 / 200, 30 / 100))
     assert nh.boxes(wave, dets) is dets and nh.table_boxes(wave, [[], []]) == [[], []]
+
+
+def test_sources_are_pulled_only_when_a_wave_slot_is_free():
+    """serve() reads `sources` lazily and takes a wave slot BEFORE it pulls that wave's first source: a generator that claims
+    work from a shared counter (distributed.PageDealer) is never asked for more than `in_flight` waves beyond what has
+    finished - the end of a sharded job is not as ragged as a static deal."""
+    an = StubAnalyzer(delay=0.02)
+    pipe = PagePipeline(an, wave=2, in_flight=2)
+    pulled, ahead = [0], []
+
+    def feed(n):
+        for i in range(n):
+            pulled[0] += 1
+            ahead.append(pulled[0] - 2 * len(an.log))  # sources pulled minus sources whose wave has been aggregated
+            yield page(i)
+
+    out = pipe.serve(feed(20))
+    assert [o[0] for o in out] == list(range(20)) and pipe.last_job["waves"] == 10
+    # at most `in_flight` waves out plus the wave being collected (its slot is already held): (2 + 1) x 2 pages; the finish
+    # stage logs a wave a moment after its slot is free, hence one wave of slack
+    assert max(ahead) <= (2 + 1 + 1) * 2, max(ahead)
+    assert pipe.serve(iter([])) == [] and pipe.serve(feed(4))[-1][0] == 3  # the slots all came back (an exact multiple of the wave too)
+    pipe.close()

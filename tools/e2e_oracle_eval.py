@@ -94,10 +94,11 @@ def state_dicts(log=None, layout_targets=None, lay_seed=None):
     return sds
 
 
-def pages(n, first_seed=3):
+def pages(n, first_seed=3, shapes=None):
     from yomitoku_amd.utils.synth import synthetic_page_with_truth
 
-    return [synthetic_page_with_truth(first_seed + i, *SHAPES[i % len(SHAPES)])[0] for i in range(n)]
+    shapes = shapes or SHAPES
+    return [synthetic_page_with_truth(first_seed + i, *shapes[i % len(shapes)])[0] for i in range(n)]
 
 
 # ---------------------------------------------------------------------------------------------- leaf comparison
@@ -304,7 +305,7 @@ def classify(roots, borderline):
 
 # ---------------------------------------------------------------------------------------------- the run
 def evaluate(n_pages, borderline=2e-3, modes=("split", "exact"), first_seed=3, log=print, only=None, layout_targets=None, lay_seed=None,
-             split_text_across_cells=False):
+             split_text_across_cells=False, shapes=None):
     """`only`: indices into the page list to keep (the GPU test runs two pages that carry tables)."""
     import torch
 
@@ -313,7 +314,7 @@ def evaluate(n_pages, borderline=2e-3, modes=("split", "exact"), first_seed=3, l
     from yomitoku_amd import DocumentAnalyzer
 
     sds = state_dicts(log, layout_targets, lay_seed)
-    imgs = pages(n_pages, first_seed)
+    imgs = pages(n_pages, first_seed, shapes)
     if only is not None:
         imgs = [imgs[i] for i in only]
         n_pages = len(imgs)
@@ -386,6 +387,7 @@ def main() -> int:
                     "more tables per page: 6,1,6,2,1,1")
     ap.add_argument("--lay-seed", type=int, default=None, help="another seeded layout head (1248: its figure and footer classes are not ties)")
     ap.add_argument("--split-text-across-cells", action="store_true", help="the analyzer option of that name, on both sides")
+    ap.add_argument("--shapes", default=None, help="page sizes HxW, comma separated, dealt in turn (default: four sizes, the 1000 x 1400 family most often)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     import torch
@@ -393,8 +395,9 @@ def main() -> int:
     torch.set_num_threads(max(1, min(int(os.environ.get("YMK_ORACLE_THREADS", 32)), torch.get_num_threads())))
     result = evaluate(args.pages, args.borderline, tuple(args.modes.split(",")), args.first_seed, log=lambda s: print(s, file=sys.stderr, flush=True),
                       layout_targets=tuple(int(v) for v in args.layout_targets.split(",")) if args.layout_targets else None,
-                      lay_seed=args.lay_seed, split_text_across_cells=args.split_text_across_cells)
-    result.update(layout_targets=args.layout_targets, lay_seed=args.lay_seed, split_text_across_cells=bool(args.split_text_across_cells))
+                      lay_seed=args.lay_seed, split_text_across_cells=args.split_text_across_cells,
+                      shapes=[tuple(int(v) for v in t.split("x")) for t in args.shapes.split(",")] if args.shapes else None)
+    result.update(layout_targets=args.layout_targets, lay_seed=args.lay_seed, split_text_across_cells=bool(args.split_text_across_cells), shapes=args.shapes)
     text = json.dumps(result, ensure_ascii=False, indent=1)
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
