@@ -60,18 +60,26 @@ class PageDealer:
         self.store = None
         self._local = {}
         self.claims = 0
+        self.error = None  # a rank that could not reach the counter says so here (ShardedServer agrees on it): it never raises alone
         if world > 1:
             from datetime import timedelta
 
             host = host or os.environ.get("MASTER_ADDR", "127.0.0.1")
             port = [None]
             if rank == 0:
-                # port 0: the server picks a free one; the number travels to the other ranks through the process group
-                self.store = dist.TCPStore(host, 0, world, True, timeout=timedelta(seconds=300), wait_for_workers=False)
-                port[0] = self.store.port
+                try:  # port 0: the server picks a free one; the number travels to the other ranks through the process group
+                    self.store = dist.TCPStore(host, 0, world, True, timeout=timedelta(seconds=300), wait_for_workers=False)
+                    port[0] = ("port", self.store.port)
+                except Exception as exc:  # noqa: BLE001 - told to the ranks waiting in the broadcast below
+                    port[0] = ("error", _describe(exc))
             dist.broadcast_object_list(port, src=0)
+            if port[0][0] == "error":  # the same on every rank
+                raise RuntimeError("rank 0 could not host the page counter: " + port[0][1])
             if rank != 0:
-                self.store = dist.TCPStore(host, int(port[0]), world, False, timeout=timedelta(seconds=300))
+                try:
+                    self.store = dist.TCPStore(host, int(port[0][1]), world, False, timeout=timedelta(seconds=300))
+                except Exception as exc:  # noqa: BLE001
+                    self.error = _describe(exc)
 
     def claim(self, job: int, chunk: int) -> int:
         """First source index of the next unclaimed chunk of `job` (may lie beyond the job's end: then there is none left)."""
@@ -363,6 +371,7 @@ class ShardedServer:
             self._close_analyzer()  # a rank that DID build one gives its workspaces (tens of GB) back before it leaves
             raise
         self.dealer = PageDealer(self.rank, self.world)
+        self._agree("connecting to the page counter", self.dealer.error)
         self._jobs = 0
         self.last_run = None
 
