@@ -315,12 +315,20 @@ def parent(args) -> int:
                "no_concurrent": bool(args.no_concurrent), "prewarm": bool(args.prewarm),
                "crashed": [{"run": k, **r} for k, r in results if "error" in r], "wall_s": round(time.time() - t_start, 1)}
     if ok:
-        # the reference: the most common schema among the runs (a wrong run 0 must not make every other run "differ")
+        # the reference: the most common schema among the runs whose cold call equals their own warm call (a wrong run 0 must
+        # not make every other run "differ" - and where a fault hits MOST runs, the majority of all runs would be the wrong one)
+        def own_fault(r):
+            return bool(r["second_call_differs"]) or any(r["crc_first"][s] != r["crc_second"][s] for s in STAGES)
+
         tally = {}
         for k, r in ok:
             tally.setdefault(r["schema_crc"], []).append(k)
-        ref_crc = max(tally, key=lambda c: len(tally[c]))
-        ref = next(r for k, r in ok if r["schema_crc"] == ref_crc)
+        pool = [(k, r) for k, r in ok if not own_fault(r)] or ok
+        votes = {}
+        for k, r in pool:
+            votes[r["schema_crc"]] = votes.get(r["schema_crc"], 0) + 1
+        ref_crc = max(votes, key=lambda c: votes[c])
+        ref = next(r for k, r in pool if r["schema_crc"] == ref_crc)
         differing = []
         for k, r in ok:
             if r["schema_crc"] != ref_crc:
