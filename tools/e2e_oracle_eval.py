@@ -305,7 +305,8 @@ def classify(roots, borderline):
 
 # ---------------------------------------------------------------------------------------------- the run
 def evaluate(n_pages, borderline=2e-3, modes=("split", "exact"), first_seed=3, log=print, only=None, layout_targets=None, lay_seed=None,
-             split_text_across_cells=False, shapes=None):
+             split_text_across_cells=False, shapes=None, options=None):
+    """`options`: DocumentAnalyzer's aggregation options on BOTH sides - {"ignore_meta", "reading_order", "ignore_ruby", "ruby_threshold"}."""
     """`only`: indices into the page list to keep (the GPU test runs two pages that carry tables)."""
     import torch
 
@@ -318,7 +319,9 @@ def evaluate(n_pages, borderline=2e-3, modes=("split", "exact"), first_seed=3, l
     if only is not None:
         imgs = [imgs[i] for i in only]
         n_pages = len(imgs)
-    an = DocumentAnalyzer(configs=LITE, device="cuda:0", split_text_across_cells=split_text_across_cells)
+    options = dict(options or {})
+    an = DocumentAnalyzer(configs=LITE, device="cuda:0", split_text_across_cells=split_text_across_cells, **options)
+    agg_opts = {("reading_order_opt" if k == "reading_order" else k): v for k, v in options.items()}
     nets = {"det": an.text_detector.model, "rec": an.text_recognizer.model, "lay": an.layout.layout_parser.model,
             "tab": an.layout.table_structure_recognizer.model}
     for k, net in nets.items():
@@ -343,7 +346,7 @@ def evaluate(n_pages, borderline=2e-3, modes=("split", "exact"), first_seed=3, l
     for i, img in enumerate(imgs):
         keep = {}
         t0 = time.perf_counter()
-        want = op.analyze(sds, ocfg, img, an.text_recognizer.charset, keep=keep, split_text_across_cells=split_text_across_cells)
+        want = op.analyze(sds, ocfg, img, an.text_recognizer.charset, keep=keep, split_text_across_cells=split_text_across_cells, agg_opts=agg_opts)
         t_oracle += time.perf_counter() - t0
         row = {"page": i, "shape": list(img.shape[:2]), "oracle_counts": {"words": len(want["words"]), "paragraphs": len(want["paragraphs"]), "tables": len(want["tables"]),
                                                                              "cells": sum(len(t["cells"]) for t in want["tables"]), "figures": len(want["figures"])}}
@@ -387,6 +390,9 @@ def main() -> int:
                     "more tables per page: 6,1,6,2,1,1")
     ap.add_argument("--lay-seed", type=int, default=None, help="another seeded layout head (1248: its figure and footer classes are not ties)")
     ap.add_argument("--split-text-across-cells", action="store_true", help="the analyzer option of that name, on both sides")
+    ap.add_argument("--ignore-meta", action="store_true")
+    ap.add_argument("--ignore-ruby", action="store_true")
+    ap.add_argument("--reading-order", default=None, choices=["auto", "top2bottom", "right2left", "left2right"])
     ap.add_argument("--shapes", default=None, help="page sizes HxW, comma separated, dealt in turn (default: four sizes, the 1000 x 1400 family most often)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
@@ -396,8 +402,11 @@ def main() -> int:
     result = evaluate(args.pages, args.borderline, tuple(args.modes.split(",")), args.first_seed, log=lambda s: print(s, file=sys.stderr, flush=True),
                       layout_targets=tuple(int(v) for v in args.layout_targets.split(",")) if args.layout_targets else None,
                       lay_seed=args.lay_seed, split_text_across_cells=args.split_text_across_cells,
-                      shapes=[tuple(int(v) for v in t.split("x")) for t in args.shapes.split(",")] if args.shapes else None)
-    result.update(layout_targets=args.layout_targets, lay_seed=args.lay_seed, split_text_across_cells=bool(args.split_text_across_cells), shapes=args.shapes)
+                      shapes=[tuple(int(v) for v in t.split("x")) for t in args.shapes.split(",")] if args.shapes else None,
+                      options=dict(({"ignore_meta": True} if args.ignore_meta else {}), **({"ignore_ruby": True} if args.ignore_ruby else {}),
+                                   **({"reading_order": args.reading_order} if args.reading_order else {})))
+    result.update(layout_targets=args.layout_targets, lay_seed=args.lay_seed, split_text_across_cells=bool(args.split_text_across_cells), shapes=args.shapes,
+                  options={"ignore_meta": args.ignore_meta, "ignore_ruby": args.ignore_ruby, "reading_order": args.reading_order})
     text = json.dumps(result, ensure_ascii=False, indent=1)
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
