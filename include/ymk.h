@@ -168,6 +168,10 @@ int ymk_prof_begin(void);
  *   "dec_rows" (0)       samples per block of the fused greedy step: 0 = by row count, 1 / 2 / 4 forced (bit-identical results)
  *   "parseq_no_rowmax" (0)  1: the fused greedy loop writes every step's logits and arg-maxes them from memory (round-2 form);
  *                        0: the vocabulary head's epilogue reduces each 64-column tile to (max, column) and no AR logits exist
+ *   "rowmax_tile" (0)    the kernel of that head where 128 x 128 tiles fill the chip: 0 = the A-stationary kernel, one column block
+ *                        per block (K <= 192; else the 128 x 64 tile), 1 / 2 / 3 = 128 x 128 x 16 waves / 128 x 128 x 8 waves / 256 x 128,
+ *                        4 = the A-stationary kernel with dealt column groups, 6 = 128 x 64 always (rounds 3-5) - the same pair
+ *                        table, bit for bit, from each (tests/test_routes_gpu.py)
  * GELU: every kernel of the library (the exact-fp32 mode "conv_split" = 0 included, and the greedy decoder step) evaluates
  *   0.5 v (1 + erf(v / sqrt 2)) through one branch-free function (csrc/ymk_common.h gelu_f32: a rational erfc form on v_rcp_f32 /
  *   v_exp_f32) since round 5: absolute error < 5e-7 over the whole line (tests/test_ops_gpu.py), the size of the rounding of
@@ -207,7 +211,7 @@ int ymk_debug_option(const char* key, int value);
 /* Launch counters since the process started, for tests that must know a route was really taken: "astat_launches" (the
  * A-stationary short-K kernel), "ln_fused_launches" (those of them that carried a LayerNorm in their operand load),
  * "planes_written_launches" / "planes_read_launches" (convolutions whose output / input lives in HBM as fp16 planes),
- * "mlp_fused_launches" (ViT MLP halves run as one launch).
+ * "mlp_fused_launches" (ViT MLP halves run as one launch), "rowmax_wide_launches" (row-max heads on anything but the 128 x 64 tile).
  * And what a forward must NOT do (round 6): a ymk_*_forward whose workspace the caller sized first (ymk_model_reserve) never
  * allocates or frees device / pinned memory, never builds a weight copy and never waits for a stream - the split weight
  * copies and the max|x| words of the precision a model runs are built by ymk_model_finalize (and by ymk_model_set_param

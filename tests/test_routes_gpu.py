@@ -111,6 +111,32 @@ def test_parseq_layernorm_fusion_and_astat_routing_on_and_off(dev):
         assert (fused - other).abs().max().item() < 1e-4
 
 
+def test_row_max_head_on_every_kernel_it_can_run_on_changes_no_bit(dev):
+    """"rowmax_tile": the greedy loop's vocabulary head (1300 rows x 7119 columns x K = 192, (max, column) per 64-column sub-tile
+    in its epilogue) on the A-stationary kernel (0: the default since round 6; 4: its column blocks dealt to groups) and on
+    128 x 128 / 256 x 128 tiles (1-3) against the 128 x 64 tile of rounds 3-5 (6) - the same planes, products and K order per
+    accumulator and the same pair table, so tokens, step counts and the refined logits are the same bits."""
+    from tests.test_parseq_gpu import _net
+    from yomitoku_amd import _lib
+    from yomitoku_amd.utils.synth import parseq_state_dict, synthetic_line_batch
+
+    sd = parseq_state_dict(1235, eos_bias=5.5)
+    _, net = _net(dev, sd)
+    x = synthetic_line_batch(31, 1300, 64).to(dev)
+    outs = {}
+    for tile in (6, 0, 1, 2, 3, 4):
+        with _Option("rowmax_tile", tile, 0):
+            w0, a0 = _lib.stat("rowmax_wide_launches"), _lib.stat("astat_launches")
+            outs[tile] = (net(x).cpu(), net.last_ar_steps)
+            wide, astat = _lib.stat("rowmax_wide_launches") - w0, _lib.stat("astat_launches") - a0
+            assert (wide == 0) if tile == 6 else (wide >= outs[tile][1]), (tile, wide)
+            if tile in (0, 4):
+                assert astat >= outs[6][1] + outs[0][1], (tile, astat)  # the head's launches on top of the encoder's
+    assert outs[6][1] >= 2
+    for tile in (0, 1, 2, 3, 4):
+        assert outs[tile][1] == outs[6][1] and torch.equal(outs[tile][0], outs[6][0]), tile
+
+
 def test_whole_pages_with_every_route_on_and_off(dev):
     """Four pages through DocumentAnalyzer.serve with the three routes on (the default) and off: every discrete leaf equal,
     scores to 1e-4 - the same bar `serve == __call__` is held to."""

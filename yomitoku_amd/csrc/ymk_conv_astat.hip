@@ -9,6 +9,10 @@
 // steps).  References for the layers: models/layers/parseq_transformer.py:188-204 (timm ViT blocks: norm1 -> qkv, norm2 ->
 // fc1), models/dbnet_plus.py:33-38 (ResNet-50 bottlenecks).
 //
+// Round 6: the greedy loop's vocabulary head (EPI_ROWMAX: (max, column) per 64-column sub-tile instead of the tile) runs here too -
+// astat_rowmax folds the accumulators across lanes, one column block per block, a group's row blocks on one XCD
+// (profiles/r06_rowmax_head_tiles.md: 28.2 us per step at 1234 rows against 35.2 on the 128 x 64 tile, 38.8 against 56.3 at 2048).
+//
 // Same arithmetic as conv_f16_dma (ymk_conv_dma.hip): two scaled fp16 planes per fp32 operand, the three MFMAs of a product
 // tile in the same order, the same K order - the results must equal that kernel's bit for bit.  What changes is who waits:
 //   * a block owns 128 rows (4 waves x 32) for ALL column blocks of the layer (or of its column group).  Each wave loads ITS
@@ -20,6 +24,7 @@
 //     sequence over (column block, K tile) - the pipeline does not drain between column blocks;
 //   * a column block's accumulators go out straight from registers, four rows at a time through buffer descriptors; with two
 //     blocks per CU (K = 192 at 128 columns: 255 VGPRs, 48 KB of LDS) the other block's MFMAs cover this one's epilogue.
+#include <atomic>
 #include <string>
 
 #include "ymk_conv_kernel.h"
@@ -97,12 +102,81 @@ __device__ __forceinline__ void astat_store(const ConvK& p, const f32x16 (&acc)[
   }
 }
 
+// EPI_ROWMAX out of the accumulators (BN = 128: two 64-column sub-tiles): every row's (largest scale * acc + bias, its column;
+// ties: lowest column) per sub-tile - the pair table epilogue_tile writes (ymk_conv_kernel.h), from the same expression per
+// value.  Per sub-tile a lane holds 16 candidates, slot r = accumulator row, each the best of its two columns; the 32 lanes of
+// a half-wave then fold them in exchange steps in which a lane keeps HALF of its slots and hands the other half to its partner
+// (xor 16, 8, 4, 2: 8 + 4 + 2 + 1 exchanged pairs, then one more with xor 1: 16 in all instead of 16 x 5), after which lane li
+// holds slot li >> 1, folded over all 32 lanes.  (value, lowest column) is a total order, so the order of the folds is
+// immaterial.  One sub-tile at a time behind a scheduling fence: 32 registers of candidates next to the A planes, not 64.
+__device__ __forceinline__ void astat_fold(float& v, int& c, float ov, int oc) {
+  const bool take = ov > v || (ov == v && oc < c);
+  v = take ? ov : v;
+  c = take ? oc : c;
+}
+
+__device__ __forceinline__ void astat_rowmax(const ConvK& p, const f32x16 (&acc)[4], float inv_sa, int mw, int n0, int li, int lh) {
+  const int ntn = (p.Cout + ROWMAX_TILE_N - 1) / ROWMAX_TILE_N;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float val[16];
+    int col[16];
+    const int c0 = n0 + 64 * j + li, c1 = c0 + 32;
+    const bool ok0 = c0 < p.Cout, ok1 = c1 < p.Cout;
+    const float s0 = (p.scale && ok0) ? p.scale[c0] : 1.f, s1 = (p.scale && ok1) ? p.scale[c1] : 1.f;
+    const float b0 = (p.bias && ok0) ? p.bias[c0] : 0.f, b1 = (p.bias && ok1) ? p.bias[c1] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float best = -INFINITY;
+      int bc = 0x7fffffff;
+      const float v0 = (acc[2 * j][r] * inv_sa) * s0 + b0, v1 = (acc[2 * j + 1][r] * inv_sa) * s1 + b1;
+      if (ok0 && v0 > best) {
+        best = v0;
+        bc = c0;
+      }
+      if (ok1 && v1 > best) {
+        best = v1;
+        bc = c1;
+      }
+      val[r] = best;
+      col[r] = bc;
+    }
+#pragma unroll
+    for (int h = 8; h >= 1; h >>= 1) {      // h slots survive in this lane; partner: lane ^ 2 h
+      const bool up = (li & (2 * h)) != 0;  // this lane keeps slots [h, 2 h) of the 2 h it holds, its partner [0, h)
+#pragma unroll
+      for (int q = 0; q < h; ++q) {
+        const float send_v = up ? val[q] : val[q + h];
+        const int send_c = up ? col[q] : col[q + h];
+        float v = up ? val[q + h] : val[q];
+        int c = up ? col[q + h] : col[q];
+        astat_fold(v, c, __shfl_xor(send_v, 2 * h), __shfl_xor(send_c, 2 * h));
+        val[q] = v;
+        col[q] = c;
+      }
+    }
+    astat_fold(val[0], col[0], __shfl_xor(val[0], 1), __shfl_xor(col[0], 1));
+    // lanes li and li ^ 1 now hold slot (li >> 1) & 15; the even one writes it
+    const int r = (li >> 1) & 15, row = mw + 4 * lh + (r & 3) + 8 * (r >> 2);
+    const int tn = n0 / ROWMAX_TILE_N + j;
+    if ((li & 1) == 0 && row < p.M && tn < ntn) {
+      float2 pr;
+      pr.x = val[0];
+      pr.y = __int_as_float(col[0]);
+      *reinterpret_cast<float2*>(p.out + ((size_t)row * ntn + tn) * 2) = pr;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // 1 x 1, stride 1, no padding (the caller checks); KT = Kpad / 32 K tiles (compile time: the A planes live in registers);
 // BN columns per column block; grid = ceil(M / 128) x column groups (p.ntiles_n column blocks are dealt to gridDim.y groups)
 // LN: the rows are LayerNorm-ed on their way into the planes (p.ln_g / p.ln_b / p.ln_eps over the C = 32 KT channels of a row:
 // a row lives in the two lanes li and li + 32 of its wave, so mean and variance are one xor-shuffle away) - what
 // k_layernorm + this kernel computed through a [M][C] round trip; p.amax is then the LayerNorm's static output bound.
-template <int BN, int KT, bool LN = false>
+// RM (BN = 128): the row-max epilogue above instead of stores (the greedy loop's vocabulary head, EPI_ROWMAX), and a block whose
+// 128 rows all belong to finished groups (p.row_group / p.group_open) returns at once
+template <int BN, int KT, bool LN = false, bool RM = false>
 __global__ __launch_bounds__(256, 2) void conv_f16_astat(ConvK p, const uint4* __restrict__ wsplit, unsigned w_bytes) {
   constexpr int TN = BN / 32;
   constexpr int RG = KT * 16 + TN * 24 <= 160 ? 16 : 4;  // residual values in flight per lane: as many as the registers allow
@@ -115,16 +189,27 @@ __global__ __launch_bounds__(256, 2) void conv_f16_astat(ConvK p, const uint4* _
   const int t = threadIdx.x, wv = t >> 6, lane = t & 63, li = lane & 31, lh = lane >> 5;
   const float2 sc = astat_scales((unsigned)__builtin_amdgcn_readfirstlane((int)amax_read(p.amax, t)));
   const float sa = sc.x, inv_sa = sc.y;
-  int tile_m;
-  {
+  int tile_m, group = (int)blockIdx.y;
+  if constexpr (RM) {
+    // few row blocks, many column groups: the row blocks of ONE group share an XCD (workgroups go to the XCDs round-robin in
+    // x-fastest order), so that an XCD's L2 holds the weights of its ~ gridDim.y / 8 groups and not the whole 5.5 MB panel
+    const int gx = gridDim.x, nblk = gx * (int)gridDim.y, bid = (int)blockIdx.x + gx * (int)blockIdx.y;
+    const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    group = v / gx;
+    tile_m = v - group * gx;
+  } else {
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
     tile_m = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int m0 = tile_m * 128;
+  if constexpr (RM) {
+    if (!tile_needed<128, 256>(p, m0, t)) return;
+  }
   // column blocks of this block: [nb0, nb1)
   const int per = (p.ntiles_n + (int)gridDim.y - 1) / (int)gridDim.y;
-  const int nb0 = (int)blockIdx.y * per, nb1 = min(p.ntiles_n, nb0 + per);
+  const int nb0 = group * per, nb1 = min(p.ntiles_n, nb0 + per);
   if (nb0 >= nb1) return;
 
   // ---- A: the lane's fragments of all KT tiles, loaded once.  MFMA 32x32x16 A operand: row li, k = 8 lh .. + 7 of the step
@@ -268,12 +353,17 @@ __global__ __launch_bounds__(256, 2) void conv_f16_astat(ConvK p, const uint4* _
       stp = stp == NST - 1 ? 0 : stp + 1;
     }
     // ---- this column block's outputs, straight from the accumulators; the stores drain under the next block's MFMAs
-    switch (p.act) {  // block-uniform
-      case ACT_RELU: astat_store<ACT_RELU, TN, RG>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
-      case ACT_GELU: astat_store<ACT_GELU, TN, RG>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
-      case ACT_SILU: astat_store<ACT_SILU, TN, RG>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
-      case ACT_SIGMOID: astat_store<ACT_SIGMOID, TN, RG>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
-      default: astat_store<ACT_NONE, TN, RG>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
+    if constexpr (RM) {
+      static_assert(!RM || TN == 4, "row-max epilogue: 128-column blocks");
+      astat_rowmax(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh);
+    } else {
+      switch (p.act) {  // block-uniform
+        case ACT_RELU: astat_store<ACT_RELU, TN, RG>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
+        case ACT_GELU: astat_store<ACT_GELU, TN, RG>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
+        case ACT_SILU: astat_store<ACT_SILU, TN, RG>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
+        case ACT_SIGMOID: astat_store<ACT_SIGMOID, TN, RG>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
+        default: astat_store<ACT_NONE, TN, RG>(p, acc, inv_sa, m0 + 32 * wv, nb * BN, li, lh, rsrc_o, rsrc_r, am); break;
+      }
     }
 #pragma unroll
     for (int b = 0; b < TN; ++b)
@@ -284,22 +374,30 @@ __global__ __launch_bounds__(256, 2) void conv_f16_astat(ConvK p, const uint4* _
 }
 
 
-template <int BN, int KT, bool LN>
+static std::atomic<int> g_astat_rowmax_dealt{0};  // "rowmax_tile" 4 (A/B runs): the head's column blocks dealt to groups as a store launch's are
+void astat_rowmax_dealt(int on) { g_astat_rowmax_dealt = on; }
+
+template <int BN, int KT, bool LN, bool RM = false>
 static void launch_astat(hipStream_t s, ConvK& k, const void* planes, size_t w_bytes, int groups) {
-  hipLaunchKernelGGL((conv_f16_astat<BN, KT, LN>), dim3((k.M + 127) / 128, groups), dim3(256), 0, s, k, reinterpret_cast<const uint4*>(planes), (unsigned)w_bytes);
+  hipLaunchKernelGGL((conv_f16_astat<BN, KT, LN, RM>), dim3((k.M + 127) / 128, groups), dim3(256), 0, s, k, reinterpret_cast<const uint4*>(planes), (unsigned)w_bytes);
 }
 
 // column width of the launch: 64 where the registers are needed elsewhere - K > 192 (A planes of 7-8 K tiles), a residual at
 // K > 128 (sixteen residual values in flight per lane instead of four: what the K = 192 projection lost to in round 4), a
 // fused LayerNorm (the fp32 staging of a whole row next to its planes) - and for Cout <= 64
-static bool astat_narrow(const ConvK& k) { return k.Kpad > 192 || k.Cout <= 64 || (k.res != nullptr && k.Kpad > 128) || k.ln_g != nullptr; }
+static bool astat_narrow(const ConvK& k) { return k.epi == EPI_ROWMAX ? false : k.Kpad > 192 || k.Cout <= 64 || (k.res != nullptr && k.Kpad > 128) || k.ln_g != nullptr; }
 
 int conv2d_f16_astat_columns(const ConvK& k) { return astat_narrow(k) ? 64 : 128; }
 
 // The launch (conv2d_split routes to it; the caller has set k.scale to the fp16 panels' epilogue scale and k.amax).  A 1 x 1,
 // stride-1, unpadded layer with Kpad <= 256, plain stores, views below 4 GiB; with k.ln_g: C == Kpad.  False = not taken.
 bool conv2d_f16_astat_can(const ConvK& k, size_t w_bytes) {
-  if (k.KH != 1 || k.KW != 1 || k.stride != 1 || k.stride_w != 1 || k.pad != 0 || k.epi != EPI_STORE || k.row_group != nullptr) return false;
+  if (k.KH != 1 || k.KW != 1 || k.stride != 1 || k.stride_w != 1 || k.pad != 0) return false;
+  if (k.epi == EPI_ROWMAX) {  // the pair table instead of the tile: 128-column blocks, K <= 192, nothing else in the epilogue
+    if (k.Kpad > 192 || k.res != nullptr || k.ln_g != nullptr || k.act != ACT_NONE || k.Cout <= 64) return false;
+  } else if (k.epi != EPI_STORE || k.row_group != nullptr) {
+    return false;
+  }
   if (k.Kpad % 32 != 0 || k.Kpad < 32 || k.Kpad > 256 || k.C % 4 != 0 || k.M <= 0) return false;
   if ((size_t)k.M * (size_t)k.out_ld * 4 >= (size_t)OOB_OFFSET || (size_t)k.M * (size_t)k.res_ld * 4 >= (size_t)OOB_OFFSET) return false;
   if (w_bytes >= (size_t)OOB_OFFSET) return false;
@@ -329,8 +427,20 @@ bool conv2d_f16_astat(hipStream_t s, ConvK& k, const void* planes, size_t w_byte
   const int mblocks = (k.M + 127) / 128;
   int groups = 1;
   while (mblocks * groups < 512 && groups * 2 <= k.ntiles_n) groups *= 2;
+  // the row-max head: ONE column block per block (job AE, 655 / 1234 / 2048 rows x 7119 columns: 24.3 / 28.2 / 38.8 us against 33.4 /
+  // 38.1 / 43.8 with two per block) - its blocks are short and latency-bound, the more of them in flight the better
+  if (k.epi == EPI_ROWMAX && !g_astat_rowmax_dealt.load(std::memory_order_relaxed)) groups = k.ntiles_n;
   const int kt = k.Kpad / 32;
-  if (k.ln_g != nullptr) {  // the ViT widths that fit the registers
+  if (k.epi == EPI_ROWMAX) {
+    switch (kt) {
+      case 1: launch_astat<128, 1, false, true>(s, k, planes, w_bytes, groups); break;
+      case 2: launch_astat<128, 2, false, true>(s, k, planes, w_bytes, groups); break;
+      case 3: launch_astat<128, 3, false, true>(s, k, planes, w_bytes, groups); break;
+      case 4: launch_astat<128, 4, false, true>(s, k, planes, w_bytes, groups); break;
+      case 5: launch_astat<128, 5, false, true>(s, k, planes, w_bytes, groups); break;
+      default: launch_astat<128, 6, false, true>(s, k, planes, w_bytes, groups); break;
+    }
+  } else if (k.ln_g != nullptr) {  // the ViT widths that fit the registers
     switch (kt) {
       case 4: launch_astat<64, 4, true>(s, k, planes, w_bytes, groups); break;
       case 6: launch_astat<64, 6, true>(s, k, planes, w_bytes, groups); break;

@@ -174,9 +174,12 @@ __device__ __forceinline__ void epilogue_tile(const ConvK& p, const float* Cs, i
   const int c4 = t % TPR, r0 = t / TPR;
   const int co = n0 + c4 * 4;
   if (p.epi == EPI_ROWMAX) {
-    // every row of the tile -> (max over this tile's columns of scale * acc + bias, its column); the TPR lanes that hold a
-    // row are neighbours in a wave (TPR divides 64), so the row reduction is TPR / 2 .. 1 xor-shuffles; ties: lowest column
-    const int ntn = p.ntiles_n, tn = n0 / BN;
+    // every row of the tile -> (max over a 64-column sub-tile of scale * acc + bias, its column); the G = 16 lanes that hold a
+    // row's sub-tile are neighbours in a wave (G divides TPR divides 64), so the row reduction is G / 2 .. 1 xor-shuffles; ties:
+    // lowest column.  A 128-column tile writes two pairs per row: the table is laid out in 64-column tiles whatever BN is
+    // (launchers only ask it of tiles of whole sub-tiles: BN = 64, 128, 256)
+    constexpr int G = (BN < ROWMAX_TILE_N ? BN : ROWMAX_TILE_N) / 4;
+    const int ntn = (p.Cout + ROWMAX_TILE_N - 1) / ROWMAX_TILE_N, tn = co / ROWMAX_TILE_N;
     for (int row = r0; row < BM; row += RPP) {  // BM % RPP == 0: every lane of a row group takes the same trips
       float best = -INFINITY;
       int bi = 0x7fffffff;
@@ -192,7 +195,7 @@ __device__ __forceinline__ void epilogue_tile(const ConvK& p, const float* Cs, i
         }
       }
 #pragma unroll
-      for (int o = TPR / 2; o > 0; o >>= 1) {
+      for (int o = G / 2; o > 0; o >>= 1) {
         const float ov = __shfl_xor(best, o);
         const int oi = __shfl_xor(bi, o);
         if (ov > best || (ov == best && oi < bi)) {
@@ -201,7 +204,7 @@ __device__ __forceinline__ void epilogue_tile(const ConvK& p, const float* Cs, i
         }
       }
       const int m = m0 + row;
-      if (c4 == 0 && m < p.M) {
+      if ((c4 & (G - 1)) == 0 && m < p.M && co < p.Cout) {
         float2 pr;
         pr.x = best;
         pr.y = __int_as_float(bi);

@@ -725,23 +725,36 @@ static std::atomic<int> g_astat{1};
 // lives in HBM as the two fp16 planes the 3 x 3 multiplies with (written by the reduction's epilogue under a bound, read by
 // LDS-DMA without any conversion: ymk_conv_dma.hip APL) wherever conv_planes_pair_ok allows; 0 = fp32 activations everywhere
 static std::atomic<int> g_act_planes{1};
+// ymk_debug_option("rowmax_tile", v): the kernel of a row-max launch (the greedy loop's vocabulary head) where 128 x 128 tiles fill
+// the chip: 0 = the A-stationary kernel, one column block per block, where it runs (K <= 192: ymk_conv_astat.hip astat_rowmax),
+// else the 128 x 64 x 8-wave tile; for A/B runs 1 = 128 x 128 x 16 waves, 2 = 128 x 128 x 8 waves, 3 = 256 x 128 x 16 waves, 4 = the
+// A-stationary kernel with its column blocks dealt to groups, 6 = 128 x 64 always (rounds 3-5) - the same (max, column) pairs per
+// 64-column sub-tile from each (ymk_conv_kernel.h, EPI_ROWMAX).  profiles/r06_rowmax_head_tiles.md: 35.2 us per step at 1234 rows
+// on 128 x 64, 36.3 / 44.4 / 55.5 on the wider tiles, 38.1 on (4), 28.2 on (0)
+static std::atomic<int> g_rowmax_tile{0};
 // launch counters since the process started (ymk_stat; tests assert that a route was really taken)
-static std::atomic<long long> g_n_astat{0}, g_n_ln_fused{0}, g_n_planes_read{0}, g_n_planes_written{0};
+static std::atomic<long long> g_n_astat{0}, g_n_ln_fused{0}, g_n_planes_read{0}, g_n_planes_written{0}, g_n_rowmax_wide{0};
 long long vit_mlp_fused_launches();
 bool conv_split_stat(const std::string& key, long long* value) {
   if (key == "astat_launches") *value = g_n_astat.load();
   else if (key == "ln_fused_launches") *value = g_n_ln_fused.load();
   else if (key == "planes_read_launches") *value = g_n_planes_read.load();
   else if (key == "planes_written_launches") *value = g_n_planes_written.load();
+  else if (key == "rowmax_wide_launches") *value = g_n_rowmax_wide.load();
   else if (key == "mlp_fused_launches") *value = vit_mlp_fused_launches();
   else return false;
   return true;
 }
+void astat_rowmax_dealt(int on);  // ymk_conv_astat.hip
 bool conv_split_debug_option(const std::string& key, int value) {
   if (key == "conv_split_tile") g_split_tile = value;
   else if (key == "amax_check") g_amax_check = value;
   else if (key == "astat") g_astat = value;
   else if (key == "act_planes") g_act_planes = value;
+  else if (key == "rowmax_tile") {
+    g_rowmax_tile = value;
+    astat_rowmax_dealt(value == 4);
+  }
   else return false;
   return true;
 }
@@ -829,8 +842,11 @@ static SplitRoute route_f16(const RouteQuery& q, int& tile, bool& narrow) {
     few = true;
   }
   if (tile == 0) tile = 3;
-  narrow = q.cout <= 64 || tile == 1 || q.rowmax || few;
-  if (!q.rowmax && q.astat_can && !q.planes_io &&
+  const int rowmax_tile = q.rowmax && auto_tile && !few ? g_rowmax_tile.load(std::memory_order_relaxed) : 0;
+  if (rowmax_tile == 2) tile = 4;
+  if (rowmax_tile == 3) tile = 2;
+  narrow = q.cout <= 64 || tile == 1 || (q.rowmax && (rowmax_tile < 1 || rowmax_tile > 3)) || few;
+  if ((!q.rowmax || ((rowmax_tile == 0 || rowmax_tile == 4) && auto_tile)) && q.astat_can && !q.planes_io &&
       (astat_forced || q.ln || (auto_tile && g_astat.load(std::memory_order_relaxed) != 0 && q.cout > 64 && !few && q.kpad <= 192)))
     return ROUTE_ASTAT;
   if (q.ln) return ROUTE_NONE;
@@ -892,6 +908,7 @@ bool conv2d_split(hipStream_t s, ConvK& k, const ConvW& w, int code, SplitCtx* c
     YMK_HIP(hipGetLastError());
     YMK_CHECK(taken, "conv_f16_astat refused a launch it had accepted");
     ++g_n_astat;
+    if (rowmax) ++g_n_rowmax_wide;
     if (k.ln_g != nullptr) ++g_n_ln_fused;
     return true;
   }
@@ -912,6 +929,7 @@ bool conv2d_split(hipStream_t s, ConvK& k, const ConvW& w, int code, SplitCtx* c
   }
   if (code == SPLIT_F16X2) {
     k.scale = pn.scale;
+    if (rowmax && !narrow) ++g_n_rowmax_wide;
     dispatch_f16(s, k, pn.planes, tile, narrow, ctx);
   } else if (code == 2) {
     dispatch_bf16<2>(s, k, pn.planes, tile, narrow);
