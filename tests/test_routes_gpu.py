@@ -131,7 +131,9 @@ def test_row_max_head_on_every_kernel_it_can_run_on_changes_no_bit(dev):
             wide, astat = _lib.stat("rowmax_wide_launches") - w0, _lib.stat("astat_launches") - a0
             assert (wide == 0) if tile == 6 else (wide >= outs[tile][1]), (tile, wide)
             if tile in (0, 4):
-                assert astat >= outs[6][1] + outs[0][1], (tile, astat)  # the head's launches on top of the encoder's
+                assert astat - astat_other >= outs[tile][1], (tile, astat, astat_other)  # the head's launches on top of the encoder's
+            else:
+                astat_other = astat
     assert outs[6][1] >= 2
     for tile in (0, 1, 2, 3, 4):
         assert outs[tile][1] == outs[6][1] and torch.equal(outs[tile][0], outs[6][0]), tile
