@@ -42,7 +42,7 @@ def test_debug_options_exist_and_their_documented_defaults_agree():
     lib = _lib.load()
     assert lib.ymk_debug_option(b"no_such_option", 1) != 0
     for key, default in (("conv_fast", _lib.CONV_FAST_DEFAULT), ("conv_variant", 0), ("no_splitk", 0), ("splitk_force", -1),
-                         ("conv_split", -1), ("conv_split_tile", 0), ("prof_dump", 0), ("dec_rows", 0), ("parseq_no_rowmax", 0), ("amax_check", 0)):
+                         ("conv_split", -1), ("conv_split_tile", 0), ("prof_dump", 0), ("dec_rows", 0), ("parseq_no_rowmax", 0), ("amax_check", 0), ("rowmax_tile", 0), ("astat", 1), ("act_planes", 1), ("ar_publish", 1)):
         assert lib.ymk_debug_option(key.encode(), default) == 0, key
     src = open(os.path.join(ROOT, "yomitoku_amd", "csrc", "ymk_conv.hip")).read()
     assert int(re.search(r"g_conv_fast\{(\d+)\}", src).group(1)) == _lib.CONV_FAST_DEFAULT
